@@ -1,0 +1,80 @@
+"""ORACLE (test infrastructure only -- never imported by the product path).
+
+CPU restatement of the reference's per-utterance inference orchestration
+(Tester_Enhance.inference, reference tester.py:846-975) on top of miso_oracle /
+mvdr_oracle, with the reference's B = 1 semantics (its batch > 1 path is buggy,
+tester.py:1065 -- see SURVEY.md section 0), plus the STFT / iSTFT contract
+(dataloader/data.py:505-522,540-544; tester.py:979-990,949-952).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import numpy as np
+import scipy.signal
+import torch
+
+from . import miso_oracle, mvdr_oracle
+
+NPERSEG, NOVERLAP, WINDOW = 256, 192, "hann"          # config/NN_BSS.yml:72-88
+SCALE = float(np.sqrt(1.0 / scipy.signal.get_window(WINDOW, NPERSEG).sum() ** 2))   # data.py:497-498 == 1/128
+
+
+def stft_chunk(wav, fs=16000):
+    """wav [L, M] float -> complex64 [M, T, F]: un-normalised one-sided STFT (data.py:505-522,542)."""
+    chans = []
+    for c in range(wav.shape[1]):
+        _, _, z = scipy.signal.stft(wav[:, c], fs=fs, window=WINDOW, nperseg=NPERSEG, noverlap=NOVERLAP)
+        chans.append(z)
+    z = np.stack(chans, axis=0) / SCALE                     # [M,F,T]
+    return np.ascontiguousarray(np.transpose(z, (0, 2, 1))).astype(np.complex64)
+
+
+def istft_int16(spec_tf, fs=16000):
+    """spec [T,F] complex -> int16 [ (T-1)*hop ]  (tester.py:950-952, 979-990): x*scale -> istft -> *32767 -> int16."""
+    x = np.asarray(spec_tf).T * SCALE
+    _, t_sig = scipy.signal.istft(x, fs=fs, window=WINDOW, nperseg=NPERSEG, noverlap=NOVERLAP)
+    return (t_sig * np.iinfo(np.int16).max).astype(np.int16)
+
+
+def miso1_inference(mix, sd1, ref_ch=0):
+    """tester.py:1014-1068 for one utterance.  mix complex [M,T,F] -> complex64 [S,M,T,F] (speaker-aligned
+    across the M circular shifts), plus the selected permutation per shift [M,S]."""
+    mix_t = torch.as_tensor(mix)[None]
+    M = mix_t.shape[1]
+    order = list(np.roll(np.arange(M), -ref_ch))
+    ref = miso_oracle.miso1_forward(torch.roll(mix_t, -ref_ch, dims=1), sd1)[0].numpy()     # [S,T,F]
+    S = ref.shape[0]
+    out = np.empty((S, M) + ref.shape[1:], dtype=np.complex64)
+    sel_all = np.tile(np.arange(S), (M, 1))
+    out[:, ref_ch] = ref
+    for k in order[1:]:
+        est = miso_oracle.miso1_forward(torch.roll(mix_t, -int(k), dims=1), sd1)[0].numpy()
+        sel, _ = mvdr_oracle.pit_select(ref[None], est[None])
+        sel_all[k] = sel[0]
+        for i in range(S):
+            out[i, k] = est[sel[0, i]]
+    return out, sel_all
+
+
+def enhance_utterance(mix, clean, sd1, sd3, ref_ch=0, epsi=1e-6) -> Dict[str, np.ndarray]:
+    """tester.py:865-939 for one utterance / one 4 s split.
+
+    mix   complex [M,T,F]; clean complex [S,T,F] (clean sources at ref_ch, tester.py:889-891)
+    Returns miso1 [S,M,T,F] (after clean alignment), bf [S,T,F], out [S,T,F] (MISO3), sel_clean [S].
+    """
+    est, sel_shift = miso1_inference(mix, sd1, ref_ch)
+    sel, _ = mvdr_oracle.pit_select(np.asarray(clean)[None], est[None, :, ref_ch])       # tester.py:902-915
+    est = est[sel[0]]
+    S = est.shape[0]
+    mix_bf = np.transpose(np.asarray(mix), (2, 0, 1))[None]                                # [1,F,M,T] tester.py:921
+    bf, out = [], []
+    mix_t = torch.as_tensor(np.asarray(mix))[None]
+    for s in range(S):
+        src = np.transpose(est[s], (2, 0, 1))[None]                                        # tester.py:923
+        b = mvdr_oracle.apply_beamforming(src, mix_bf, epsi)                               # [1,T,F]
+        bf.append(b[0])
+        o = miso_oracle.miso3_forward(mix_t, torch.from_numpy(b)[:, None],
+                                      torch.from_numpy(est[s, ref_ch])[None, None], sd3)   # tester.py:937-939,1242
+        out.append(o[0, 0].numpy())
+    return dict(miso1=est, bf=np.stack(bf), out=np.stack(out), sel_clean=sel[0], sel_shift=sel_shift)

@@ -1,0 +1,45 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def rel_l2(a, b):
+    a = np.asarray(a); b = np.asarray(b)
+    return float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-30))
+
+
+def mag_parity(x_hat, x, tol=1e-3):
+    """SURVEY.md 8(d) parity metric on complex-spectrogram magnitudes.
+
+    Returns (rel_l2 of magnitudes, fraction of bins violating | |x^|-|x| | <= tol*|x| + tol*median|x|)."""
+    mh, m = np.abs(np.asarray(x_hat)), np.abs(np.asarray(x))
+    r = float(np.linalg.norm((mh - m).ravel()) / max(np.linalg.norm(m.ravel()), 1e-30))
+    bad = np.abs(mh - m) > tol * m + tol * np.median(m)
+    return r, float(bad.mean())
+
+
+@pytest.fixture(scope="session")
+def sd1():
+    from misonet_amd import weights as W
+    return W.make_state_dict(W.miso1_spec(), seed=0)
+
+
+@pytest.fixture(scope="session")
+def sd3():
+    from misonet_amd import weights as W
+    return W.make_state_dict(W.miso3_spec(), seed=1)

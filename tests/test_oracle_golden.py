@@ -1,0 +1,93 @@
+"""Pin the oracle (oracle/*.py) against vectors produced by the real reference (oracle/gen_golden.py).
+CPU only.  Tolerances: the restatement calls the same ATen/LAPACK back-ends as the reference, so agreement
+is at float32 round-off (1e-5 relative), far inside the 1e-3 parity budget of the GPU path."""
+import numpy as np
+import torch
+
+from conftest import golden, rel_l2, mag_parity
+from oracle import miso_oracle, mvdr_oracle, pipeline_oracle
+
+
+def test_weight_spec_counts(sd1, sd3):
+    # 268 tensors, 2,587,384 / 2,587,382 parameters
+    assert len(sd1) == 268 and len(sd3) == 268
+    assert sum(v.size for v in sd1.values()) == 2587384
+    assert sum(v.size for v in sd3.values()) == 2587382
+    assert sd3["encoders.0.0.conv2d.weight"].shape == (24, 16, 3, 3)
+    assert sd3["decoders.6.1.deconv2d.weight"].shape == (48, 2, 3, 3)
+
+
+def test_g1_miso1_forward_and_taps(sd1):
+    for T in (32, 96):
+        g = golden(f"g1_miso1_T{T}.npz")
+        taps = {}
+        y = miso_oracle.miso1_forward(torch.from_numpy(g["x"]), sd1, taps).numpy()
+        assert y.dtype == np.complex64 and y.shape == (1, 2, T, 129)
+        assert rel_l2(y, g["y"]) < 2e-5
+        if T == 32:
+            n = 0
+            for k in g.files:
+                if not k.startswith("tap_"):
+                    continue
+                v = taps[k[4:]].numpy()
+                if v.size > 60000:
+                    v = v[:, ::4]
+                assert v.shape == g[k].shape, k
+                assert rel_l2(v, g[k]) < 2e-5, k
+                n += 1
+            assert n >= 16
+
+
+def test_g3_miso3_forward(sd3):
+    g = golden("g3_miso3_T32.npz")
+    y = miso_oracle.miso3_forward(torch.from_numpy(g["x"]), torch.from_numpy(g["a"]), torch.from_numpy(g["b"]), sd3)
+    assert rel_l2(y.numpy(), g["y"]) < 2e-5
+
+
+def test_g4_miso1_inference(sd1):
+    g = golden("g4_miso1_inference_T32.npz")
+    est, sel = pipeline_oracle.miso1_inference(g["x"][0], sd1, ref_ch=0)
+    assert rel_l2(est[0], g["spk0"][0]) < 2e-5
+    assert rel_l2(est[1], g["spk1"][0]) < 2e-5
+    assert sel.shape == (6, 2)
+
+
+def test_g5_mvdr_parts():
+    g = golden("g5_mvdr.npz")
+    p = mvdr_oracle.mvdr_parts(g["src"], g["mix"])
+    assert rel_l2(p["scm_n"], g["scm_n"]) < 1e-5
+    assert rel_l2(p["steer0"], g["steer0"]) < 1e-4
+    assert rel_l2(p["steer1"], g["steer1"]) < 1e-4
+    assert rel_l2(p["w"], g["w"]) < 1e-4
+    assert rel_l2(p["out"], g["out"]) < 1e-4
+    # double-precision evaluation of the same algebra stays within the complex64 noise of the reference
+    p64 = mvdr_oracle.mvdr_parts(g["src"], g["mix"], dtype=np.complex128)
+    assert rel_l2(p64["out"], g["out"]) < 1e-4
+
+
+def test_g6_pipeline(sd1, sd3):
+    g = golden("g6_pipeline_T64.npz")
+    from misonet_amd.weights import synthetic_utterance
+    obs, s0, s1 = synthetic_utterance(int(g["utt"]), 63 * 64)
+    mix = pipeline_oracle.stft_chunk(obs)
+    clean = np.stack([pipeline_oracle.stft_chunk(s0)[0], pipeline_oracle.stft_chunk(s1)[0]])
+    r = pipeline_oracle.enhance_utterance(mix, clean, sd1, sd3, ref_ch=0)
+    assert rel_l2(r["miso1"][:, 0], g["miso1_ref"]) < 5e-5
+    assert rel_l2(r["bf"], g["bf"]) < 5e-4
+    rl2, bad = mag_parity(r["out"], g["out"])
+    assert rl2 < 2e-4 and bad < 1e-3
+    # G7: iSTFT -> int16 (tester.py:949-952).  Truncation makes +-1 LSB flips possible at round-off level.
+    for s in range(2):
+        w = pipeline_oracle.istft_int16(r["out"][s])
+        assert w.shape == g[f"wav{s}"].shape == (63 * 64,)
+        assert np.max(np.abs(w.astype(np.int32) - g[f"wav{s}"].astype(np.int32))) <= 2
+
+
+def test_g8_sample_clean_config1(sd1):
+    """BASELINE.json configs[0]: first 4 s of sample/Clean (8 kHz, 6 mics) through one MISO_1 forward."""
+    g = golden("g8_sample_clean_miso1.npz")
+    x = pipeline_oracle.stft_chunk(g["obs_wav_f16"].astype(np.float32), 8000)[None]
+    assert x.shape == (1, 6, 501, 129)
+    y = miso_oracle.miso1_forward(torch.from_numpy(x), sd1).numpy()
+    assert rel_l2(y[:, :, 200:232], g["y_slice"]) < 5e-5
+    assert rel_l2(np.abs(y).sum(-1), g["mag_sum_per_frame"]) < 2e-5
