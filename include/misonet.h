@@ -1,0 +1,121 @@
+/*
+ * misonet.h -- C ABI of libmisonet_hip.so: the MI355X (gfx950) MISO1 -> MVDR -> MISO3 inference path.
+ *
+ * The reference (yuhogun0908/MISOnet) is pure Python and has no FFI layer; its boundary for this
+ * path is the Python call surface named in SURVEY.md 8(b).  Each entry point below states the
+ * reference interface it replaces (file:line into the reference tree).  All pointers named *_dev are
+ * device pointers owned by the caller (e.g. torch tensors); the library allocates device memory only
+ * in *_commit (weights).  Every call is asynchronous on the given HIP stream unless stated.  Return
+ * value: 0 = success, negative = error (misonet_strerror / misonet_last_error).  One handle per
+ * device; a handle is not re-entrant.
+ *
+ * Spectrogram layout at this boundary is the reference's: complex64 (interleaved re,im float32),
+ * [B, channels, T frames, F = 129 bins], F innermost (model.py:77-80, tester.py:1025).
+ */
+#ifndef MISONET_H_
+#define MISONET_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct misonet_net misonet_net;
+typedef struct misonet_pipeline misonet_pipeline;
+typedef void* misonet_stream;           /* hipStream_t */
+
+enum {
+  MISONET_OK = 0,
+  MISONET_EINVAL = -1,        /* bad argument / unsupported geometry */
+  MISONET_ESTATE = -2,        /* call order (e.g. forward before commit, missing tensor) */
+  MISONET_EHIP = -3,          /* a HIP runtime call failed */
+  MISONET_ENOMEM = -4,        /* workspace too small */
+  MISONET_ENAN = -5           /* NaN in a network output (the reference drops into pdb, model.py:109-110) */
+};
+
+/* Geometry of one MISO trunk.  Mirrors the constructor arguments of MISO_1 / MISO_3
+ * (model.py:9, 283): in_ch = 2*num_ch (MISO_1, model.py:16) or 2*(num_ch+2) (MISO_3, model.py:290);
+ * out_ch = 2*num_spks (model.py:17); en_ch / de_ch = en/de_bottleneck_channels (config/NN_BSS.yml:120-123). */
+typedef struct {
+  int in_ch;
+  int out_ch;
+  int en_ch[7];
+  int de_ch[7];
+  int n_freq;                 /* must be 129 (nperseg 256): the encoder must reduce F to one bin */
+} misonet_cfg;
+
+const char* misonet_strerror(int code);
+const char* misonet_last_error(void);   /* thread-local detail of the last failing call */
+int misonet_version(void);
+
+/* ---- network handle: replaces nn.Module construction + load_state_dict (run.py:121-151) --------------- */
+int misonet_net_create(const misonet_cfg* cfg, misonet_net** out);
+int misonet_net_destroy(misonet_net* net);
+/* the state_dict this network expects: the reference's key names (268 tensors for the default cfg) */
+int misonet_net_num_tensors(const misonet_net* net);
+const char* misonet_net_tensor_name(const misonet_net* net, int i);
+long long misonet_net_tensor_numel(const misonet_net* net, int i);
+/* host float32 data of one state_dict entry (load_state_dict, run.py:139-151) */
+int misonet_net_set_tensor(misonet_net* net, const char* key, const float* host_data, long long numel);
+/* all tensors set -> repack into the kernel layouts and upload to the current device (synchronous) */
+int misonet_net_commit(misonet_net* net);
+
+/* workspace (device bytes) for n_samples spectrograms of n_frames frames */
+long long misonet_net_workspace_bytes(const misonet_net* net, int n_samples, int n_frames);
+
+/* MISO_1.forward(mixture) (model.py:76-111) and MISO_3.forward(mixture, a, b) (model.py:350-395).
+ * The input is given as n_seg channel segments, each complex64 [B, seg_ch[i], T, F]; their real parts are
+ * concatenated in order, then their imaginary parts (model.py:80 / 360-364).  MISO_1: one segment (mixture);
+ * MISO_3: three (mixture, a, b).  out_dev: complex64 [B, out_ch/2, T, F]. */
+int misonet_net_forward(misonet_net* net, int n_seg, const void* const* seg_dev, const int* seg_ch,
+                        int B, int T, void* out_dev, void* ws_dev, long long ws_bytes, misonet_stream stream);
+/* synchronises the stream and reports MISONET_ENAN if the last forward on this workspace produced a NaN */
+int misonet_net_check(misonet_net* net, const void* ws_dev, misonet_stream stream);
+
+/* test/diagnostic taps: copy an intermediate activation of the LAST forward (still in ws_dev) out as float32
+ * [B, C, T, F] in the reference's layout and normalisation.  Names: enc0_conv, enc0..enc6, tcn_out, dec0..dec6. */
+int misonet_net_tap_shape(const misonet_net* net, const char* name, int* C, int* F);
+int misonet_net_tap(misonet_net* net, const char* name, const void* ws_dev, int B, int T, float* dst_dev,
+                    misonet_stream stream);
+
+/* ---- MVDR: Tester_Enhance.Apply_Beamforming(source_stft, mix_stft, epsi) (tester.py:1071-1136) ---------- */
+/* src_dev, mix_dev: complex64 [B, F, M, T] contiguous (the reference passes permuted views, tester.py:921-923);
+ * out_dev: complex64 [B, T, F] (tester.py:1134).  M <= 8. */
+long long misonet_mvdr_workspace_bytes(int B, int F, int M);
+int misonet_mvdr(const void* src_dev, const void* mix_dev, int B, int F, int M, int T, float epsi,
+                 void* out_dev, void* ws_dev, long long ws_bytes, misonet_stream stream);
+/* diagnostic: after misonet_mvdr, copy steering vectors (after phase correction) and beamformer weights,
+ * both complex128 [B,F,M], to device buffers (either may be NULL) */
+int misonet_mvdr_debug(const void* ws_dev, int B, int F, int M, void* steer_c128_dev, void* w_c128_dev,
+                       misonet_stream stream);
+
+/* ---- PIT speaker alignment (tester.py:1043-1065 and 889-915) ----------------------------------------------- */
+/* anchor_dev, cand_dev: complex64 [B, S, T, F]; sel_dev: int32 [B, S] with aligned speaker i = cand[sel[i]];
+ * dist_dev (may be NULL): float64 [B, S, S], dist[i][j] = sum_{t,f} | |anchor_i| - |cand_j| |.  S must be 2. */
+int misonet_pit_select(const void* anchor_dev, const void* cand_dev, int B, int S, int T, int F,
+                       int* sel_dev, double* dist_dev, misonet_stream stream);
+
+/* ---- fused on-device pipeline: the body of Tester_Enhance.inference (tester.py:865-939) -------------------- */
+/* MISO1_Inference (6 circular shifts batched as 6B forwards, tester.py:1014-1068) -> clean-reference
+ * alignment (tester.py:889-915; skipped when clean_dev == NULL) -> MVDR per speaker (tester.py:917-924) ->
+ * MISO3 per speaker (tester.py:936-939).  Everything stays in HBM in the kernels' own layout. */
+int misonet_pipeline_create(misonet_net* miso1, misonet_net* miso3, int num_mic, int num_spk, int ref_ch,
+                            float epsi, misonet_pipeline** out);
+int misonet_pipeline_destroy(misonet_pipeline* p);
+long long misonet_pipeline_workspace_bytes(const misonet_pipeline* p, int B, int T);
+/* mix_dev complex64 [B,M,T,F]; clean_dev complex64 [B,S,T,F] or NULL; out_dev complex64 [B,S,T,F] (MISO3);
+ * optional outputs (may be NULL): bf_dev complex64 [B,S,T,F] (MVDR), miso1_dev complex64 [B,S,M,T,F] (aligned). */
+int misonet_pipeline_run(misonet_pipeline* p, const void* mix_dev, const void* clean_dev, int B, int T,
+                         void* out_dev, void* bf_dev, void* miso1_dev, void* ws_dev, long long ws_bytes,
+                         misonet_stream stream);
+int misonet_pipeline_check(misonet_pipeline* p, const void* ws_dev, misonet_stream stream);
+
+/* ---- timing helper: HIP events on the caller's stream (bench.py roofline leg) ------------------------------- */
+int misonet_event_create(void** ev);
+int misonet_event_record(void* ev, misonet_stream stream);
+int misonet_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises on stop */
+int misonet_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MISONET_H_ */

@@ -1,0 +1,108 @@
+// Internal declarations shared by the HIP translation units of libmisonet_hip.so (gfx950 only).
+//
+// Activation layout in HBM ("planar"): float32 [n][c][f][Tp], frames (t) innermost, Tp = T rounded up to 32 so
+// every row starts 128-byte aligned.  Conv outputs are stored RAW (bias + ELU applied, instance norm NOT applied);
+// each producer accumulates per-(n,c) sum / sum-of-squares in float64 next to the buffer and every consumer
+// normalises while it stages its input tile into LDS ("normalise on load").  Dense-block concatenation is free:
+// a block's tensors are channel slices of one buffer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mn {
+
+constexpr int CK = 8;       // input channels per K-chunk of the implicit GEMM
+constexpr int TT = 128;     // output frames per workgroup (4 MFMA column tiles of 32)
+constexpr int TW = 136;     // staged frames per input row: [t0-4, t0+132) -> 34 aligned float4
+constexpr int FT = 4;       // output rows (frequency bins) per workgroup = waves per workgroup
+constexpr float IN_EPS = 1e-5f;    // nn.InstanceNorm{1,2}d default eps (reference model.py:413,579)
+constexpr float GLN_EPS = 1e-8f;   // reference model.py:6
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+inline int frames_pitch(int T) { return round_up(T, 32); }
+
+// ---- 3x3 convolution family (reference model.py:401-482), one launch per layer ------------------------------
+struct ConvArgs {
+  const float* in;          // planar buffer base
+  const double* in_stats;   // [n][in_sstride][2] (sum, sumsq) or nullptr when every input channel is identity
+  float* out;
+  double* out_stats;        // [n][out_sstride][2], accumulated with atomics when act != 0
+  const float* w;           // packed [ncg][nchunk][9][CK][COP]
+  const float* bias;        // [ncg*COP]
+  long long in_bstride;     // floats per sample of the input buffer
+  long long out_bstride;
+  int in_sstride, out_sstride;   // channels per sample in the stats arrays (= channels of the whole buffer)
+  int in_c0, Cin, Fin;
+  int ident_c;              // input channels [0, ident_c) are consumed as they are (no instance norm)
+  int out_c0, Cout, Fout;
+  int T, Tp;
+  int sf;                   // frequency stride of a forward conv (1 or 2)
+  int padf;                 // frequency zero padding of the conv form (0, 1, or 2 for a stride-1 transposed conv)
+  int tr2;                  // 1: stride-2 transposed conv (fin = (f + kf - 2) / 2 when even)
+  int act;                  // 1: ELU + statistics for the following instance norm; 0: raw output
+  int NR;                   // staged input rows per workgroup
+  int ncg;                  // output-channel groups (grid.z = n_samples * ncg)
+  int cop;                  // 32 or 64 output channels per group
+};
+int conv_cop(int Cout);                      // 32 (Cout <= 32) or 64
+int conv_rows(int sf, int tr2);              // NR for the mode
+hipError_t launch_conv(const ConvArgs& a, int n_samples, hipStream_t s);
+hipError_t conv_init();                      // dynamic-LDS attributes
+
+// ---- TCN (reference model.py:486-632) -----------------------------------------------------------------------------
+// x0 = IN2d(raw) materialised as the residual stream + its per-(n,c) statistics
+hipError_t launch_tcn_prepare(const float* raw, long long raw_bstride, int raw_c0, const double* raw_stats, int raw_sstride,
+                              float* x, double* x_stats, int C, int T, int Tp, int n_samples, hipStream_t s);
+// d = PReLU(dwconv_dilated(ELU(IN1d(x)))) ; accumulates gLN statistics (per sample) of d
+hipError_t launch_tcn_dw(const float* x, const double* x_stats, const float* wdw /*[C][3]*/, const float* prelu /*[1]*/,
+                         float* d, double* gln_stats /*[n][2]*/, int C, int T, int Tp, int dilation, int n_samples, hipStream_t s);
+// y = pwconv(gLN(d)) (+ residual) ; accumulates IN statistics of y
+hipError_t launch_tcn_pw(const float* d, const double* gln_stats, const float* gamma, const float* beta,
+                         const float* wpw /*packed [C/CK... see tcn.hip]*/, const float* residual /*or nullptr*/,
+                         float* y, long long y_bstride, int y_c0, double* y_stats /*[n][C][2]*/, int C, int T, int Tp,
+                         int n_samples, hipStream_t s);
+
+// ---- layout conversion ----------------------------------------------------------------------------------------
+// complex64 [B][Mseg][T][F] -> planar real/imag channel planes; optional circular mic shifts (tester.py:1034,1050):
+// destination sample n = b*nshift + k receives source channel (m + k) % Mseg at destination channel m.
+hipError_t launch_pack(const float2* src, int B, int Mseg, int T, int F, float* dst, long long dst_bstride, int Tp,
+                       int c_re, int c_im, int nshift, hipStream_t s);
+// planar [n][2S][F][Tp] -> complex64 [n][S][T][F]; sets *nan_flag when a NaN is seen (model.py:109-110)
+hipError_t launch_unpack(const float* src, long long src_bstride, int Tp, int S, int T, int F, float2* dst, int n_samples,
+                         int* nan_flag, hipStream_t s);
+// planar view (+ optional instance norm) -> float32 [n][C][T][F]  (diagnostic taps)
+hipError_t launch_export(const float* src, long long src_bstride, int c0, int C, int Fq, int T, int Tp,
+                         const double* stats, int sstride, int ident_c, float* dst, int n_samples, hipStream_t s);
+
+// ---- MVDR + PIT -------------------------------------------------------------------------------------------------
+// Accessor for a multichannel complex STFT with frames contiguous: element (b, f, m, t) =
+//   re[b*sb + f*sf + m*sm + t*st], im likewise.  Interleaved complex64 [B,F,M,T]: re=base, im=base+1, st=2.
+struct CView {
+  const float* re; const float* im;
+  long long sb, sf, sm; int st;
+};
+struct MvdrArgs {
+  CView mix;              // observation Y
+  const float* est;       // planar MISO1 output buffer [B*M][2S][F][Tp] (pipeline mode) or nullptr
+  long long est_bstride;  // floats per sample
+  const int* sel;         // [B][M][S]: estimated-speaker index to use for (b, mic m, aligned speaker j), or nullptr
+  CView src;              // source estimate S when est == nullptr (drop-in mode)
+  int S;                  // speakers handled per utterance (grid.z)
+  int B, F, M, T, Tp;
+  float epsi;
+};
+long long mvdr_ws_bytes(int B, int S, int F, int M);
+// out: complex, element (b, spk, t, f) at out_re[b*ob + spk*os + t*ot + f*of]
+struct COut { float* re; float* im; long long ob, os, ot, of; };
+hipError_t launch_mvdr(const MvdrArgs& a, const COut& out, void* ws, hipStream_t s);
+hipError_t launch_mvdr_debug(const void* ws, int B, int S, int F, int M, double* steer, double* w, hipStream_t s);
+
+// dist[b][i][j] = sum_{t,f} | |A_i| - |B_j| | for S = 2, accumulated in float64 with atomics; then sel.
+struct PitArgs {
+  CView a, b;             // sm = speaker stride here; (b, f, spk, t) addressing
+  int B, F, T;
+};
+hipError_t launch_pit_dist(const PitArgs& p, double* dist /*[B][2][2], pre-zeroed*/, hipStream_t s);
+hipError_t launch_pit_pick(const double* dist, int B, int* sel /*[B][2]*/, hipStream_t s);
+
+}  // namespace mn

@@ -1,0 +1,745 @@
+// Host runtime of libmisonet_hip.so: layer plan of a MISO trunk (reference model.py:8-111 / 282-395), weight
+// repacking into the kernels' layouts, workspace layout, forward scheduling, and the C ABI of include/misonet.h.
+#include "kernels.hpp"
+#include "../../include/misonet.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+namespace mn {
+hipError_t launch_unpack_ex(const float* src, int Cbuf, int Tp, int S, int T, int F, int c_re0, int c_im0, int mode,
+                            int M, const int* sel, float2* dst, int n_out, int* nan_flag, hipStream_t s);
+hipError_t launch_pit_dist_k(const PitArgs& p, int K, double* dist, hipStream_t s);
+hipError_t launch_compose_sel(const int* shift_sel, const int* clean_sel, int B, int M, int S, int* out, hipStream_t s);
+hipError_t launch_assemble3(const float* in1, long long in1_bstride, const float* out1, long long out1_bstride,
+                            const int* sel, int B, int M, int S, int ref_ch, int F, int Tp, float* in3,
+                            long long in3_bstride, hipStream_t s);
+}  // namespace mn
+
+using namespace mn;
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIPCHK(expr)                                                                                    \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess) return fail(MISONET_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------------------------
+struct Tensor {
+  std::string name;
+  long long numel;
+  std::vector<float> host;
+  bool set = false;
+};
+
+enum { B_IN = 0, B_E0, B_E1, B_E2, B_E3, B_E4, B_D0, B_D1, B_D2, B_D3, B_D4, B_D5, B_D6, B_X2, B_X3, B_X4, B_X5, B_X6,
+       B_OUT, B_TXA, B_TXB, B_TD, B_TP, NBUF };
+
+struct BufSpec { int C = 0, F = 0; };
+
+struct ConvL {
+  int in_buf, in_c0, Cin, ident_c;
+  int out_buf, out_c0, Cout;
+  int sf, padf, tr2, act;
+  bool transposed;
+  int wt, bt;                   // tensor indices
+  int cop, ncg;
+  long long w_off = 0, b_off = 0;   // offsets (floats) into the device weight arena
+};
+
+struct TcnHalf { int dw, prelu, gamma, beta, pw; long long o_dw, o_prelu, o_gamma, o_beta, o_pw; };
+struct TcnBlock { int dilation; TcnHalf h[2]; };
+
+struct Tap { std::string name; int buf, c0, C; bool normalised; };
+
+struct Layout {
+  int N, T, Tp;
+  long long data_off[NBUF];      // floats
+  long long stats_off[NBUF];     // doubles
+  long long tcn_xs, tcn_ps, tcn_gln;   // doubles: [15][N*128*2], [14][N*128*2], [28][N*2]
+  long long stats_doubles;
+  long long data_base;           // bytes from ws start to the float arena
+  long long total_bytes;
+};
+
+struct misonet_net {
+  misonet_cfg cfg;
+  int S;                         // speakers out = out_ch / 2
+  BufSpec bufs[NBUF];
+  std::vector<Tensor> tensors;
+  std::vector<ConvL> enc, dec;
+  std::vector<TcnBlock> tcn;
+  std::vector<Tap> taps;
+  float* w_dev = nullptr;
+  bool committed = false;
+};
+
+static int find_tensor(const misonet_net* n, const std::string& name) {
+  for (size_t i = 0; i < n->tensors.size(); ++i)
+    if (n->tensors[i].name == name) return (int)i;
+  return -1;
+}
+static int add_tensor(misonet_net* n, const std::string& name, long long numel) {
+  Tensor t;
+  t.name = name;
+  t.numel = numel;
+  n->tensors.push_back(t);
+  return (int)n->tensors.size() - 1;
+}
+
+static ConvL make_conv(misonet_net* n, const std::string& prefix, int in_buf, int in_c0, int Cin, int ident_c, int out_buf,
+                       int out_c0, int Cout, int sf, int padf, bool transposed, int act) {
+  ConvL L;
+  L.in_buf = in_buf; L.in_c0 = in_c0; L.Cin = Cin; L.ident_c = ident_c;
+  L.out_buf = out_buf; L.out_c0 = out_c0; L.Cout = Cout;
+  L.transposed = transposed;
+  L.act = act;
+  if (transposed) {
+    L.tr2 = (sf == 2);
+    L.sf = 1;
+    L.padf = 2;          // stride-1 transposed conv == conv with flipped taps and full padding
+  } else {
+    L.tr2 = 0; L.sf = sf; L.padf = padf;
+  }
+  L.wt = add_tensor(n, prefix + ".weight", (long long)Cin * Cout * 9);
+  L.bt = add_tensor(n, prefix + ".bias", Cout);
+  L.cop = conv_cop(Cout);
+  L.ncg = (Cout + L.cop - 1) / L.cop;
+  return L;
+}
+
+// DenseBlock(init_ch, g1, g2) on buffer `buf` ([x | y0..y3]); y4 -> (out_buf, out_c0)   (model.py:437-482)
+static void add_dense(misonet_net* n, std::vector<ConvL>& v, const std::string& prefix, int buf, int init_ch, int g1, int g2,
+                      int ident_c, int out_buf, int out_c0) {
+  for (int i = 0; i < 5; ++i) {
+    const int cin = init_ch + i * g1;
+    char nm[64];
+    snprintf(nm, sizeof(nm), ".conv%d.0", i + 1);
+    if (i < 4)
+      v.push_back(make_conv(n, prefix + nm, buf, 0, cin, ident_c, buf, cin, g1, 1, 1, false, 1));
+    else
+      v.push_back(make_conv(n, prefix + nm, buf, 0, cin, ident_c, out_buf, out_c0, g2, 1, 1, false, 1));
+  }
+}
+
+static int freq_after_conv(int F, int sf) { return (F - 3) / sf + 1; }
+
+static int build_plan(misonet_net* n) {
+  const misonet_cfg& c = n->cfg;
+  if (c.n_freq != 129) return fail(MISONET_EINVAL, "n_freq must be 129 (got %d): the encoder must reduce F to one bin", c.n_freq);
+  if (c.in_ch < 2 || c.in_ch % 2 || c.out_ch < 2 || c.out_ch % 2 || c.in_ch > 64 || c.out_ch > 32)
+    return fail(MISONET_EINVAL, "in_ch/out_ch must be even and small (got %d/%d)", c.in_ch, c.out_ch);
+  for (int i = 0; i < 7; ++i) {
+    if (c.en_ch[i] <= 0 || c.en_ch[i] % 8 || c.de_ch[i] <= 0 || c.de_ch[i] % 8)
+      return fail(MISONET_EINVAL, "bottleneck channels must be positive multiples of 8");
+    if (c.en_ch[6 - i] != c.de_ch[i])
+      return fail(MISONET_EINVAL, "U-Net skip concat needs en_ch[6-i] == de_ch[i] (model.py:35,99)");
+  }
+  if (c.en_ch[6] != 128) return fail(MISONET_EINVAL, "the TCN is TemporalConvNet(2,7,128,128,128) (model.py:31): en_ch[6] must be 128");
+  for (int i = 0; i < 7; ++i)
+    if (c.en_ch[i] > 128) return fail(MISONET_EINVAL, "channel counts above 128 are not supported");
+  n->S = c.out_ch / 2;
+  const int* en = c.en_ch;
+  const int* de = c.de_ch;
+  // frequency sizes per encoder level (model.py:40-54): F_e[b] = output bins of encoder b
+  int Fe[7];
+  Fe[0] = freq_after_conv(c.n_freq, 1);
+  for (int b = 1; b < 7; ++b) Fe[b] = freq_after_conv(Fe[b - 1], b == 6 ? 1 : 2);
+  if (Fe[6] != 1) return fail(MISONET_EINVAL, "encoder does not reduce to one frequency bin");
+  // buffers
+  n->bufs[B_IN] = {c.in_ch, c.n_freq};
+  for (int b = 0; b < 5; ++b) n->bufs[B_E0 + b] = {5 * en[b], Fe[b]};
+  n->bufs[B_D0] = {2 * de[0], Fe[6]};
+  n->bufs[B_D1] = {2 * de[1], Fe[5]};
+  for (int i = 2; i < 7; ++i) {
+    n->bufs[B_D0 + i] = {6 * de[i], Fe[6 - i]};
+    n->bufs[B_X2 + (i - 2)] = {2 * de[i], Fe[6 - i]};
+  }
+  n->bufs[B_OUT] = {c.out_ch, c.n_freq};
+  for (int b = B_TXA; b <= B_TP; ++b) n->bufs[b] = {128, 1};
+
+  // ---- encoders (model.py:40-54); xs[b] is written straight into decoder buffer D[6-b] at channel de[6-b] ----
+  char nm[96];
+  for (int b = 0; b < 7; ++b) {
+    const int skip_buf = B_D0 + (6 - b), skip_c0 = de[6 - b];
+    const int src_buf = (b == 0) ? B_IN : B_D0 + (7 - b);
+    const int src_c0 = (b == 0) ? 0 : de[7 - b];
+    const int cin = (b == 0) ? c.in_ch : en[b - 1];
+    if (b == 0) {
+      n->enc.push_back(make_conv(n, "encoders.0.0.conv2d", B_IN, 0, cin, cin, B_E0, 0, en[0], 1, 0, false, 0));
+      add_dense(n, n->enc, "encoders.0.1", B_E0, en[0], en[0], en[0], en[0], skip_buf, skip_c0);
+    } else if (b < 5) {
+      snprintf(nm, sizeof(nm), "encoders.%d.0.net.0", b);
+      n->enc.push_back(make_conv(n, nm, src_buf, src_c0, cin, 0, B_E0 + b, 0, en[b], 2, 0, false, 1));
+      snprintf(nm, sizeof(nm), "encoders.%d.1", b);
+      add_dense(n, n->enc, nm, B_E0 + b, en[b], en[b], en[b], 0, skip_buf, skip_c0);
+    } else {
+      snprintf(nm, sizeof(nm), "encoders.%d.0.net.0", b);
+      n->enc.push_back(make_conv(n, nm, src_buf, src_c0, cin, 0, skip_buf, skip_c0, en[b], b == 6 ? 1 : 2, 0, false, 1));
+    }
+  }
+  // ---- decoders (model.py:56-73) ----
+  for (int i = 0; i < 7; ++i) {
+    const int buf = B_D0 + i;
+    const int cin = 2 * de[i];
+    const int cout = (i == 6) ? c.out_ch : de[i + 1];
+    const int obuf = (i == 6) ? B_OUT : B_D0 + i + 1;
+    if (i >= 2) {
+      snprintf(nm, sizeof(nm), "decoders.%d.0", i);
+      add_dense(n, n->dec, nm, buf, cin, cin / 2, cin, 0, B_X2 + (i - 2), 0);
+      snprintf(nm, sizeof(nm), i == 6 ? "decoders.%d.1.deconv2d" : "decoders.%d.1.net.0", i);
+      n->dec.push_back(make_conv(n, nm, B_X2 + (i - 2), 0, cin, 0, obuf, 0, cout, i == 6 ? 1 : 2, 0, true, i == 6 ? 0 : 1));
+    } else {
+      snprintf(nm, sizeof(nm), "decoders.%d.0.net.0", i);
+      // decoder 0 consumes [TCN output (raw, identity) | xs[6] (instance-normalised)]
+      n->dec.push_back(make_conv(n, nm, buf, 0, cin, i == 0 ? de[0] : 0, obuf, 0, cout, i == 0 ? 1 : 2, 0, true, 1));
+    }
+  }
+  // ---- TCN (model.py:486-567) ----
+  for (int r = 0; r < 2; ++r)
+    for (int x = 0; x < 7; ++x) {
+      TcnBlock tb;
+      tb.dilation = 1 << x;
+      for (int h = 0; h < 2; ++h) {
+        snprintf(nm, sizeof(nm), "TCN.temporal_conv_net.%d.%d.net.%d.net", r, x, h == 0 ? 2 : 5);
+        const std::string p(nm);
+        tb.h[h].dw = add_tensor(n, p + ".0.weight", 128 * 3);
+        tb.h[h].prelu = add_tensor(n, p + ".1.weight", 1);
+        tb.h[h].gamma = add_tensor(n, p + ".2.gamma", 128);
+        tb.h[h].beta = add_tensor(n, p + ".2.beta", 128);
+        tb.h[h].pw = add_tensor(n, p + ".3.weight", 128 * 128);
+      }
+      n->tcn.push_back(tb);
+    }
+  // ---- taps ----
+  n->taps.push_back({"enc0_conv", B_E0, 0, en[0], false});
+  for (int b = 0; b < 7; ++b) {
+    snprintf(nm, sizeof(nm), "enc%d", b);
+    n->taps.push_back({nm, B_D0 + (6 - b), de[6 - b], en[b], true});
+  }
+  n->taps.push_back({"tcn_out", B_D0, 0, 128, false});
+  for (int i = 0; i < 6; ++i) {
+    snprintf(nm, sizeof(nm), "dec%d", i);
+    n->taps.push_back({nm, B_D0 + i + 1, 0, de[i + 1], true});
+  }
+  n->taps.push_back({"dec6", B_OUT, 0, c.out_ch, false});
+  return MISONET_OK;
+}
+
+static long long align_up(long long x, long long a) { return (x + a - 1) / a * a; }
+
+static Layout make_layout(const misonet_net* n, int N, int T) {
+  Layout L;
+  L.N = N; L.T = T; L.Tp = frames_pitch(T);
+  long long so = 0;
+  for (int b = 0; b < NBUF; ++b) {
+    L.stats_off[b] = so;
+    so += (long long)N * n->bufs[b].C * 2;
+  }
+  L.tcn_xs = so;  so += 15LL * N * 128 * 2;
+  L.tcn_ps = so;  so += 14LL * N * 128 * 2;
+  L.tcn_gln = so; so += 28LL * N * 2;
+  L.stats_doubles = so;
+  L.data_base = align_up(256 + so * 8, 256);
+  long long d = 0;
+  for (int b = 0; b < NBUF; ++b) {
+    L.data_off[b] = d;
+    d += align_up((long long)N * n->bufs[b].C * n->bufs[b].F * L.Tp, 64);
+  }
+  L.total_bytes = L.data_base + d * 4;
+  return L;
+}
+
+static inline float* buf_ptr(const Layout& L, void* ws, int b) {
+  return reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + L.data_base) + L.data_off[b];
+}
+static inline double* stats_base(void* ws) { return reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + 256); }
+static inline double* stats_ptr(const Layout& L, void* ws, int b) { return stats_base(ws) + L.stats_off[b]; }
+static inline long long bstride(const misonet_net* n, const Layout& L, int b) {
+  return (long long)n->bufs[b].C * n->bufs[b].F * L.Tp;
+}
+
+static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL& c, hipStream_t s) {
+  ConvArgs a;
+  a.in = buf_ptr(L, ws, c.in_buf);
+  a.in_stats = stats_ptr(L, ws, c.in_buf);
+  a.out = buf_ptr(L, ws, c.out_buf);
+  a.out_stats = stats_ptr(L, ws, c.out_buf);
+  a.w = n->w_dev + c.w_off;
+  a.bias = n->w_dev + c.b_off;
+  a.in_bstride = bstride(n, L, c.in_buf);
+  a.out_bstride = bstride(n, L, c.out_buf);
+  a.in_sstride = n->bufs[c.in_buf].C;
+  a.out_sstride = n->bufs[c.out_buf].C;
+  a.in_c0 = c.in_c0; a.Cin = c.Cin; a.Fin = n->bufs[c.in_buf].F; a.ident_c = c.ident_c;
+  a.out_c0 = c.out_c0; a.Cout = c.Cout; a.Fout = n->bufs[c.out_buf].F;
+  a.T = L.T; a.Tp = L.Tp;
+  a.sf = c.sf; a.padf = c.padf; a.tr2 = c.tr2; a.act = c.act;
+  a.NR = conv_rows(c.sf, c.tr2);
+  a.ncg = c.ncg; a.cop = c.cop;
+  HIPCHK(launch_conv(a, L.N, s));
+  return MISONET_OK;
+}
+
+// IN buffer already filled (planar).  Leaves the result (raw) in B_OUT.
+static int forward_planar(misonet_net* n, const Layout& L, void* ws, hipStream_t s) {
+  HIPCHK(hipMemsetAsync(ws, 0, (size_t)(256 + L.stats_doubles * 8), s));
+  for (const ConvL& c : n->enc) { int r = run_conv(n, L, ws, c, s); if (r) return r; }
+  // ---- TCN ----
+  {
+    const int N = L.N, T = L.T, Tp = L.Tp;
+    double* xs = stats_base(ws) + L.tcn_xs;
+    double* ps = stats_base(ws) + L.tcn_ps;
+    double* gl = stats_base(ws) + L.tcn_gln;
+    const long long per = (long long)N * 128 * 2;
+    float* xa = buf_ptr(L, ws, B_TXA);
+    float* xb = buf_ptr(L, ws, B_TXB);
+    float* td = buf_ptr(L, ws, B_TD);
+    float* tp = buf_ptr(L, ws, B_TP);
+    const int skip_c0 = n->cfg.de_ch[0];
+    HIPCHK(launch_tcn_prepare(buf_ptr(L, ws, B_D0), bstride(n, L, B_D0), skip_c0, stats_ptr(L, ws, B_D0),
+                              n->bufs[B_D0].C, xa, xs, 128, T, Tp, N, s));
+    float* cur = xa;
+    float* nxt = xb;
+    for (int k = 0; k < 14; ++k) {
+      const TcnBlock& tb = n->tcn[k];
+      const float* W = n->w_dev;
+      HIPCHK(launch_tcn_dw(cur, xs + k * per, W + tb.h[0].o_dw, W + tb.h[0].o_prelu, td, gl + (2 * k) * (long long)N * 2,
+                           128, T, Tp, tb.dilation, N, s));
+      HIPCHK(launch_tcn_pw(td, gl + (2 * k) * (long long)N * 2, W + tb.h[0].o_gamma, W + tb.h[0].o_beta, W + tb.h[0].o_pw,
+                           nullptr, tp, 128LL * Tp, 0, ps + k * per, 128, T, Tp, N, s));
+      HIPCHK(launch_tcn_dw(tp, ps + k * per, W + tb.h[1].o_dw, W + tb.h[1].o_prelu, td,
+                           gl + (2 * k + 1) * (long long)N * 2, 128, T, Tp, tb.dilation, N, s));
+      const bool last = (k == 13);
+      float* y = last ? buf_ptr(L, ws, B_D0) : nxt;
+      HIPCHK(launch_tcn_pw(td, gl + (2 * k + 1) * (long long)N * 2, W + tb.h[1].o_gamma, W + tb.h[1].o_beta,
+                           W + tb.h[1].o_pw, cur, y, last ? bstride(n, L, B_D0) : 128LL * Tp, 0,
+                           xs + (k + 1) * per, 128, T, Tp, N, s));
+      float* t = cur; cur = nxt; nxt = t;
+    }
+  }
+  for (const ConvL& c : n->dec) { int r = run_conv(n, L, ws, c, s); if (r) return r; }
+  return MISONET_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* misonet_strerror(int code) {
+  switch (code) {
+    case MISONET_OK: return "ok";
+    case MISONET_EINVAL: return "invalid argument / unsupported geometry";
+    case MISONET_ESTATE: return "invalid call order or missing tensor";
+    case MISONET_EHIP: return "HIP runtime error";
+    case MISONET_ENOMEM: return "workspace too small";
+    case MISONET_ENAN: return "NaN in network output";
+    default: return "unknown error";
+  }
+}
+const char* misonet_last_error(void) { return g_err; }
+int misonet_version(void) { return 100; }
+
+int misonet_net_create(const misonet_cfg* cfg, misonet_net** out) {
+  if (!cfg || !out) return fail(MISONET_EINVAL, "null argument");
+  misonet_net* n = new misonet_net();
+  n->cfg = *cfg;
+  int r = build_plan(n);
+  if (r) { delete n; return r; }
+  *out = n;
+  return MISONET_OK;
+}
+
+int misonet_net_destroy(misonet_net* n) {
+  if (!n) return MISONET_OK;
+  if (n->w_dev) hipFree(n->w_dev);
+  delete n;
+  return MISONET_OK;
+}
+
+int misonet_net_num_tensors(const misonet_net* n) { return n ? (int)n->tensors.size() : 0; }
+const char* misonet_net_tensor_name(const misonet_net* n, int i) {
+  if (!n || i < 0 || i >= (int)n->tensors.size()) return nullptr;
+  return n->tensors[i].name.c_str();
+}
+long long misonet_net_tensor_numel(const misonet_net* n, int i) {
+  if (!n || i < 0 || i >= (int)n->tensors.size()) return -1;
+  return n->tensors[i].numel;
+}
+
+int misonet_net_set_tensor(misonet_net* n, const char* key, const float* host, long long numel) {
+  if (!n || !key || !host) return fail(MISONET_EINVAL, "null argument");
+  const int i = find_tensor(n, key);
+  if (i < 0) return fail(MISONET_EINVAL, "unexpected state_dict key '%s'", key);
+  if (n->tensors[i].numel != numel)
+    return fail(MISONET_EINVAL, "size mismatch for '%s': expected %lld elements, got %lld", key, n->tensors[i].numel, numel);
+  n->tensors[i].host.assign(host, host + numel);
+  n->tensors[i].set = true;
+  n->committed = false;
+  return MISONET_OK;
+}
+
+static void pack_conv(const misonet_net* n, const ConvL& c, std::vector<float>& arena) {
+  const std::vector<float>& W = n->tensors[c.wt].host;
+  const std::vector<float>& Bv = n->tensors[c.bt].host;
+  const int nchunk = (c.Cin + CK - 1) / CK;
+  const int COP = c.cop;
+  float* w = arena.data() + c.w_off;
+  for (int cg = 0; cg < c.ncg; ++cg)
+    for (int kc = 0; kc < nchunk; ++kc)
+      for (int kt = 0; kt < 3; ++kt)
+        for (int kf = 0; kf < 3; ++kf)
+          for (int cil = 0; cil < CK; ++cil)
+            for (int col = 0; col < COP; ++col) {
+              const int ci = kc * CK + cil, co = cg * COP + col;
+              float v = 0.f;
+              if (ci < c.Cin && co < c.Cout) {
+                if (c.transposed)   // ConvTranspose2d weight [Cin][Cout][3][3], taps flipped into conv form
+                  v = W[(((long long)ci * c.Cout + co) * 3 + (2 - kt)) * 3 + (2 - kf)];
+                else                // Conv2d weight [Cout][Cin][3][3]
+                  v = W[(((long long)co * c.Cin + ci) * 3 + kt) * 3 + kf];
+              }
+              w[((((long long)cg * nchunk + kc) * 9 + (kt * 3 + kf)) * CK + cil) * COP + col] = v;
+            }
+  float* b = arena.data() + c.b_off;
+  for (int co = 0; co < c.ncg * COP; ++co) b[co] = co < c.Cout ? Bv[co] : 0.f;
+}
+
+int misonet_net_commit(misonet_net* n) {
+  if (!n) return fail(MISONET_EINVAL, "null argument");
+  for (const Tensor& t : n->tensors)
+    if (!t.set) return fail(MISONET_ESTATE, "missing state_dict key '%s'", t.name.c_str());
+  long long off = 0;
+  auto take = [&off](long long nfl) { long long o = off; off += (nfl + 63) / 64 * 64; return o; };
+  auto place = [&](std::vector<ConvL>& v) {
+    for (ConvL& c : v) {
+      const int nchunk = (c.Cin + CK - 1) / CK;
+      c.w_off = take((long long)c.ncg * nchunk * 9 * CK * c.cop);
+      c.b_off = take((long long)c.ncg * c.cop);
+    }
+  };
+  place(n->enc);
+  place(n->dec);
+  for (TcnBlock& tb : n->tcn)
+    for (int h = 0; h < 2; ++h) {
+      tb.h[h].o_dw = take(128 * 3);
+      tb.h[h].o_prelu = take(1);
+      tb.h[h].o_gamma = take(128);
+      tb.h[h].o_beta = take(128);
+      tb.h[h].o_pw = take(128 * 128);
+    }
+  std::vector<float> arena((size_t)off, 0.f);
+  for (const ConvL& c : n->enc) pack_conv(n, c, arena);
+  for (const ConvL& c : n->dec) pack_conv(n, c, arena);
+  for (const TcnBlock& tb : n->tcn)
+    for (int h = 0; h < 2; ++h) {
+      const TcnHalf& H = tb.h[h];
+      memcpy(arena.data() + H.o_dw, n->tensors[H.dw].host.data(), 128 * 3 * sizeof(float));
+      arena[H.o_prelu] = n->tensors[H.prelu].host[0];
+      memcpy(arena.data() + H.o_gamma, n->tensors[H.gamma].host.data(), 128 * sizeof(float));
+      memcpy(arena.data() + H.o_beta, n->tensors[H.beta].host.data(), 128 * sizeof(float));
+      const std::vector<float>& P = n->tensors[H.pw].host;     // [co][ci][1] -> [ci][co]
+      for (int co = 0; co < 128; ++co)
+        for (int ci = 0; ci < 128; ++ci) arena[H.o_pw + (long long)ci * 128 + co] = P[(long long)co * 128 + ci];
+    }
+  if (n->w_dev) { hipFree(n->w_dev); n->w_dev = nullptr; }
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&n->w_dev), arena.size() * sizeof(float)));
+  HIPCHK(hipMemcpy(n->w_dev, arena.data(), arena.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(conv_init());
+  n->committed = true;
+  return MISONET_OK;
+}
+
+long long misonet_net_workspace_bytes(const misonet_net* n, int n_samples, int n_frames) {
+  if (!n || n_samples <= 0 || n_frames <= 0) return -1;
+  return make_layout(n, n_samples, n_frames).total_bytes;
+}
+
+int misonet_net_forward(misonet_net* n, int n_seg, const void* const* seg_dev, const int* seg_ch, int B, int T,
+                        void* out_dev, void* ws, long long ws_bytes, misonet_stream stream) {
+  if (!n || !seg_dev || !seg_ch || !out_dev || !ws) return fail(MISONET_EINVAL, "null argument");
+  if (!n->committed) return fail(MISONET_ESTATE, "misonet_net_commit has not been called");
+  if (B <= 0 || T <= 0) return fail(MISONET_EINVAL, "B and T must be positive");
+  int tot = 0;
+  for (int i = 0; i < n_seg; ++i) tot += seg_ch[i];
+  if (2 * tot != n->cfg.in_ch) return fail(MISONET_EINVAL, "input segments give %d complex channels, network expects %d", tot, n->cfg.in_ch / 2);
+  const Layout L = make_layout(n, B, T);
+  if (ws_bytes < L.total_bytes) return fail(MISONET_ENOMEM, "workspace %lld < %lld bytes", ws_bytes, L.total_bytes);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int c0 = 0;
+  for (int i = 0; i < n_seg; ++i) {
+    HIPCHK(launch_pack(reinterpret_cast<const float2*>(seg_dev[i]), B, seg_ch[i], T, n->cfg.n_freq, buf_ptr(L, ws, B_IN),
+                       bstride(n, L, B_IN), L.Tp, c0, tot + c0, 1, s));
+    c0 += seg_ch[i];
+  }
+  int r = forward_planar(n, L, ws, s);
+  if (r) return r;
+  HIPCHK(launch_unpack(buf_ptr(L, ws, B_OUT), bstride(n, L, B_OUT), L.Tp, n->S, T, n->cfg.n_freq,
+                       reinterpret_cast<float2*>(out_dev), B, reinterpret_cast<int*>(ws), s));
+  return MISONET_OK;
+}
+
+int misonet_net_check(misonet_net* n, const void* ws, misonet_stream stream) {
+  if (!n || !ws) return fail(MISONET_EINVAL, "null argument");
+  int flag = 0;
+  HIPCHK(hipMemcpyAsync(&flag, ws, sizeof(int), hipMemcpyDeviceToHost, reinterpret_cast<hipStream_t>(stream)));
+  HIPCHK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+  if (flag) return fail(MISONET_ENAN, "NaN in network output");
+  return MISONET_OK;
+}
+
+int misonet_net_tap_shape(const misonet_net* n, const char* name, int* C, int* F) {
+  if (!n || !name) return fail(MISONET_EINVAL, "null argument");
+  for (const Tap& t : n->taps)
+    if (t.name == name) {
+      if (C) *C = t.C;
+      if (F) *F = n->bufs[t.buf].F;
+      return MISONET_OK;
+    }
+  return fail(MISONET_EINVAL, "unknown tap '%s'", name);
+}
+
+int misonet_net_tap(misonet_net* n, const char* name, const void* ws, int B, int T, float* dst, misonet_stream stream) {
+  if (!n || !name || !ws || !dst) return fail(MISONET_EINVAL, "null argument");
+  const Layout L = make_layout(n, B, T);
+  for (const Tap& t : n->taps)
+    if (t.name == name) {
+      void* w = const_cast<void*>(ws);
+      HIPCHK(launch_export(buf_ptr(L, w, t.buf), bstride(n, L, t.buf), t.c0, t.C, n->bufs[t.buf].F, T, L.Tp,
+                           t.normalised ? stats_ptr(L, w, t.buf) : nullptr, n->bufs[t.buf].C, 0, dst, B,
+                           reinterpret_cast<hipStream_t>(stream)));
+      return MISONET_OK;
+    }
+  return fail(MISONET_EINVAL, "unknown tap '%s'", name);
+}
+
+// ---- MVDR / PIT drop-in entry points ---------------------------------------------------------------------------
+long long misonet_mvdr_workspace_bytes(int B, int F, int M) { return mvdr_ws_bytes(B, 1, F, M); }
+
+int misonet_mvdr(const void* src, const void* mix, int B, int F, int M, int T, float epsi, void* out, void* ws,
+                 long long ws_bytes, misonet_stream stream) {
+  if (!src || !mix || !out || !ws) return fail(MISONET_EINVAL, "null argument");
+  if (M < 2 || M > 8) return fail(MISONET_EINVAL, "M must be in [2, 8] (got %d)", M);
+  if (B <= 0 || F <= 0 || T <= 0) return fail(MISONET_EINVAL, "B, F, T must be positive");
+  if (ws_bytes < mvdr_ws_bytes(B, 1, F, M)) return fail(MISONET_ENOMEM, "workspace too small");
+  MvdrArgs a;
+  const float* y = reinterpret_cast<const float*>(mix);
+  const float* x = reinterpret_cast<const float*>(src);
+  a.mix = {y, y + 1, 2LL * F * M * T, 2LL * M * T, 2LL * T, 2};
+  a.src = {x, x + 1, 2LL * F * M * T, 2LL * M * T, 2LL * T, 2};
+  a.est = nullptr; a.est_bstride = 0; a.sel = nullptr;
+  a.S = 1; a.B = B; a.F = F; a.M = M; a.T = T; a.Tp = T; a.epsi = epsi;
+  float* o = reinterpret_cast<float*>(out);
+  COut co = {o, o + 1, 2LL * T * F, 0, 2LL * F, 2};      // [B,T,F] complex64 (tester.py:1134)
+  HIPCHK(launch_mvdr(a, co, ws, reinterpret_cast<hipStream_t>(stream)));
+  return MISONET_OK;
+}
+
+int misonet_mvdr_debug(const void* ws, int B, int F, int M, void* steer, void* w, misonet_stream stream) {
+  if (!ws) return fail(MISONET_EINVAL, "null argument");
+  HIPCHK(launch_mvdr_debug(ws, B, 1, F, M, reinterpret_cast<double*>(steer), reinterpret_cast<double*>(w),
+                           reinterpret_cast<hipStream_t>(stream)));
+  return MISONET_OK;
+}
+
+int misonet_pit_select(const void* anchor, const void* cand, int B, int S, int T, int F, int* sel, double* dist,
+                       misonet_stream stream) {
+  if (!anchor || !cand || !sel) return fail(MISONET_EINVAL, "null argument");
+  if (S != 2) return fail(MISONET_EINVAL, "PIT alignment supports num_spks == 2 only (got %d)", S);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  double* d = dist;
+  bool own = false;
+  if (!d) { HIPCHK(hipMalloc(reinterpret_cast<void**>(&d), (size_t)B * 4 * sizeof(double))); own = true; }
+  HIPCHK(hipMemsetAsync(d, 0, (size_t)B * 4 * sizeof(double), s));
+  const float* a = reinterpret_cast<const float*>(anchor);
+  const float* c = reinterpret_cast<const float*>(cand);
+  PitArgs p;
+  // [B,S,T,F] complex64: element (b, f, spk, t) at ((b*S + spk)*T + t)*F + f
+  p.a = {a, a + 1, 2LL * S * T * F, 2, 2LL * T * F, 2 * F};
+  p.b = {c, c + 1, 2LL * S * T * F, 2, 2LL * T * F, 2 * F};
+  p.B = B; p.F = F; p.T = T;
+  HIPCHK(launch_pit_dist(p, d, s));
+  HIPCHK(launch_pit_pick(d, B, sel, s));
+  if (own) { HIPCHK(hipStreamSynchronize(s)); HIPCHK(hipFree(d)); }
+  return MISONET_OK;
+}
+
+// ---- fused pipeline ----------------------------------------------------------------------------------------------
+struct misonet_pipeline {
+  misonet_net* n1;
+  misonet_net* n3;
+  int M, S, ref_ch;
+  float epsi;
+};
+
+struct PipeLayout {
+  Layout L1, L3;
+  long long off_ws1, off_ws3, off_clean, off_dist, off_sel, off_mvdr, total;
+  long long clean_bstride;
+};
+
+static PipeLayout pipe_layout(const misonet_pipeline* p, int B, int T) {
+  PipeLayout P;
+  P.L1 = make_layout(p->n1, B * p->M, T);
+  P.L3 = make_layout(p->n3, B * p->S, T);
+  const int F = p->n1->cfg.n_freq, Tp = P.L1.Tp;
+  long long o = 256;                                   // [0]: nan flag
+  P.off_dist = o;  o += align_up((long long)(B * p->M + B) * 4 * 8, 256);
+  P.off_sel = o;   o += align_up((long long)(B * p->M * p->S * 2 + B * p->S) * 4, 256);
+  P.off_mvdr = o;  o += align_up(mvdr_ws_bytes(B, p->S, F, p->M), 256);
+  P.clean_bstride = (long long)2 * p->S * F * Tp;
+  P.off_clean = o; o += align_up(P.clean_bstride * B * 4, 256);
+  P.off_ws1 = o;   o += align_up(P.L1.total_bytes, 256);
+  P.off_ws3 = o;   o += align_up(P.L3.total_bytes, 256);
+  P.total = o;
+  return P;
+}
+
+int misonet_pipeline_create(misonet_net* n1, misonet_net* n3, int num_mic, int num_spk, int ref_ch, float epsi,
+                            misonet_pipeline** out) {
+  if (!n1 || !n3 || !out) return fail(MISONET_EINVAL, "null argument");
+  if (num_spk != 2) return fail(MISONET_EINVAL, "the pipeline supports num_spks == 2 (PIT over 2 permutations)");
+  if (num_mic < 2 || num_mic > 8) return fail(MISONET_EINVAL, "num_mic must be in [2, 8]");
+  if (ref_ch < 0 || ref_ch >= num_mic) return fail(MISONET_EINVAL, "ref_ch out of range");
+  if (n1->cfg.in_ch != 2 * num_mic || n1->cfg.out_ch != 2 * num_spk)
+    return fail(MISONET_EINVAL, "MISO_1 geometry does not match num_mic/num_spk");
+  if (n3->cfg.in_ch != 2 * (num_mic + 2) || n3->cfg.out_ch != 2)
+    return fail(MISONET_EINVAL, "MISO_3 geometry must be in_ch = 2*(num_mic+2), out_ch = 2");
+  misonet_pipeline* p = new misonet_pipeline{n1, n3, num_mic, num_spk, ref_ch, epsi};
+  *out = p;
+  return MISONET_OK;
+}
+int misonet_pipeline_destroy(misonet_pipeline* p) { delete p; return MISONET_OK; }
+
+long long misonet_pipeline_workspace_bytes(const misonet_pipeline* p, int B, int T) {
+  if (!p || B <= 0 || T <= 0) return -1;
+  return pipe_layout(p, B, T).total;
+}
+
+int misonet_pipeline_run(misonet_pipeline* p, const void* mix, const void* clean, int B, int T, void* out, void* bf_out,
+                         void* miso1_out, void* ws, long long ws_bytes, misonet_stream stream) {
+  if (!p || !mix || !out || !ws) return fail(MISONET_EINVAL, "null argument");
+  if (!p->n1->committed || !p->n3->committed) return fail(MISONET_ESTATE, "networks not committed");
+  if (B <= 0 || T <= 0) return fail(MISONET_EINVAL, "B and T must be positive");
+  const PipeLayout P = pipe_layout(p, B, T);
+  if (ws_bytes < P.total) return fail(MISONET_ENOMEM, "workspace %lld < %lld bytes", ws_bytes, P.total);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  char* base = reinterpret_cast<char*>(ws);
+  void* ws1 = base + P.off_ws1;
+  void* ws3 = base + P.off_ws3;
+  const int M = p->M, S = p->S, F = p->n1->cfg.n_freq, Tp = P.L1.Tp;
+  misonet_net *n1 = p->n1, *n3 = p->n3;
+  double* dist_shift = reinterpret_cast<double*>(base + P.off_dist);          // [B*M][4]
+  double* dist_clean = dist_shift + (long long)B * M * 4;                      // [B][4]
+  int* sel_shift = reinterpret_cast<int*>(base + P.off_sel);                   // [B*M][S]
+  int* sel_final = sel_shift + (long long)B * M * S;                           // [B*M][S]
+  int* sel_clean = sel_final + (long long)B * M * S;                           // [B][S]
+  HIPCHK(hipMemsetAsync(base, 0, (size_t)P.off_sel, s));                       // nan flag + distances
+
+  // 1. MISO1_Inference: the M circular shifts as one batch of B*M samples (tester.py:1033-1051)
+  float* in1 = buf_ptr(P.L1, ws1, B_IN);
+  const long long in1_bs = bstride(n1, P.L1, B_IN);
+  HIPCHK(launch_pack(reinterpret_cast<const float2*>(mix), B, M, T, F, in1, in1_bs, Tp, 0, M, M, s));
+  int r = forward_planar(n1, P.L1, ws1, s);
+  if (r) return r;
+  float* out1 = buf_ptr(P.L1, ws1, B_OUT);
+  const long long out1_bs = bstride(n1, P.L1, B_OUT);
+  const long long plane = (long long)F * Tp;
+
+  // 2. align the speakers of every shift to the reference-mic forward (tester.py:1043-1065)
+  {
+    PitArgs q;
+    const float* anc = out1 + (long long)p->ref_ch * out1_bs;
+    q.a = {anc, anc + S * plane, (long long)M * out1_bs, Tp, plane, 1};
+    q.b = {out1, out1 + S * plane, out1_bs, Tp, plane, 1};
+    q.B = B; q.F = F; q.T = T;
+    HIPCHK(launch_pit_dist_k(q, M, dist_shift, s));
+    HIPCHK(launch_pit_pick(dist_shift, B * M, sel_shift, s));
+  }
+  // 3. align to the clean references at ref_ch (tester.py:889-915), optional
+  if (clean) {
+    float* cl = reinterpret_cast<float*>(base + P.off_clean);
+    HIPCHK(launch_pack(reinterpret_cast<const float2*>(clean), B, S, T, F, cl, P.clean_bstride, Tp, 0, S, 1, s));
+    // anchors = clean sources; candidates = shift-aligned ref-mic estimates.  The ref-mic forward is never
+    // permuted by step 2 (its distance matrix has a zero diagonal), so the raw OUT1 planes are the candidates.
+    PitArgs q;
+    const float* cand = out1 + (long long)p->ref_ch * out1_bs;
+    q.a = {cl, cl + S * plane, P.clean_bstride, Tp, plane, 1};
+    q.b = {cand, cand + S * plane, (long long)M * out1_bs, Tp, plane, 1};
+    q.B = B; q.F = F; q.T = T;
+    HIPCHK(launch_pit_dist_k(q, 1, dist_clean, s));
+    HIPCHK(launch_pit_pick(dist_clean, B, sel_clean, s));
+  }
+  HIPCHK(launch_compose_sel(sel_shift, clean ? sel_clean : nullptr, B, M, S, sel_final, s));
+
+  // 4. MISO3 input = [mixture | beamformer | MISO1 estimate at ref_ch] (tester.py:936-939), B*S samples
+  float* in3 = buf_ptr(P.L3, ws3, B_IN);
+  const long long in3_bs = bstride(n3, P.L3, B_IN);
+  HIPCHK(launch_assemble3(in1, in1_bs, out1, out1_bs, sel_final, B, M, S, p->ref_ch, F, Tp, in3, in3_bs, s));
+
+  // 5. MVDR per aligned speaker (tester.py:917-924, 1071-1136); writes the beamformer planes of the MISO3 input
+  {
+    MvdrArgs a;
+    a.mix = {in1, in1 + (long long)M * plane, (long long)M * in1_bs, Tp, plane, 1};   // shift-0 sample = un-rolled mixture
+    a.est = out1; a.est_bstride = out1_bs; a.sel = sel_final;
+    a.src = {nullptr, nullptr, 0, 0, 0, 1};
+    a.S = S; a.B = B; a.F = F; a.M = M; a.T = T; a.Tp = Tp; a.epsi = p->epsi;
+    COut co = {in3 + (long long)M * plane, in3 + (long long)(2 * M + 2) * plane, (long long)S * in3_bs, in3_bs, 1, Tp};
+    HIPCHK(launch_mvdr(a, co, base + P.off_mvdr, s));
+  }
+  // 6. MISO3 per speaker (tester.py:1231-1244)
+  r = forward_planar(n3, P.L3, ws3, s);
+  if (r) return r;
+  HIPCHK(launch_unpack(buf_ptr(P.L3, ws3, B_OUT), bstride(n3, P.L3, B_OUT), Tp, 1, T, F, reinterpret_cast<float2*>(out),
+                       B * S, reinterpret_cast<int*>(base), s));
+  if (bf_out)
+    HIPCHK(launch_unpack_ex(in3, n3->cfg.in_ch, Tp, 1, T, F, M, 2 * M + 2, 0, 1, nullptr, reinterpret_cast<float2*>(bf_out),
+                            B * S, reinterpret_cast<int*>(base), s));
+  if (miso1_out)
+    HIPCHK(launch_unpack_ex(out1, n1->cfg.out_ch, Tp, S, T, F, 0, S, 1, M, sel_final, reinterpret_cast<float2*>(miso1_out),
+                            B * S * M, reinterpret_cast<int*>(base), s));
+  return MISONET_OK;
+}
+
+int misonet_pipeline_check(misonet_pipeline* p, const void* ws, misonet_stream stream) {
+  if (!p || !ws) return fail(MISONET_EINVAL, "null argument");
+  int flag = 0;
+  HIPCHK(hipMemcpyAsync(&flag, ws, sizeof(int), hipMemcpyDeviceToHost, reinterpret_cast<hipStream_t>(stream)));
+  HIPCHK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+  if (flag) return fail(MISONET_ENAN, "NaN in pipeline output");
+  return MISONET_OK;
+}
+
+// ---- events --------------------------------------------------------------------------------------------------------
+int misonet_event_create(void** ev) {
+  hipEvent_t e;
+  HIPCHK(hipEventCreate(&e));
+  *ev = e;
+  return MISONET_OK;
+}
+int misonet_event_record(void* ev, misonet_stream stream) {
+  HIPCHK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev), reinterpret_cast<hipStream_t>(stream)));
+  return MISONET_OK;
+}
+int misonet_event_elapsed_ms(void* start, void* stop, float* ms) {
+  HIPCHK(hipEventSynchronize(reinterpret_cast<hipEvent_t>(stop)));
+  HIPCHK(hipEventElapsedTime(ms, reinterpret_cast<hipEvent_t>(start), reinterpret_cast<hipEvent_t>(stop)));
+  return MISONET_OK;
+}
+int misonet_event_destroy(void* ev) {
+  HIPCHK(hipEventDestroy(reinterpret_cast<hipEvent_t>(ev)));
+  return MISONET_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,212 @@
+// Temporal convolution network kernels (reference model.py:486-632): TemporalConvNet(2,7,128,128,128,"IN").
+//
+// One TemporalBlock (model.py:517-550) =  x + DS2(ELU(IN1d(DS1(ELU(IN1d(x))))))  with
+// DS(y) = pwconv(gLN(PReLU(dwconv_dilated(y))))  (model.py:553-567).  Every norm is a reduction over the whole
+// utterance (IN1d: per (n,c) over T; gLN: per n over (C,T)), so a DS conv is two launches:
+//   tcn_dw : a = ELU(IN1d(x)) on the fly -> depth-wise dilated conv -> PReLU -> d ; gLN sums of d
+//   tcn_pw : g = gLN(d) on the fly -> 128x128 point-wise conv on the fp32 matrix cores (+ residual) ; IN1d sums
+// All sums are float64.  Activations are planar [n][c][Tp] (F = 1).
+#include "kernels.hpp"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+namespace mn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ inline double block_sum_256(double v, double* s_tmp /*[4]*/) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  const int tid = threadIdx.x;
+  __syncthreads();
+  if ((tid & 63) == 0) s_tmp[tid >> 6] = v;
+  __syncthreads();
+  return s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
+}
+
+__device__ inline void in_params(const double* st, int T, float& mean, float& rstd) {
+  const double m = st[0] / (double)T;
+  double var = st[1] / (double)T - m * m;
+  var = var > 0.0 ? var : 0.0;
+  mean = (float)m;
+  rstd = (float)(1.0 / sqrt(var + (double)IN_EPS));
+}
+
+// x[n][c][t] = IN2d(raw)[n][c][t] (the encoder's last Conv2d_ output, F = 1; model.py:89) + sums of x
+__global__ __launch_bounds__(256) void tcn_prepare_k(const float* raw, long long raw_bstride, int raw_c0,
+                                                     const double* raw_stats, int raw_sstride, float* x,
+                                                     double* x_stats, int C, int T, int Tp) {
+  __shared__ double s_tmp[4];
+  const int c = blockIdx.x, n = blockIdx.y;
+  float mean, rstd;
+  in_params(raw_stats + ((long long)n * raw_sstride + raw_c0 + c) * 2, T, mean, rstd);
+  const float* src = raw + (long long)n * raw_bstride + (long long)(raw_c0 + c) * Tp;
+  float* dst = x + ((long long)n * C + c) * Tp;
+  double s1 = 0.0, s2 = 0.0;
+  for (int t = threadIdx.x; t < T; t += 256) {
+    const float v = (src[t] - mean) * rstd;
+    dst[t] = v;
+    s1 += v;
+    s2 += (double)v * v;
+  }
+  s1 = block_sum_256(s1, s_tmp);
+  s2 = block_sum_256(s2, s_tmp);
+  if (threadIdx.x == 0) {
+    double* o = x_stats + ((long long)n * C + c) * 2;
+    o[0] = s1;
+    o[1] = s2;
+  }
+}
+
+// d = PReLU(dwconv(ELU(IN1d(x)))), kernel 3, dilation = padding = dil, no bias (model.py:556-558)
+__global__ __launch_bounds__(256) void tcn_dw_k(const float* x, const double* x_stats, const float* wdw,
+                                                const float* prelu, float* d, double* gln_stats, int C, int T,
+                                                int Tp, int dil) {
+  __shared__ double s_tmp[4];
+  const int c = blockIdx.x, n = blockIdx.y;
+  float mean, rstd;
+  in_params(x_stats + ((long long)n * C + c) * 2, T, mean, rstd);
+  const float w0 = wdw[c * 3 + 0], w1 = wdw[c * 3 + 1], w2 = wdw[c * 3 + 2];
+  const float slope = prelu[0];
+  const float* src = x + ((long long)n * C + c) * Tp;
+  float* dst = d + ((long long)n * C + c) * Tp;
+  double s1 = 0.0, s2 = 0.0;
+  for (int t = threadIdx.x; t < T; t += 256) {
+    float acc = 0.f;
+    {
+      const int tt = t - dil;
+      if (tt >= 0) { float v = (src[tt] - mean) * rstd; v = v > 0.f ? v : expm1f(v); acc = w0 * v; }
+    }
+    {
+      float v = (src[t] - mean) * rstd; v = v > 0.f ? v : expm1f(v); acc = fmaf(w1, v, acc);
+    }
+    {
+      const int tt = t + dil;
+      if (tt < T) { float v = (src[tt] - mean) * rstd; v = v > 0.f ? v : expm1f(v); acc = fmaf(w2, v, acc); }
+    }
+    acc = acc > 0.f ? acc : slope * acc;
+    dst[t] = acc;
+    s1 += acc;
+    s2 += (double)acc * acc;
+  }
+  s1 = block_sum_256(s1, s_tmp);
+  s2 = block_sum_256(s2, s_tmp);
+  if (threadIdx.x == 0) {
+    unsafeAtomicAdd(gln_stats + (long long)n * 2 + 0, s1);
+    unsafeAtomicAdd(gln_stats + (long long)n * 2 + 1, s2);
+  }
+}
+
+// y[co][t] = sum_ci W[co][ci] * (gamma[ci] * (d[ci][t] - mean_n) * rstd_n + beta[ci])  (+ residual[co][t])
+// C must be 128.  Workgroup: 128 output channels x 64 frames; wave w owns channels 32w..32w+31, two 32-frame tiles.
+constexpr int PW_TT = 64;
+constexpr int PW_KC = 32;
+__global__ __launch_bounds__(256) void tcn_pw_k(const float* d, const double* gln_stats, const float* gamma,
+                                                const float* beta, const float* wt /*[ci][co]*/,
+                                                const float* residual, float* y, long long y_bstride, int y_c0,
+                                                double* y_stats, int T, int Tp) {
+  constexpr int C = 128;
+  __shared__ __align__(16) float s_g[PW_KC][PW_TT];
+  __shared__ __align__(16) float s_w[PW_KC][C];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int t0 = blockIdx.x * PW_TT, n = blockIdx.y;
+  const double cnt = (double)C * (double)T;
+  const double gm = gln_stats[(long long)n * 2] / cnt;
+  double gv = gln_stats[(long long)n * 2 + 1] / cnt - gm * gm;
+  gv = gv > 0.0 ? gv : 0.0;
+  const float mean = (float)gm;
+  const float rstd = (float)(1.0 / sqrt(gv + (double)GLN_EPS));
+  const float* dn = d + (long long)n * C * Tp;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+
+  for (int k0 = 0; k0 < C; k0 += PW_KC) {
+    __syncthreads();
+    for (int i = tid; i < PW_KC * PW_TT; i += 256) {
+      const int ci = i / PW_TT, tl = i % PW_TT;
+      const int t = t0 + tl;
+      float v = 0.f;
+      if (t < T) v = gamma[k0 + ci] * ((dn[(long long)(k0 + ci) * Tp + t] - mean) * rstd) + beta[k0 + ci];
+      s_g[ci][tl] = v;
+    }
+    for (int i = tid; i < PW_KC * C; i += 256) s_w[i / C][i % C] = wt[(long long)(k0 + i / C) * C + (i % C)];
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < PW_KC; kk += 2) {
+      const float av = s_w[kk + half][wave * 32 + l31];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const float bv = s_g[kk + half][s * 32 + l31];
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[s], 0, 0, 0);
+      }
+    }
+  }
+
+  float* yn = y + (long long)n * y_bstride + (long long)y_c0 * Tp;
+  const float* rn = residual ? residual + (long long)n * C * Tp : nullptr;
+  float s1[16], s2[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int t = t0 + s * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (t < T) {
+        float v = acc[s][r];
+        if (rn) v += rn[(long long)co * Tp + t];
+        yn[(long long)co * Tp + t] = v;
+        s1[r] += v;
+        s2[r] += v * v;
+      }
+    }
+  }
+  if (y_stats) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float x1 = s1[r], x2 = s2[r];
+#pragma unroll
+      for (int m = 16; m >= 1; m >>= 1) {
+        x1 += __shfl_xor(x1, m, 64);
+        x2 += __shfl_xor(x2, m, 64);
+      }
+      if (l31 == 0) {
+        const int co = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        double* o = y_stats + ((long long)n * C + co) * 2;
+        unsafeAtomicAdd(o + 0, (double)x1);
+        unsafeAtomicAdd(o + 1, (double)x2);
+      }
+    }
+  }
+}
+
+hipError_t launch_tcn_prepare(const float* raw, long long raw_bstride, int raw_c0, const double* raw_stats,
+                              int raw_sstride, float* x, double* x_stats, int C, int T, int Tp, int n_samples,
+                              hipStream_t s) {
+  hipLaunchKernelGGL(tcn_prepare_k, dim3(C, n_samples), dim3(256), 0, s, raw, raw_bstride, raw_c0, raw_stats,
+                     raw_sstride, x, x_stats, C, T, Tp);
+  return hipGetLastError();
+}
+
+hipError_t launch_tcn_dw(const float* x, const double* x_stats, const float* wdw, const float* prelu, float* d,
+                         double* gln_stats, int C, int T, int Tp, int dilation, int n_samples, hipStream_t s) {
+  hipLaunchKernelGGL(tcn_dw_k, dim3(C, n_samples), dim3(256), 0, s, x, x_stats, wdw, prelu, d, gln_stats, C, T, Tp,
+                     dilation);
+  return hipGetLastError();
+}
+
+hipError_t launch_tcn_pw(const float* d, const double* gln_stats, const float* gamma, const float* beta,
+                         const float* wpw, const float* residual, float* y, long long y_bstride, int y_c0,
+                         double* y_stats, int C, int T, int Tp, int n_samples, hipStream_t s) {
+  if (C != 128) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(tcn_pw_k, dim3((T + PW_TT - 1) / PW_TT, n_samples), dim3(256), 0, s, d, gln_stats, gamma, beta,
+                     wpw, residual, y, y_bstride, y_c0, y_stats, T, Tp);
+  return hipGetLastError();
+}
+
+}  // namespace mn

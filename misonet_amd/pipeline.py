@@ -1,0 +1,138 @@
+"""On-device MISO1 -> MVDR -> MISO3 pipeline: the body of the reference's Tester_Enhance.inference
+(reference tester.py:846-975) with every stage kept in HBM, plus the utterance sharding used for multi-GPU runs.
+
+``Enhancer`` mirrors the part of ``Tester_Enhance`` that does arithmetic:
+    __init__(model_sep, model, num_spks, ref_ch, ...)   tester.py:799-825
+    MISO1_Inference / alignment / Apply_Beamforming / MISO3_inference   tester.py:874-939  -> ``enhance``
+    ISTFT + int16 + gap trim + chunk concat                               tester.py:949-969  -> ``to_wav_int16``
+Unlike the reference it is correct for batch > 1 (the reference broadcasts the last batch row, tester.py:1065):
+every utterance of the batch gets its own alignment, i.e. results equal the reference run utterance by utterance.
+
+Multi-GPU: utterances are independent, so the batch is block-split over ranks with no collective on the data
+path; ``gather_outputs`` is the optional all_gather of the results (RCCL on GPUs, gloo in the CPU tests).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import stft as S
+from .model import MISO_1, MISO_3
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block split of ``n_items`` utterances: rank r owns [lo, hi).
+    The first ``n_items % world`` ranks get one extra item."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_outputs(local: torch.Tensor, n_items: int, group=None) -> torch.Tensor:
+    """all_gather of per-rank results (first dim = utterances of this rank's shard) back into global order."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    sizes = [shard_range(n_items, r, world) for r in range(world)]
+    cap = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((cap,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    if pad.is_complex():
+        bufs = [torch.empty_like(torch.view_as_real(pad)) for _ in range(world)]
+        dist.all_gather(bufs, torch.view_as_real(pad).contiguous(), group=group)
+        bufs = [torch.view_as_complex(b) for b in bufs]
+    else:
+        bufs = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(bufs, pad, group=group)
+    return torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], dim=0)
+
+
+def run_sharded(process: Callable[[int, int], torch.Tensor], n_items: int, rank: int, world: int, gather: bool,
+                group=None):
+    """Run ``process(lo, hi)`` on this rank's shard; optionally gather every rank's result in global order."""
+    lo, hi = shard_range(n_items, rank, world)
+    local = process(lo, hi)
+    if gather and world > 1:
+        return gather_outputs(local, n_items, group)
+    return local
+
+
+class Enhancer:
+    """Fused on-device MISO1 -> (alignment) -> MVDR -> MISO3 for batches of 4 s chunks."""
+
+    def __init__(self, model_sep: MISO_1, model: MISO_3, num_spks: int = 2, ref_ch: int = 0, epsi: float = 1e-6):
+        if not isinstance(model_sep, MISO_1) or not isinstance(model, MISO_3):
+            raise TypeError("Enhancer needs misonet_amd.MISO_1 and misonet_amd.MISO_3 instances")
+        self.model_sep, self.model = model_sep, model
+        self.num_spks, self.ref_ch, self.num_ch = int(num_spks), int(ref_ch), model_sep.num_ch
+        if model_sep._device is None:
+            model_sep.cuda()
+        if model._device is None:
+            model.cuda(model_sep._device)
+        self.device = model_sep._device
+        model_sep._commit()
+        model._commit()
+        self._pipe = C.c_void_p()
+        _lib.check(_lib.lib().misonet_pipeline_create(model_sep._net, model._net, self.num_ch, self.num_spks, self.ref_ch,
+                                                      float(epsi), C.byref(self._pipe)))
+        self._ws: Dict[tuple, torch.Tensor] = {}
+
+    def __del__(self):
+        try:
+            if self._pipe:
+                _lib.lib().misonet_pipeline_destroy(self._pipe)
+                self._pipe = C.c_void_p()
+        except Exception:
+            pass
+
+    def workspace(self, B, T):
+        ws = self._ws.get((B, T))
+        if ws is None:
+            self._ws.clear()
+            n = _lib.lib().misonet_pipeline_workspace_bytes(self._pipe, B, T)
+            ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+            self._ws[(B, T)] = ws
+        return ws
+
+    def enhance(self, mix: torch.Tensor, clean: Optional[torch.Tensor] = None, want_bf=False, want_miso1=False,
+                check_nan=True, out: Optional[torch.Tensor] = None):
+        """mix complex [B,M,T,F] (device); clean complex [B,S,T,F] = clean sources at ref_ch (tester.py:889-891) or
+        None to skip the clean-reference re-ordering.  Returns MISO3 output complex64 [B,S,T,F]
+        (and a dict with 'bf' [B,S,T,F] / 'miso1' [B,S,M,T,F] when requested)."""
+        mix = mix.to(torch.complex64).contiguous()
+        B, M, T, F = mix.shape
+        if M != self.num_ch:
+            raise ValueError(f"expected {self.num_ch} microphones, got {M}")
+        if clean is not None:
+            clean = clean.to(torch.complex64).contiguous()
+            if tuple(clean.shape) != (B, self.num_spks, T, F):
+                raise ValueError("clean must be [B, num_spks, T, F]")
+        ws = self.workspace(B, T)
+        if out is None:
+            out = torch.empty((B, self.num_spks, T, F), dtype=torch.complex64, device=self.device)
+        bf = torch.empty_like(out) if want_bf else None
+        m1 = torch.empty((B, self.num_spks, M, T, F), dtype=torch.complex64, device=self.device) if want_miso1 else None
+        L = _lib.lib()
+        with torch.cuda.device(self.device):
+            st = _lib.stream_ptr(self.device)
+            _lib.check(L.misonet_pipeline_run(self._pipe, mix.data_ptr(), clean.data_ptr() if clean is not None else None,
+                                              B, T, out.data_ptr(), bf.data_ptr() if want_bf else None,
+                                              m1.data_ptr() if want_miso1 else None, ws.data_ptr(), ws.numel(), st))
+            if check_nan:
+                _lib.check(L.misonet_pipeline_check(self._pipe, ws.data_ptr(), st))
+        if want_bf or want_miso1:
+            return out, dict(bf=bf, miso1=m1)
+        return out
+
+    def to_wav_int16(self, enhanced_chunks: List[torch.Tensor], gap: int) -> np.ndarray:
+        """tester.py:949-969 for one recording: list over 4 s splits of complex [S,T,F] -> int16 [S, n_samples]."""
+        per_spk = []
+        for s in range(self.num_spks):
+            pcs = [S.istft_int16(ch[s]).cpu().numpy() for ch in enhanced_chunks]
+            per_spk.append(S.stitch_int16(pcs, gap))
+        return np.stack(per_spk)

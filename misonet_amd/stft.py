@@ -1,0 +1,74 @@
+"""STFT / iSTFT contract of the reference's test-time data path, on torch (device or CPU).
+
+  * analysis  : dataloader/data.py:505-522,540-544 -- scipy.signal.stft(hann, 256, 192) / scale with
+                scale = 1/sum(hann) = 1/128, i.e. the UN-normalised one-sided STFT, zero 'boundary' padding of
+                nperseg/2 on both sides; chunking into 4 s pieces with a zero-padded tail and its ``gap``
+                (data.py:555-595)
+  * synthesis : tester.py:949-952, 979-990 -- istft(spec * scale) * 32767 -> int16 (truncation toward zero)
+
+torch.stft/istft with center=True, zero padding and a periodic hann window compute the same transforms (checked
+against SciPy in tests/test_stft.py).  PyTorch is used here as the north_star allows ("tensor containers and iSTFT").
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import numpy as np
+import torch
+
+NPERSEG, HOP = 256, 64
+MAX_INT16 = 32767
+
+
+def _window(device, dtype=torch.float32):
+    return torch.hann_window(NPERSEG, periodic=True, device=device, dtype=dtype)
+
+
+def stft(wav: torch.Tensor) -> torch.Tensor:
+    """wav float [..., L] -> complex64 [..., T, F] with T = L // 64 + 1, F = 129 (un-normalised, as fed to MISO_1)."""
+    lead = wav.shape[:-1]
+    x = wav.reshape(-1, wav.shape[-1]).float()
+    z = torch.stft(x, n_fft=NPERSEG, hop_length=HOP, win_length=NPERSEG, window=_window(x.device), center=True,
+                   pad_mode="constant", normalized=False, onesided=True, return_complex=True)      # [N, F, T]
+    return z.transpose(1, 2).reshape(*lead, z.shape[2], z.shape[1]).to(torch.complex64)
+
+
+def istft(spec: torch.Tensor, length: int = None) -> torch.Tensor:
+    """complex [..., T, F] -> float32 [..., (T-1)*64]: inverse of :func:`stft` (== scipy istft(spec * scale))."""
+    lead = spec.shape[:-2]
+    T, F = spec.shape[-2:]
+    z = spec.reshape(-1, T, F).transpose(1, 2).to(torch.complex64)
+    n = (T - 1) * HOP if length is None else length
+    x = torch.istft(z, n_fft=NPERSEG, hop_length=HOP, win_length=NPERSEG, window=_window(z.device), center=True,
+                    normalized=False, onesided=True, length=n, return_complex=False)
+    return x.reshape(*lead, n)
+
+
+def istft_int16(spec: torch.Tensor) -> torch.Tensor:
+    """tester.py:950-952: time signal * 32767 -> int16 (C-style truncation, like ndarray.astype(np.int16))."""
+    return (istft(spec) * MAX_INT16).to(torch.int16)
+
+
+def split_chunks(wav: np.ndarray, chunk: int) -> Tuple[List[np.ndarray], int]:
+    """data.py:555-595: wav [L, M] -> list of [chunk, M] pieces (last one zero-padded) and the pad length ``gap``.
+
+    The reference leaves L == chunk unhandled (neither branch, data.py:558-565); here it is one chunk, gap 0."""
+    L = wav.shape[0]
+    out, start = [], 0
+    while True:
+        piece = wav[start:start + chunk]
+        gap = chunk - piece.shape[0]
+        if gap:
+            piece = np.pad(piece, ((0, gap), (0, 0)))
+        out.append(piece)
+        start += chunk
+        if start >= L:
+            return out, gap
+
+
+def stitch_int16(chunks: List[np.ndarray], gap: int) -> np.ndarray:
+    """tester.py:960-969: drop the zero-padded tail of the last chunk and concatenate."""
+    chunks = list(chunks)
+    if gap:
+        chunks[-1] = chunks[-1][: len(chunks[-1]) - gap]
+    return np.concatenate(chunks)

@@ -1,0 +1,118 @@
+"""CPU-side checks of the C-ABI shared library: it loads, exports every symbol include/misonet.h declares, and its
+host-only entry points (plan construction, tensor registry, workspace sizing, argument validation) behave.
+No kernels are launched here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lib():
+    from misonet_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return _lib
+
+
+def test_header_symbols_exported():
+    L = _lib()
+    hdr = open(os.path.join(ROOT, "include", "misonet.h")).read()
+    declared = set(re.findall(r"\b(misonet_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    assert declared == set(L.SIGNATURES.keys()), declared ^ set(L.SIGNATURES.keys())
+    lib = L.lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.misonet_version() >= 100
+    assert lib.misonet_strerror(-4).decode() == "workspace too small"
+
+
+def _make(in_ch=12, out_ch=4, en=(24, 32, 32, 32, 32, 64, 128), de=(128, 64, 32, 32, 32, 32, 24), nf=129):
+    L = _lib()
+    cfg = L.Cfg(in_ch, out_ch, (C.c_int * 7)(*en), (C.c_int * 7)(*de), nf)
+    h = C.c_void_p()
+    return L, L.lib().misonet_net_create(C.byref(cfg), C.byref(h)), h
+
+
+def test_tensor_registry_matches_reference_keys():
+    from misonet_amd import weights as W
+    L, rc, h = _make()
+    assert rc == 0
+    lib = L.lib()
+    names = [lib.misonet_net_tensor_name(h, i).decode() for i in range(lib.misonet_net_num_tensors(h))]
+    spec = W.miso1_spec()
+    assert names == list(spec.keys()) and len(names) == 268
+    for i, k in enumerate(names):
+        assert lib.misonet_net_tensor_numel(h, i) == int(np.prod(spec[k]))
+    # MISO_3 geometry
+    L3, rc3, h3 = _make(in_ch=16, out_ch=2)
+    assert rc3 == 0
+    names3 = [lib.misonet_net_tensor_name(h3, i).decode() for i in range(lib.misonet_net_num_tensors(h3))]
+    assert names3 == list(W.miso3_spec().keys())
+    lib.misonet_net_destroy(h)
+    lib.misonet_net_destroy(h3)
+
+
+def test_workspace_and_validation():
+    L, rc, h = _make()
+    lib = L.lib()
+    w1 = lib.misonet_net_workspace_bytes(h, 1, 1001)
+    w2 = lib.misonet_net_workspace_bytes(h, 2, 1001)
+    assert 300e6 < w1 < 450e6 and 1.9 < w2 / w1 < 2.1           # ~0.37 GB of activations per sample at T = 1001
+    assert lib.misonet_net_workspace_bytes(h, 0, 10) == -1
+    # set_tensor validation
+    v = np.zeros(10, np.float32)
+    assert lib.misonet_net_set_tensor(h, b"nope", v.ctypes.data_as(C.c_void_p), 10) == L.EINVAL
+    assert b"nope" in lib.misonet_last_error()
+    assert lib.misonet_net_set_tensor(h, b"encoders.0.0.conv2d.bias", v.ctypes.data_as(C.c_void_p), 10) == L.EINVAL
+    # commit before all tensors are set -> state error naming the missing key
+    assert lib.misonet_net_commit(h) == L.ESTATE
+    assert b"missing state_dict key" in lib.misonet_last_error()
+    lib.misonet_net_destroy(h)
+    # unsupported geometries are rejected at create time
+    assert _make(nf=257)[1] == L.EINVAL                          # only F = 129 works
+    assert _make(en=(24, 32, 32, 32, 32, 64, 256))[1] == L.EINVAL
+    assert _make(de=(128, 64, 32, 32, 32, 32, 32))[1] == L.EINVAL  # skip-concat mismatch
+    assert _make(in_ch=13)[1] == L.EINVAL
+    assert lib.misonet_mvdr_workspace_bytes(2, 129, 6) > 0
+
+
+def test_host_mirror_requires_library_and_validates():
+    import misonet_amd as mz
+    from misonet_amd import weights as W
+    with pytest.raises(ValueError):
+        mz.MISO_1(2, 6, 8, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN")
+    with pytest.raises(ValueError):
+        mz.MISO_1(2, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "BN")
+    en = list(W.DEFAULT_EN_CH)
+    m = mz.MISO_1(2, 6, 7, en, list(W.DEFAULT_DE_CH), "IN")
+    assert en == list(W.DEFAULT_EN_CH)                           # no in-place mutation (model.py:16-17 mutates)
+    sd = W.make_state_dict(W.miso1_spec(), 0)
+    m.load_state_dict(sd)
+    back = m.state_dict()
+    assert list(back.keys()) == list(sd.keys())
+    assert np.array_equal(back["decoders.6.1.deconv2d.bias"].numpy(), sd["decoders.6.1.deconv2d.bias"])
+    bad = dict(sd)
+    bad["encoders.0.0.conv2d.weight"] = np.zeros((24, 16, 3, 3), np.float32)
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(bad)
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({k: v for k, v in list(sd.items())[:10]})
+    assert "MISO_1" in repr(m) and "2587384" in repr(m)
+    with pytest.raises(NotImplementedError):
+        m.train()
+
+
+def test_product_does_not_import_oracle():
+    """The product path must never route through the oracle or a CPU fallback."""
+    pkg = os.path.join(ROOT, "misonet_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+\.*oracle", src, flags=re.M), fn
+            assert "import oracle" not in src and "from oracle" not in src, fn

@@ -1,0 +1,43 @@
+"""The torch STFT / iSTFT used on the product side equals the reference's SciPy contract
+(dataloader/data.py:505-522,542; tester.py:949-952,979-990) -- checked on CPU against the oracle's SciPy form."""
+import numpy as np
+import torch
+
+from misonet_amd import stft as S
+from misonet_amd.weights import synthetic_utterance
+from oracle import pipeline_oracle
+
+
+def test_stft_matches_scipy_contract():
+    obs, _, _ = synthetic_utterance(2, 63 * 64, 3)
+    ref = pipeline_oracle.stft_chunk(obs)                                     # [M,T,F]
+    got = S.stft(torch.from_numpy(obs.T.copy())).numpy()
+    assert got.shape == ref.shape == (3, 64, 129)
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-6
+    full, _, _ = synthetic_utterance(2, 64000, 1)
+    assert S.stft(torch.from_numpy(full.T.copy())).shape == (1, 1001, 129)    # 16 kHz, 4 s -> T = 1001
+
+
+def test_istft_int16_matches_scipy_contract():
+    r = np.random.default_rng(0)
+    wav = (0.2 * r.standard_normal(63 * 64)).astype(np.float32)
+    spec = pipeline_oracle.stft_chunk(wav[:, None])[0]                         # [T,F]
+    ref = pipeline_oracle.istft_int16(spec)
+    got = S.istft_int16(torch.from_numpy(spec)).numpy()
+    assert got.shape == ref.shape == (63 * 64,)
+    assert np.max(np.abs(got.astype(np.int32) - ref.astype(np.int32))) <= 1
+    back = S.istft(torch.from_numpy(spec)).numpy()                             # round trip
+    assert np.max(np.abs(back - wav)) < 1e-5
+
+
+def test_chunking_and_stitching():
+    wav = np.arange(10 * 2, dtype=np.float32).reshape(10, 2)
+    chunks, gap = S.split_chunks(wav, 4)
+    assert len(chunks) == 3 and gap == 2 and all(c.shape == (4, 2) for c in chunks)
+    assert np.array_equal(chunks[2][2:], np.zeros((2, 2)))
+    chunks1, gap1 = S.split_chunks(wav[:3], 4)                                 # shorter than one chunk (data.py:558-565)
+    assert len(chunks1) == 1 and gap1 == 1
+    chunks2, gap2 = S.split_chunks(wav[:8], 4)
+    assert len(chunks2) == 2 and gap2 == 0
+    pcs = [np.arange(4, dtype=np.int16), np.arange(4, dtype=np.int16)]
+    assert S.stitch_int16(pcs, 3).tolist() == [0, 1, 2, 3, 0]
