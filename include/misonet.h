@@ -109,6 +109,12 @@ int misonet_pipeline_run(misonet_pipeline* p, const void* mix_dev, const void* c
                          misonet_stream stream);
 int misonet_pipeline_check(misonet_pipeline* p, const void* ws_dev, misonet_stream stream);
 
+/* ---- per-launch timing (bench.py roofline leg): while enabled, the library brackets every conv launch, the TCN
+ * section and the MVDR section of each forward with HIP events on the caller's stream.  kinds: 0 = conv3x3_mfma
+ * launches, 1 = TCN sections, 2 = MVDR sections, 3 = other.  misonet_profile_end synchronises and sums. */
+int misonet_profile_begin(int max_launches);
+int misonet_profile_end(double* ms_by_kind /*[4]*/, long long* launches_by_kind /*[4]*/);
+
 /* ---- timing helper: HIP events on the caller's stream (bench.py roofline leg) ------------------------------- */
 int misonet_event_create(void** ev);
 int misonet_event_record(void* ev, misonet_stream stream);

@@ -56,6 +56,8 @@ SIGNATURES = {
     "misonet_pipeline_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
     "misonet_pipeline_check": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "misonet_profile_begin": (C.c_int, [C.c_int]),
+    "misonet_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "misonet_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "misonet_event_record": (C.c_int, [C.c_void_p, C.c_void_p]),
     "misonet_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),

@@ -36,6 +36,32 @@ static int fail(int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return fail(MISONET_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
+// ---- optional per-launch timing with HIP events on the caller's stream (bench.py roofline leg) ------------------
+enum { PK_CONV = 0, PK_TCN, PK_MVDR, PK_OTHER, PK_N };
+struct ProfRec { int kind; hipEvent_t e0, e1; };
+struct Prof {
+  bool on = false;
+  std::vector<hipEvent_t> pool;
+  size_t used = 0;
+  std::vector<ProfRec> recs;
+  bool overflow = false;
+};
+static Prof g_prof;
+struct ProfScope {
+  hipStream_t s; int kind; hipEvent_t e0 = nullptr, e1 = nullptr; bool active = false;
+  ProfScope(hipStream_t s_, int kind_) : s(s_), kind(kind_) {
+    if (!g_prof.on) return;
+    if (g_prof.used + 2 > g_prof.pool.size()) { g_prof.overflow = true; return; }
+    e0 = g_prof.pool[g_prof.used++];
+    e1 = g_prof.pool[g_prof.used++];
+    active = (hipEventRecord(e0, s) == hipSuccess);
+  }
+  ~ProfScope() {
+    if (!active) return;
+    if (hipEventRecord(e1, s) == hipSuccess) g_prof.recs.push_back({kind, e0, e1});
+  }
+};
+
 // ---------------------------------------------------------------------------------------------------------------
 struct Tensor {
   std::string name;
@@ -289,7 +315,10 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
   a.sf = c.sf; a.padf = c.padf; a.tr2 = c.tr2; a.act = c.act;
   a.NR = conv_rows(c.sf, c.tr2);
   a.ncg = c.ncg; a.cop = c.cop;
-  HIPCHK(launch_conv(a, L.N, s));
+  {
+    ProfScope ps(s, PK_CONV);
+    HIPCHK(launch_conv(a, L.N, s));
+  }
   return MISONET_OK;
 }
 
@@ -299,6 +328,7 @@ static int forward_planar(misonet_net* n, const Layout& L, void* ws, hipStream_t
   for (const ConvL& c : n->enc) { int r = run_conv(n, L, ws, c, s); if (r) return r; }
   // ---- TCN ----
   {
+    ProfScope ps_tcn(s, PK_TCN);
     const int N = L.N, T = L.T, Tp = L.Tp;
     double* xs = stats_base(ws) + L.tcn_xs;
     double* ps = stats_base(ws) + L.tcn_ps;
@@ -696,6 +726,7 @@ int misonet_pipeline_run(misonet_pipeline* p, const void* mix, const void* clean
     a.src = {nullptr, nullptr, 0, 0, 0, 1};
     a.S = S; a.B = B; a.F = F; a.M = M; a.T = T; a.Tp = Tp; a.epsi = p->epsi;
     COut co = {in3 + (long long)M * plane, in3 + (long long)(2 * M + 2) * plane, (long long)S * in3_bs, in3_bs, 1, Tp};
+    ProfScope ps(s, PK_MVDR);
     HIPCHK(launch_mvdr(a, co, base + P.off_mvdr, s));
   }
   // 6. MISO3 per speaker (tester.py:1231-1244)
@@ -718,6 +749,35 @@ int misonet_pipeline_check(misonet_pipeline* p, const void* ws, misonet_stream s
   HIPCHK(hipMemcpyAsync(&flag, ws, sizeof(int), hipMemcpyDeviceToHost, reinterpret_cast<hipStream_t>(stream)));
   HIPCHK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
   if (flag) return fail(MISONET_ENAN, "NaN in pipeline output");
+  return MISONET_OK;
+}
+
+// ---- per-launch profiling -----------------------------------------------------------------------------------------
+int misonet_profile_begin(int max_launches) {
+  if (max_launches <= 0) return fail(MISONET_EINVAL, "max_launches must be positive");
+  while (g_prof.pool.size() < (size_t)max_launches * 2) {
+    hipEvent_t e;
+    HIPCHK(hipEventCreate(&e));
+    g_prof.pool.push_back(e);
+  }
+  g_prof.used = 0;
+  g_prof.recs.clear();
+  g_prof.overflow = false;
+  g_prof.on = true;
+  return MISONET_OK;
+}
+int misonet_profile_end(double* ms_by_kind, long long* launches_by_kind) {
+  g_prof.on = false;
+  if (!ms_by_kind || !launches_by_kind) return fail(MISONET_EINVAL, "null argument");
+  for (int k = 0; k < PK_N; ++k) { ms_by_kind[k] = 0.0; launches_by_kind[k] = 0; }
+  for (const ProfRec& r : g_prof.recs) {
+    HIPCHK(hipEventSynchronize(r.e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, r.e0, r.e1));
+    ms_by_kind[r.kind] += ms;
+    launches_by_kind[r.kind] += 1;
+  }
+  if (g_prof.overflow) return fail(MISONET_ENOMEM, "profile event pool exhausted");
   return MISONET_OK;
 }
 
