@@ -27,12 +27,24 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 int conv_cop(int Cout) { return Cout <= 32 ? 32 : 64; }
 int conv_rows(int sf, int tr2) { return tr2 ? 3 : sf * (FT - 1) + 3; }
 
-template <int NCO>
-__global__ __launch_bounds__(256) void conv3x3_mfma(const ConvArgs a) {
+// MODE 0: forward / stride-1-transposed conv (sf = 1, NR = 6 staged rows); MODE 1: stride-2 conv (NR = 9);
+// MODE 2: stride-2 transposed conv (NR = 3).
+//
+// Software pipeline per K-chunk (guide T14, "issue early / write late"): the global loads of chunk k+1 (NR float4 of
+// the input patch + 1 halo scalar + the weight slab share per thread) are issued into registers BEFORE the MFMA loop
+// of chunk k and are normalised and written to LDS after it, so HBM/L2 latency hides under the matrix work.
+// Staging roles are division-free: thread (q = tid & 31, ci = tid >> 5) owns frames t0+4q..t0+4q+3 of channel ci
+// for every staged row; threads < 16*NR own the two halo frames t0-1 / t0+128 of one (row, channel).
+template <int NCO, int MODE>
+__global__ __launch_bounds__(256, (NCO == 1 ? 3 : 2)) void conv3x3_mfma(const ConvArgs a) {
   constexpr int COP = NCO * 32;
+  constexpr int NR = MODE == 0 ? 6 : (MODE == 1 ? 9 : 3);
+  constexpr int SF = MODE == 1 ? 2 : 1;
+  constexpr bool TR2 = MODE == 2;
+  constexpr int NW4 = 9 * CK * COP / 4;          // float4 per weight slab
+  constexpr int NWI = (NW4 + 255) / 256;
   extern __shared__ __align__(16) float smem[];
-  const int NR = a.NR;
-  float* s_in = smem;                         // [CK][NR][TW]
+  float* s_in = smem;                         // [CK][NR][TW]: col 3 = frame t0-1, cols 4..131 = t0..t0+127, col 132 = t0+128
   float* s_w = s_in + CK * NR * TW;           // [9][CK][COP]
   float2* s_nrm = reinterpret_cast<float2*>(s_w + 9 * CK * COP);   // [CinP] (mean, rstd)
 
@@ -45,7 +57,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma(const ConvArgs a) {
   const int cg = blockIdx.z - n * a.ncg;
   const int T = a.T, Tp = a.Tp, Fin = a.Fin, Cin = a.Cin;
   const int nchunk = (Cin + CK - 1) / CK;
-  const int fin0 = a.tr2 ? (f0 >> 1) - 1 : a.sf * f0 - a.padf;
+  const int fin0 = TR2 ? (f0 >> 1) - 1 : SF * f0 - a.padf;
 
   // instance-norm parameters of the input channels (normalise-on-load)
   for (int c = tid; c < nchunk * CK; c += 256) {
@@ -63,7 +75,66 @@ __global__ __launch_bounds__(256) void conv3x3_mfma(const ConvArgs a) {
   }
 
   const float* in_n = a.in + (long long)n * a.in_bstride + (long long)a.in_c0 * Fin * Tp;
-  const float* w_g = a.w + (long long)cg * nchunk * (9 * CK * COP);
+  const float4* w_g = reinterpret_cast<const float4*>(a.w + (long long)cg * nchunk * (9 * CK * COP));
+
+  // staging roles
+  const int sq = tid & 31, sci = tid >> 5;
+  const int tg = t0 + 4 * sq;
+  const bool tok = tg < Tp;
+  const int hr = tid >> 4, hci = (tid >> 1) & 7, hside = tid & 1;
+  const int htg = hside ? t0 + TT : t0 - 1;
+  const bool hok = (hr < NR) && htg >= 0 && htg < T && (fin0 + hr) >= 0 && (fin0 + hr) < Fin;
+
+  float4 pin[NR];
+  float ph = 0.f;
+  float4 pw[NWI];
+
+  auto issue = [&](int kc) {
+    const int c = kc * CK + sci;
+    const bool cok = (c < Cin) && tok;
+    const float* base = in_n + (long long)c * Fin * Tp + tg;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int fin = fin0 + r;
+      pin[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (cok && fin >= 0 && fin < Fin) pin[r] = *reinterpret_cast<const float4*>(base + (long long)fin * Tp);
+    }
+    ph = 0.f;
+    const int c2 = kc * CK + hci;
+    if (hok && c2 < Cin) ph = in_n[((long long)c2 * Fin + (fin0 + hr)) * Tp + htg];
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) {
+      const int idx = tid + 256 * i;
+      pw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (NW4 % 256 == 0 || idx < NW4) pw[i] = w_g[(long long)kc * NW4 + idx];
+    }
+  };
+  auto commit = [&](int kc) {
+    const int c = kc * CK + sci;
+    const bool cok = (c < Cin) && tok;
+    const float2 m = s_nrm[c];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int fin = fin0 + r;
+      const bool ok = cok && fin >= 0 && fin < Fin;
+      float4 v = pin[r];
+      v.x = (ok && tg + 0 < T) ? (v.x - m.x) * m.y : 0.f;
+      v.y = (ok && tg + 1 < T) ? (v.y - m.x) * m.y : 0.f;
+      v.z = (ok && tg + 2 < T) ? (v.z - m.x) * m.y : 0.f;
+      v.w = (ok && tg + 3 < T) ? (v.w - m.x) * m.y : 0.f;
+      *reinterpret_cast<float4*>(s_in + (sci * NR + r) * TW + 4 + 4 * sq) = v;
+    }
+    if (hr < NR) {
+      const int c2 = kc * CK + hci;
+      const float2 m2 = s_nrm[c2];
+      s_in[(hci * NR + hr) * TW + (hside ? TT + 4 : 3)] = (hok && c2 < Cin) ? (ph - m2.x) * m2.y : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) {
+      const int idx = tid + 256 * i;
+      if (NW4 % 256 == 0 || idx < NW4) reinterpret_cast<float4*>(s_w)[idx] = pw[i];
+    }
+  };
 
   const int f = f0 + wave;
   const bool row_ok = f < a.Fout;                       // wave-uniform
@@ -80,49 +151,26 @@ __global__ __launch_bounds__(256) void conv3x3_mfma(const ConvArgs a) {
 
   const int half = lane >> 5, l31 = lane & 31;
 
-  for (int kc = 0; kc < nchunk; ++kc) {
-    __syncthreads();   // previous chunk fully consumed (and s_nrm visible on the first pass)
-    // ---- stage the normalised input patch: rows fin0..fin0+NR-1, frames t0-4..t0+131 ----
-    const int n4 = CK * NR * (TW / 4);
-    for (int i = tid; i < n4; i += 256) {
-      const int q = i % (TW / 4);
-      const int rr = i / (TW / 4);
-      const int r = rr % NR;
-      const int ci = rr / NR;
-      const int c = kc * CK + ci;
-      const int fin = fin0 + r;
-      const int tg = t0 - 4 + 4 * q;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c < Cin && fin >= 0 && fin < Fin && tg >= 0 && tg < Tp) {
-        v = *reinterpret_cast<const float4*>(in_n + ((long long)c * Fin + fin) * Tp + tg);
-        const float2 m = s_nrm[c];
-        v.x = (tg + 0 < T) ? (v.x - m.x) * m.y : 0.f;
-        v.y = (tg + 1 < T) ? (v.y - m.x) * m.y : 0.f;
-        v.z = (tg + 2 < T) ? (v.z - m.x) * m.y : 0.f;
-        v.w = (tg + 3 < T) ? (v.w - m.x) * m.y : 0.f;
-      }
-      *reinterpret_cast<float4*>(s_in + (ci * NR + r) * TW + 4 * q) = v;
-    }
-    // ---- stage the weight slab of this chunk (already in LDS order) ----
-    {
-      const float4* wsrc = reinterpret_cast<const float4*>(w_g + (long long)kc * (9 * CK * COP));
-      float4* wdst = reinterpret_cast<float4*>(s_w);
-      for (int i = tid; i < 9 * CK * COP / 4; i += 256) wdst[i] = wsrc[i];
-    }
-    __syncthreads();
+  issue(0);
+  __syncthreads();          // s_nrm visible
+  commit(0);
+  __syncthreads();
 
+  for (int kc = 0; kc < nchunk; ++kc) {
+    const bool more = (kc + 1 < nchunk);
+    if (more) issue(kc + 1);
     if (row_ok) {
 #pragma unroll
       for (int kt = 0; kt < 3; ++kt) {
 #pragma unroll
         for (int kf = 0; kf < 3; ++kf) {
           int rl;
-          if (a.tr2) {
+          if (TR2) {
             const int v = (f - f0) + kf;      // f0 is a multiple of 4: parity of (f + kf - 2)
             if (v & 1) continue;
             rl = v >> 1;
           } else {
-            rl = a.sf * (f - f0) + kf;
+            rl = SF * (f - f0) + kf;
           }
           const float* wrow = s_w + ((kt * 3 + kf) * CK + half) * COP + l31;
           const float* irow = s_in + (half * NR + rl) * TW + l31 + kt + 3;
@@ -145,10 +193,14 @@ __global__ __launch_bounds__(256) void conv3x3_mfma(const ConvArgs a) {
         }
       }
     }
+    __syncthreads();        // every wave is done reading this chunk
+    if (more) {
+      commit(kc + 1);
+      __syncthreads();
+    }
   }
-  __syncthreads();   // all waves done with s_in / s_w: reuse the front of LDS for the statistics
 
-  float* s_red = smem;   // [FT waves][COP][2]
+  float* s_red = smem;   // [FT waves][COP][2]  (safe: the loop ends with a barrier after the last reads)
   float* out_n = a.out + (long long)n * a.out_bstride + (long long)a.out_c0 * a.Fout * Tp;
 #pragma unroll
   for (int j = 0; j < NCO; ++j) {
@@ -213,21 +265,34 @@ static size_t conv_lds_bytes(int NR, int cop, int Cin) {
   return (size_t)(CK * NR * TW + 9 * CK * cop) * sizeof(float) + (size_t)nchunk * CK * sizeof(float2);
 }
 
-hipError_t conv_init() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma<1>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma<2>),
+template <int NCO, int MODE>
+static hipError_t set_lds_attr() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma<NCO, MODE>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+}
+
+hipError_t conv_init() {
+  hipError_t e;
+  if ((e = set_lds_attr<1, 0>()) != hipSuccess) return e;
+  if ((e = set_lds_attr<1, 1>()) != hipSuccess) return e;
+  if ((e = set_lds_attr<1, 2>()) != hipSuccess) return e;
+  if ((e = set_lds_attr<2, 0>()) != hipSuccess) return e;
+  if ((e = set_lds_attr<2, 1>()) != hipSuccess) return e;
+  return set_lds_attr<2, 2>();
 }
 
 hipError_t launch_conv(const ConvArgs& a, int n_samples, hipStream_t s) {
   dim3 grid((a.T + TT - 1) / TT, (a.Fout + FT - 1) / FT, n_samples * a.ncg);
   const size_t lds = conv_lds_bytes(a.NR, a.cop, a.Cin);
-  if (a.cop == 32)
-    hipLaunchKernelGGL(conv3x3_mfma<1>, grid, dim3(256), lds, s, a);
-  else
-    hipLaunchKernelGGL(conv3x3_mfma<2>, grid, dim3(256), lds, s, a);
+  const int mode = a.tr2 ? 2 : (a.sf == 2 ? 1 : 0);
+  if (a.NR != conv_rows(a.sf, a.tr2)) return hipErrorInvalidValue;
+#define MN_LAUNCH(NCO, MODE) hipLaunchKernelGGL((conv3x3_mfma<NCO, MODE>), grid, dim3(256), lds, s, a)
+  if (a.cop == 32) {
+    if (mode == 0) MN_LAUNCH(1, 0); else if (mode == 1) MN_LAUNCH(1, 1); else MN_LAUNCH(1, 2);
+  } else {
+    if (mode == 0) MN_LAUNCH(2, 0); else if (mode == 1) MN_LAUNCH(2, 1); else MN_LAUNCH(2, 2);
+  }
+#undef MN_LAUNCH
   return hipGetLastError();
 }
 
