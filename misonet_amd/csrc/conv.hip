@@ -23,9 +23,67 @@
 namespace mn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 int conv_cop(int Cout) { return Cout <= 32 ? 32 : 64; }
 int conv_rows(int sf, int tr2) { return tr2 ? 3 : sf * (FT - 1) + 3; }
+
+// MFMA work of one K-chunk for one wave: one output row, four 32-frame column tiles, NCO 32-channel row tiles.
+// The (tap, channel-pair) steps are flattened into one fully unrolled sequence with an explicit two-deep operand
+// pipeline: the ds_reads of step k+1 are issued before the MFMAs of step k, and a sched_barrier per step keeps the
+// compiler from hoisting more (which would spill).  All LDS addresses are two per-lane bases + immediates.
+// KFMASK selects the frequency taps (all three for convs; {1} / {0,2} for the odd / even rows of a stride-2
+// transposed conv).  The kernel always computes all four column tiles: frames >= T are staged as zeros, so a ragged
+// last tile costs MFMAs, not correctness (T = 1001 and T = 501 both end in a tile that needs four anyway).
+template <int NCO, int NR, int SF, bool TR2, int KFMASK>
+__device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[NCO][4], const float* s_in, const float* s_w, int frel,
+                                           int half, int l31) {
+  constexpr int COP = NCO * 32;
+  constexpr int NKF = ((KFMASK >> 0) & 1) + ((KFMASK >> 1) & 1) + ((KFMASK >> 2) & 1);
+  constexpr int NSTEP = 3 * NKF * (CK / 2);
+  const float* wbase = s_w + half * COP + l31;
+  // one input-row base per selected kf
+  const float* ibase[3];
+#pragma unroll
+  for (int kf = 0; kf < 3; ++kf) {
+    const int rl = TR2 ? ((frel + kf) >> 1) : (SF * frel + kf);
+    ibase[kf] = s_in + (half * NR + rl) * TW + l31 + 3;
+  }
+  float av[2][NCO], bv[2][4];
+#define MN_LOAD(ST, BUF)                                                                        \
+  {                                                                                             \
+    constexpr int tap_ = (ST) / (CK / 2), cp_ = (ST) % (CK / 2);                                \
+    constexpr int kt_ = tap_ / NKF, ks_ = tap_ % NKF;                                           \
+    constexpr int kf_ = (NKF == 3) ? ks_ : ((KFMASK == 2) ? 1 : (ks_ == 0 ? 0 : 2));            \
+    _Pragma("unroll") for (int j = 0; j < NCO; ++j)                                             \
+        av[BUF][j] = wbase[((kt_ * 3 + kf_) * CK + cp_ * 2) * COP + j * 32];                    \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                               \
+        bv[BUF][q] = ibase[kf_][cp_ * 2 * NR * TW + q * 32 + kt_];                              \
+  }
+  MN_LOAD(0, 0)
+#pragma unroll
+  for (int st = 0; st < NSTEP; ++st) {
+    const int cur = st & 1;
+    if (st + 1 < NSTEP) {
+      // (the macro needs a constant: unrolled loop index)
+      const int nx = st + 1;
+      const int tap_ = nx / (CK / 2), cp_ = nx % (CK / 2);
+      const int kt_ = tap_ / NKF, ks_ = tap_ % NKF;
+      const int kf_ = (NKF == 3) ? ks_ : ((KFMASK == 2) ? 1 : (ks_ == 0 ? 0 : 2));
+#pragma unroll
+      for (int j = 0; j < NCO; ++j) av[cur ^ 1][j] = wbase[((kt_ * 3 + kf_) * CK + cp_ * 2) * COP + j * 32];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bv[cur ^ 1][q] = ibase[kf_][cp_ * 2 * NR * TW + q * 32 + kt_];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < NCO; ++j)
+        acc[j][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][j], bv[cur][q], acc[j][q], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef MN_LOAD
+}
 
 // MODE 0: forward / stride-1-transposed conv (sf = 1, NR = 6 staged rows); MODE 1: stride-2 conv (NR = 9);
 // MODE 2: stride-2 transposed conv (NR = 3).
@@ -36,7 +94,7 @@ int conv_rows(int sf, int tr2) { return tr2 ? 3 : sf * (FT - 1) + 3; }
 // Staging roles are division-free: thread (q = tid & 31, ci = tid >> 5) owns frames t0+4q..t0+4q+3 of channel ci
 // for every staged row; threads < 16*NR own the two halo frames t0-1 / t0+128 of one (row, channel).
 template <int NCO, int MODE>
-__global__ __launch_bounds__(256, (NCO == 1 ? 3 : 2)) void conv3x3_mfma(const ConvArgs a) {
+__global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2) ? 3 : 2)) void conv3x3_mfma(const ConvArgs a) {
   constexpr int COP = NCO * 32;
   constexpr int NR = MODE == 0 ? 6 : (MODE == 1 ? 9 : 3);
   constexpr int SF = MODE == 1 ? 2 : 1;
@@ -75,7 +133,7 @@ __global__ __launch_bounds__(256, (NCO == 1 ? 3 : 2)) void conv3x3_mfma(const Co
   }
 
   const float* in_n = a.in + (long long)n * a.in_bstride + (long long)a.in_c0 * Fin * Tp;
-  const float4* w_g = reinterpret_cast<const float4*>(a.w + (long long)cg * nchunk * (9 * CK * COP));
+  const f32x4* w_g = reinterpret_cast<const f32x4*>(a.w + (long long)cg * nchunk * (9 * CK * COP));
 
   // staging roles
   const int sq = tid & 31, sci = tid >> 5;
@@ -85,56 +143,73 @@ __global__ __launch_bounds__(256, (NCO == 1 ? 3 : 2)) void conv3x3_mfma(const Co
   const int htg = hside ? t0 + TT : t0 - 1;
   const bool hok = (hr < NR) && htg >= 0 && htg < T && (fin0 + hr) >= 0 && (fin0 + hr) < Fin;
 
-  float4 pin[NR];
+  f32x4 pin[NR];
   float ph = 0.f;
-  float4 pw[NWI];
+  f32x4 pw[NWI];
 
-  auto issue = [&](int kc) {
-    const int c = kc * CK + sci;
-    const bool cok = (c < Cin) && tok;
-    const float* base = in_n + (long long)c * Fin * Tp + tg;
+  // All prefetch loads are unconditional with clamped 32-bit offsets from wave-uniform bases (no 64-bit address
+  // VGPRs, no branches); validity is re-derived in STAGE_COMMIT.
+  const unsigned row_e = (unsigned)Tp;
+  const unsigned plane_e = (unsigned)Fin * row_e;
+  const unsigned tg_e = (unsigned)(tg < Tp ? tg : Tp - 4);
+  unsigned hoff_e;
+  {
+    int fh = fin0 + (hr < NR ? hr : NR - 1);
+    fh = fh < 0 ? 0 : (fh >= Fin ? Fin - 1 : fh);
+    const int th = htg < 0 ? 0 : (htg >= Tp ? Tp - 1 : htg);
+    hoff_e = (unsigned)fh * row_e + (unsigned)th;
+  }
+  unsigned roff_e[NR];
 #pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      const int fin = fin0 + r;
-      pin[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (cok && fin >= 0 && fin < Fin) pin[r] = *reinterpret_cast<const float4*>(base + (long long)fin * Tp);
-    }
-    ph = 0.f;
-    const int c2 = kc * CK + hci;
-    if (hok && c2 < Cin) ph = in_n[((long long)c2 * Fin + (fin0 + hr)) * Tp + htg];
-#pragma unroll
-    for (int i = 0; i < NWI; ++i) {
-      const int idx = tid + 256 * i;
-      pw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (NW4 % 256 == 0 || idx < NW4) pw[i] = w_g[(long long)kc * NW4 + idx];
-    }
-  };
-  auto commit = [&](int kc) {
-    const int c = kc * CK + sci;
-    const bool cok = (c < Cin) && tok;
-    const float2 m = s_nrm[c];
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      const int fin = fin0 + r;
-      const bool ok = cok && fin >= 0 && fin < Fin;
-      float4 v = pin[r];
-      v.x = (ok && tg + 0 < T) ? (v.x - m.x) * m.y : 0.f;
-      v.y = (ok && tg + 1 < T) ? (v.y - m.x) * m.y : 0.f;
-      v.z = (ok && tg + 2 < T) ? (v.z - m.x) * m.y : 0.f;
-      v.w = (ok && tg + 3 < T) ? (v.w - m.x) * m.y : 0.f;
-      *reinterpret_cast<float4*>(s_in + (sci * NR + r) * TW + 4 + 4 * sq) = v;
-    }
-    if (hr < NR) {
-      const int c2 = kc * CK + hci;
-      const float2 m2 = s_nrm[c2];
-      s_in[(hci * NR + hr) * TW + (hside ? TT + 4 : 3)] = (hok && c2 < Cin) ? (ph - m2.x) * m2.y : 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < NWI; ++i) {
-      const int idx = tid + 256 * i;
-      if (NW4 % 256 == 0 || idx < NW4) reinterpret_cast<float4*>(s_w)[idx] = pw[i];
-    }
-  };
+  for (int r = 0; r < NR; ++r) {
+    int fin = fin0 + r;
+    fin = fin < 0 ? 0 : (fin >= Fin ? Fin - 1 : fin);
+    roff_e[r] = (unsigned)fin * row_e + tg_e;
+  }
+
+#define STAGE_ISSUE(KC)                                                                          \
+  {                                                                                              \
+    int c_ = (KC) * CK + sci;                                                                    \
+    c_ = c_ < Cin ? c_ : Cin - 1;                                                                \
+    const float* cb_ = in_n + (unsigned)c_ * plane_e;                                            \
+    _Pragma("unroll") for (int r = 0; r < NR; ++r)                                               \
+        pin[r] = *reinterpret_cast<const f32x4*>(cb_ + roff_e[r]);                              \
+    int c2_ = (KC) * CK + hci;                                                                   \
+    c2_ = c2_ < Cin ? c2_ : Cin - 1;                                                             \
+    ph = in_n[(unsigned)c2_ * plane_e + hoff_e];                                                 \
+    const f32x4* wsrc_ = w_g + (unsigned)(KC) * (unsigned)NW4;                                  \
+    _Pragma("unroll") for (int i = 0; i < NWI; ++i) {                                            \
+      unsigned idx_ = tid + 256 * i;                                                             \
+      if (NW4 % 256 != 0) idx_ = idx_ < (unsigned)NW4 ? idx_ : (unsigned)(NW4 - 1);              \
+      pw[i] = wsrc_[idx_];                                                                       \
+    }                                                                                            \
+  }
+
+#define STAGE_COMMIT(KC)                                                                         \
+  {                                                                                              \
+    const int c_ = (KC) * CK + sci;                                                              \
+    const bool cok_ = (c_ < Cin) && tok;                                                         \
+    const float2 m_ = s_nrm[c_];                                                                 \
+    _Pragma("unroll") for (int r = 0; r < NR; ++r) {                                             \
+      const int fin_ = fin0 + r;                                                                 \
+      const bool ok_ = cok_ && fin_ >= 0 && fin_ < Fin;                                          \
+      f32x4 v_ = pin[r];                                                                         \
+      v_.x = (ok_ && tg + 0 < T) ? (v_.x - m_.x) * m_.y : 0.f;                                   \
+      v_.y = (ok_ && tg + 1 < T) ? (v_.y - m_.x) * m_.y : 0.f;                                   \
+      v_.z = (ok_ && tg + 2 < T) ? (v_.z - m_.x) * m_.y : 0.f;                                   \
+      v_.w = (ok_ && tg + 3 < T) ? (v_.w - m_.x) * m_.y : 0.f;                                   \
+      *reinterpret_cast<f32x4*>(s_in + (sci * NR + r) * TW + 4 + 4 * sq) = v_;                   \
+    }                                                                                            \
+    if (hr < NR) {                                                                               \
+      const int c2_ = (KC) * CK + hci;                                                           \
+      const float2 m2_ = s_nrm[c2_];                                                             \
+      s_in[(hci * NR + hr) * TW + (hside ? TT + 4 : 3)] = (hok && c2_ < Cin) ? (ph - m2_.x) * m2_.y : 0.f; \
+    }                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < NWI; ++i) {                                            \
+      const int idx_ = tid + 256 * i;                                                            \
+      if (NW4 % 256 == 0 || idx_ < NW4) reinterpret_cast<f32x4*>(s_w)[idx_] = pw[i];            \
+    }                                                                                            \
+  }
 
   const int f = f0 + wave;
   const bool row_ok = f < a.Fout;                       // wave-uniform
@@ -151,51 +226,25 @@ __global__ __launch_bounds__(256, (NCO == 1 ? 3 : 2)) void conv3x3_mfma(const Co
 
   const int half = lane >> 5, l31 = lane & 31;
 
-  issue(0);
+  STAGE_ISSUE(0)
   __syncthreads();          // s_nrm visible
-  commit(0);
+  STAGE_COMMIT(0)
   __syncthreads();
 
   for (int kc = 0; kc < nchunk; ++kc) {
     const bool more = (kc + 1 < nchunk);
-    if (more) issue(kc + 1);
+    if (more) STAGE_ISSUE(kc + 1)
     if (row_ok) {
-#pragma unroll
-      for (int kt = 0; kt < 3; ++kt) {
-#pragma unroll
-        for (int kf = 0; kf < 3; ++kf) {
-          int rl;
-          if (TR2) {
-            const int v = (f - f0) + kf;      // f0 is a multiple of 4: parity of (f + kf - 2)
-            if (v & 1) continue;
-            rl = v >> 1;
-          } else {
-            rl = SF * (f - f0) + kf;
-          }
-          const float* wrow = s_w + ((kt * 3 + kf) * CK + half) * COP + l31;
-          const float* irow = s_in + (half * NR + rl) * TW + l31 + kt + 3;
-#pragma unroll
-          for (int cp = 0; cp < CK / 2; ++cp) {
-            float av[NCO], bv[4];
-#pragma unroll
-            for (int j = 0; j < NCO; ++j) av[j] = wrow[cp * 2 * COP + j * 32];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) bv[s] = (s < nseg) ? irow[cp * 2 * NR * TW + s * 32] : 0.f;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-              if (s < nseg) {
-#pragma unroll
-                for (int j = 0; j < NCO; ++j)
-                  acc[j][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[s], acc[j][s], 0, 0, 0);
-              }
-            }
-          }
-        }
+      if (TR2) {
+        if ((f - f0) & 1) chunk_mfma<NCO, NR, SF, TR2, 2>(acc, s_in, s_w, f - f0, half, l31);
+        else chunk_mfma<NCO, NR, SF, TR2, 5>(acc, s_in, s_w, f - f0, half, l31);
+      } else {
+        chunk_mfma<NCO, NR, SF, TR2, 7>(acc, s_in, s_w, f - f0, half, l31);
       }
     }
     __syncthreads();        // every wave is done reading this chunk
     if (more) {
-      commit(kc + 1);
+      STAGE_COMMIT(kc + 1)
       __syncthreads();
     }
   }
@@ -259,6 +308,9 @@ __global__ __launch_bounds__(256, (NCO == 1 ? 3 : 2)) void conv3x3_mfma(const Co
     }
   }
 }
+
+#undef STAGE_ISSUE
+#undef STAGE_COMMIT
 
 static size_t conv_lds_bytes(int NR, int cop, int Cin) {
   const int nchunk = (Cin + CK - 1) / CK;
