@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=16, help="utterances per GPU per step (BASELINE configs[3]: 16)")
     ap.add_argument("--frames", type=int, default=1001)
+    ap.add_argument("--precision", choices=["f32", "bf16x3"], default="f32", help="arithmetic of the 3x3 convs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket launches with HIP events")
     args = ap.parse_args()
@@ -92,6 +93,8 @@ def main():
     m1.load_state_dict(sd1)
     m3 = mz.MISO_3(1, N_MIC, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN").cuda(local_rank)
     m3.load_state_dict(sd3)
+    m1.set_precision(args.precision)
+    m3.set_precision(args.precision)
     enh = mz.Enhancer(m1.eval(), m3.eval(), num_spks=N_SPK, ref_ch=0)
 
     # ---- synthetic inputs (SURVEY.md 8(d) config 2-5 generator), global utterance index = rank*B + i ----
@@ -162,7 +165,7 @@ def main():
             "metric": "utterances/sec MISO1->MVDR->MISO3, 6-mic 16kHz 4s",
             "value": round(value, 3), "unit": "utt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "BASELINE configs[3]: synthetic 6-mic 16 kHz 4 s, full MISO1x6 -> align -> MVDRx2 -> MISO3x2",
                        "batch_per_gpu": B, "frames": T, "freq_bins": 129, "parallelism": f"utterance-shard x{world}"},
             "realtime_factor": round(value * (n / 16000.0), 2),

@@ -59,6 +59,12 @@ int misonet_net_set_tensor(misonet_net* net, const char* key, const float* host_
 /* all tensors set -> repack into the kernel layouts and upload to the current device (synchronous) */
 int misonet_net_commit(misonet_net* net);
 
+/* arithmetic of the 3x3 convolutions (99.4 % of the FLOPs): 0 = exact float32 matrix cores
+ * (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain; default), 1 = "bf16x3": every product is evaluated as
+ * w_hi*x_hi + w_hi*x_lo + w_lo*x_hi on the bf16 matrix cores with f32 accumulation (~1e-5 relative per layer). */
+int misonet_net_set_precision(misonet_net* net, int mode);
+int misonet_net_get_precision(const misonet_net* net);
+
 /* workspace (device bytes) for n_samples spectrograms of n_frames frames */
 long long misonet_net_workspace_bytes(const misonet_net* net, int n_samples, int n_frames);
 

@@ -29,6 +29,7 @@ struct ConvArgs {
   double* out_stats;        // [n][out_sstride][2], accumulated with atomics when act != 0
   const float* w;           // packed [ncg][nchunk][9][CK][COP]
   const float* bias;        // [ncg*COP]
+  const unsigned short* w16; // bf16x3 path: packed [ncg][nchunk16][hi|lo][9][2][COP][8] bf16, or nullptr
   long long in_bstride;     // floats per sample of the input buffer
   long long out_bstride;
   int in_sstride, out_sstride;   // channels per sample in the stats arrays (= channels of the whole buffer)
@@ -48,6 +49,8 @@ int conv_cop(int Cout);                      // 32 (Cout <= 32) or 64
 int conv_rows(int sf, int tr2);              // NR for the mode
 hipError_t launch_conv(const ConvArgs& a, int n_samples, hipStream_t s);
 hipError_t conv_init();                      // dynamic-LDS attributes
+hipError_t launch_conv_bf16(const ConvArgs& a, int n_samples, hipStream_t s);   // conv_bf16.hip (needs a.w16)
+hipError_t conv_bf16_init();
 
 // ---- TCN (reference model.py:486-632) -----------------------------------------------------------------------------
 // x0 = IN2d(raw) materialised as the residual stream + its per-(n,c) statistics

@@ -83,6 +83,7 @@ struct ConvL {
   int wt, bt;                   // tensor indices
   int cop, ncg;
   long long w_off = 0, b_off = 0;   // offsets (floats) into the device weight arena
+  long long w16_off = 0;            // offset (floats) of the bf16 hi/lo packed weights
 };
 
 struct TcnHalf { int dw, prelu, gamma, beta, pw; long long o_dw, o_prelu, o_gamma, o_beta, o_pw; };
@@ -110,6 +111,7 @@ struct misonet_net {
   std::vector<Tap> taps;
   float* w_dev = nullptr;
   bool committed = false;
+  int precision = 0;             // 0: exact f32 MFMA, 1: bf16x3 split MFMA
 };
 
 static int find_tensor(const misonet_net* n, const std::string& name) {
@@ -305,6 +307,7 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
   a.out_stats = stats_ptr(L, ws, c.out_buf);
   a.w = n->w_dev + c.w_off;
   a.bias = n->w_dev + c.b_off;
+  a.w16 = n->precision == 1 ? reinterpret_cast<const unsigned short*>(n->w_dev + c.w16_off) : nullptr;
   a.in_bstride = bstride(n, L, c.in_buf);
   a.out_bstride = bstride(n, L, c.out_buf);
   a.in_sstride = n->bufs[c.in_buf].C;
@@ -317,7 +320,8 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
   a.ncg = c.ncg; a.cop = c.cop;
   {
     ProfScope ps(s, PK_CONV);
-    HIPCHK(launch_conv(a, L.N, s));
+    if (a.w16) HIPCHK(launch_conv_bf16(a, L.N, s));
+    else HIPCHK(launch_conv(a, L.N, s));
   }
   return MISONET_OK;
 }
@@ -446,6 +450,48 @@ static void pack_conv(const misonet_net* n, const ConvL& c, std::vector<float>& 
   for (int co = 0; co < c.ncg * COP; ++co) b[co] = co < c.Cout ? Bv[co] : 0.f;
 }
 
+static inline unsigned short f32_to_bf16_rne(float f) {
+  unsigned int u;
+  memcpy(&u, &f, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+static inline float bf16_to_f32(unsigned short h) {
+  unsigned int u = (unsigned int)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+// bf16x3 path: [cg][chunk of 16 ci][hi|lo][tap][octet h][COP][8] bf16 (conv_bf16.hip)
+static void pack_conv_bf16(const misonet_net* n, const ConvL& c, std::vector<float>& arena) {
+  const std::vector<float>& W = n->tensors[c.wt].host;
+  const int nchunk = (c.Cin + 15) / 16;
+  const int COP = c.cop;
+  unsigned short* w = reinterpret_cast<unsigned short*>(arena.data() + c.w16_off);
+  const long long img = 9LL * 2 * COP * 8;
+  for (int cg = 0; cg < c.ncg; ++cg)
+    for (int kc = 0; kc < nchunk; ++kc)
+      for (int kt = 0; kt < 3; ++kt)
+        for (int kf = 0; kf < 3; ++kf)
+          for (int h = 0; h < 2; ++h)
+            for (int col = 0; col < COP; ++col)
+              for (int e = 0; e < 8; ++e) {
+                const int ci = kc * 16 + 8 * h + e, co = cg * COP + col;
+                float v = 0.f;
+                if (ci < c.Cin && co < c.Cout) {
+                  if (c.transposed) v = W[(((long long)ci * c.Cout + co) * 3 + (2 - kt)) * 3 + (2 - kf)];
+                  else v = W[(((long long)co * c.Cin + ci) * 3 + kt) * 3 + kf];
+                }
+                const unsigned short hi = f32_to_bf16_rne(v);
+                const unsigned short lo = f32_to_bf16_rne(v - bf16_to_f32(hi));
+                const long long base = ((long long)cg * nchunk + kc) * 2 * img;
+                const long long idx = ((((long long)(kt * 3 + kf)) * 2 + h) * COP + col) * 8 + e;
+                w[base + idx] = hi;
+                w[base + img + idx] = lo;
+              }
+}
+
 int misonet_net_commit(misonet_net* n) {
   if (!n) return fail(MISONET_EINVAL, "null argument");
   for (const Tensor& t : n->tensors)
@@ -457,6 +503,7 @@ int misonet_net_commit(misonet_net* n) {
       const int nchunk = (c.Cin + CK - 1) / CK;
       c.w_off = take((long long)c.ncg * nchunk * 9 * CK * c.cop);
       c.b_off = take((long long)c.ncg * c.cop);
+      c.w16_off = take((long long)c.ncg * ((c.Cin + 15) / 16) * 2 * 9 * 2 * c.cop * 8 / 2);   // u16 -> floats
     }
   };
   place(n->enc);
@@ -470,8 +517,8 @@ int misonet_net_commit(misonet_net* n) {
       tb.h[h].o_pw = take(128 * 128);
     }
   std::vector<float> arena((size_t)off, 0.f);
-  for (const ConvL& c : n->enc) pack_conv(n, c, arena);
-  for (const ConvL& c : n->dec) pack_conv(n, c, arena);
+  for (const ConvL& c : n->enc) { pack_conv(n, c, arena); pack_conv_bf16(n, c, arena); }
+  for (const ConvL& c : n->dec) { pack_conv(n, c, arena); pack_conv_bf16(n, c, arena); }
   for (const TcnBlock& tb : n->tcn)
     for (int h = 0; h < 2; ++h) {
       const TcnHalf& H = tb.h[h];
@@ -487,9 +534,18 @@ int misonet_net_commit(misonet_net* n) {
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&n->w_dev), arena.size() * sizeof(float)));
   HIPCHK(hipMemcpy(n->w_dev, arena.data(), arena.size() * sizeof(float), hipMemcpyHostToDevice));
   HIPCHK(conv_init());
+  HIPCHK(conv_bf16_init());
   n->committed = true;
   return MISONET_OK;
 }
+
+int misonet_net_set_precision(misonet_net* n, int mode) {
+  if (!n) return fail(MISONET_EINVAL, "null argument");
+  if (mode != 0 && mode != 1) return fail(MISONET_EINVAL, "precision mode must be 0 (f32) or 1 (bf16x3)");
+  n->precision = mode;
+  return MISONET_OK;
+}
+int misonet_net_get_precision(const misonet_net* n) { return n ? n->precision : -1; }
 
 long long misonet_net_workspace_bytes(const misonet_net* n, int n_samples, int n_frames) {
   if (!n || n_samples <= 0 || n_frames <= 0) return -1;

@@ -36,7 +36,7 @@ def main():
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     name_col = "name" if "name" in cols else "kernel_name"
     rows = cur.execute(f"select {name_col}, start, end from kernels order by start").fetchall()
-    conv = [(n, e - s) for n, s, e in rows if "conv3x3_mfma" in n]
+    conv = [(n, e - s) for n, s, e in rows if "conv3x3_" in n]
     assert len(conv) % 128 == 0, len(conv)
     last = conv[-128:]
     l1, l3 = layers(12, 4), layers(16, 2)
