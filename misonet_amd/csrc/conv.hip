@@ -18,6 +18,7 @@
 // Epilogue: + bias, ELU (model.py:412,429,444), raw store, per-(n,co) sum / sum^2 for the instance norm that the
 // NEXT layer applies while staging (model.py:413,430,445).
 #include "kernels.hpp"
+#include "conv_epilogue.hpp"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 namespace mn {
@@ -75,6 +76,7 @@ __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[NCO][4], const float* s
 #pragma unroll
       for (int q = 0; q < 4; ++q) bv[cur ^ 1][q] = ibase[kf_][cp_ * 2 * NR * TW + q * 32 + kt_];
     }
+    __builtin_amdgcn_sched_barrier(0);     // keep the next step's ds_reads AHEAD of this step's MFMAs
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -250,50 +252,7 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2) ? 3 : 2)) void conv3x
   }
 
   float* s_red = smem;   // [FT waves][COP][2]  (safe: the loop ends with a barrier after the last reads)
-  float* out_n = a.out + (long long)n * a.out_bstride + (long long)a.out_c0 * a.Fout * Tp;
-#pragma unroll
-  for (int j = 0; j < NCO; ++j) {
-    float s1[16], s2[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
-    if (row_ok) {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        if (s < nseg) {
-          const int t = t0 + s * 32 + l31;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int co_l = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int co = cg * COP + co_l;
-            float v = acc[j][s][r] + a.bias[co];
-            if (a.act) v = v > 0.f ? v : expm1f(v);
-            const bool ok = (co < a.Cout) && (t < T);
-            if (ok) {
-              out_n[((long long)co * a.Fout + f) * Tp + t] = v;
-              s1[r] += v;
-              s2[r] += v * v;
-            }
-          }
-        }
-      }
-    }
-    if (a.act) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float x1 = s1[r], x2 = s2[r];
-#pragma unroll
-        for (int m = 16; m >= 1; m >>= 1) {
-          x1 += __shfl_xor(x1, m, 64);
-          x2 += __shfl_xor(x2, m, 64);
-        }
-        if (l31 == 0) {
-          const int co_l = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          s_red[(wave * COP + co_l) * 2 + 0] = x1;
-          s_red[(wave * COP + co_l) * 2 + 1] = x2;
-        }
-      }
-    }
-  }
+  conv_epilogue<NCO>(a, acc, n, cg, f, t0, row_ok, lane, s_red + wave * (COP * 2));
   if (a.act) {
     __syncthreads();
     if (tid < COP * 2) {

@@ -44,6 +44,7 @@ struct ConvArgs {
   int NR;                   // staged input rows per workgroup
   int ncg;                  // output-channel groups (grid.z = n_samples * ncg)
   int cop;                  // 32 or 64 output channels per group
+  int dbg;                  // timing experiments only (MISONET_WS_DEBUG bits): 1 = consumers skip MFMAs, 2 = producers idle, 4 = skip epilogue
 };
 int conv_cop(int Cout);                      // 32 (Cout <= 32) or 64
 int conv_rows(int sf, int tr2);              // NR for the mode

@@ -318,6 +318,8 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
   a.sf = c.sf; a.padf = c.padf; a.tr2 = c.tr2; a.act = c.act;
   a.NR = conv_rows(c.sf, c.tr2);
   a.ncg = c.ncg; a.cop = c.cop;
+  a.dbg = 0;
+  if (a.w16) { a.cop = 32; a.ncg = (c.Cout + 31) / 32; }
   {
     ProfScope ps(s, PK_CONV);
     if (a.w16) HIPCHK(launch_conv_bf16(a, L.N, s));
@@ -467,10 +469,11 @@ static inline float bf16_to_f32(unsigned short h) {
 static void pack_conv_bf16(const misonet_net* n, const ConvL& c, std::vector<float>& arena) {
   const std::vector<float>& W = n->tensors[c.wt].host;
   const int nchunk = (c.Cin + 15) / 16;
-  const int COP = c.cop;
+  const int COP = 32;                       // the bf16x3 kernels always work on 32-channel output groups
+  const int ncg16 = (c.Cout + 31) / 32;
   unsigned short* w = reinterpret_cast<unsigned short*>(arena.data() + c.w16_off);
   const long long img = 9LL * 2 * COP * 8;
-  for (int cg = 0; cg < c.ncg; ++cg)
+  for (int cg = 0; cg < ncg16; ++cg)
     for (int kc = 0; kc < nchunk; ++kc)
       for (int kt = 0; kt < 3; ++kt)
         for (int kf = 0; kf < 3; ++kf)
@@ -503,7 +506,7 @@ int misonet_net_commit(misonet_net* n) {
       const int nchunk = (c.Cin + CK - 1) / CK;
       c.w_off = take((long long)c.ncg * nchunk * 9 * CK * c.cop);
       c.b_off = take((long long)c.ncg * c.cop);
-      c.w16_off = take((long long)c.ncg * ((c.Cin + 15) / 16) * 2 * 9 * 2 * c.cop * 8 / 2);   // u16 -> floats
+      c.w16_off = take((long long)((c.Cout + 31) / 32) * ((c.Cin + 15) / 16) * 2 * 9 * 2 * 32 * 8 / 2);   // u16 -> floats
     }
   };
   place(n->enc);
