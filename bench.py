@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 N_MIC, N_SPK, N_SAMPLES = 6, 2, 64000
 PEAK_F32_MFMA_TF = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, fp32 matrix peak (spec)
+PEAK_BF16_MFMA_TF = 2500.0      # dense bf16 matrix peak (spec); the bf16x3 mode issues 3 bf16 MFMA FLOPs per algorithmic FLOP
 PEAK_HBM_TBS = 8.0
 ALGO_BYTES_PER_UTT = 6.23e9     # 8 forwards x 0.776 GB + 2 x 13.43 MB
 
@@ -57,6 +58,91 @@ def conv_flops_per_forward(in_ch, out_ch, T, en=(24, 32, 32, 32, 32, 64, 128), d
     return 2.0 * mac
 
 
+def conv_bytes_per_forward(in_ch, out_ch, T, en=(24, 32, 32, 32, 32, 64, 128), de=(128, 64, 32, 32, 32, 32, 24)):
+    """Algorithmic HBM bytes of the conv layers of one forward-sample with layer-level fusion only (every conv reads its
+    whole (concatenated) input once and writes its output once, float32): the 1.46 GB figure of SURVEY.md 8(d)."""
+    Fe = [127, 63, 31, 15, 7, 3, 1]
+    el = 0
+
+    def dense(c0, g1, g2, F):
+        return sum((c0 + i * g1) + (g1 if i < 4 else g2) for i in range(5)) * F
+    ench = [in_ch] + list(en)
+    Fin = [129] + Fe
+    for b in range(7):
+        el += ench[b] * Fin[b] + ench[b + 1] * Fe[b]
+        if b < 5:
+            el += dense(en[b], en[b], en[b], Fe[b])
+    dech = list(de) + [out_ch]
+    Fo = [3, 7, 15, 31, 63, 127, 129]
+    for i in range(7):
+        Fi = Fe[6 - i]
+        if i >= 2:
+            el += dense(2 * de[i], de[i], 2 * de[i], Fi)
+        el += 2 * de[i] * Fi + dech[i + 1] * Fo[i]
+    return 4.0 * el * T
+
+
+def run_steps(enh, mix, clean, out, steps, warmup, dist, L, _lib, profile):
+    """warm-up, then time exactly `steps` passes between barrier + synchronize; returns (seconds, ms_by_kind, counts)."""
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(warmup):
+        enh.enhance(mix, clean, check_nan=False, out=out)
+    barrier()
+    if profile:
+        _lib.check(L.misonet_profile_begin(steps * 200))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        enh.enhance(mix, clean, check_nan=False, out=out)
+    barrier()
+    dt = time.perf_counter() - t0
+    ms = (C.c_double * 4)()
+    cnt = (C.c_longlong * 4)()
+    if profile:
+        _lib.check(L.misonet_profile_end(ms, cnt))
+    return dt, list(ms), list(cnt)
+
+
+def roofline_objects(precision, B, T, steps, dt_conv_ms, n_launch, value_per_gpu):
+    """roofline of the dominant kernel (the 3x3 conv launches) for one precision mode."""
+    fl1 = conv_flops_per_forward(2 * N_MIC, 2 * N_SPK, T)
+    fl3 = conv_flops_per_forward(2 * (N_MIC + 2), 2, T)
+    by1 = conv_bytes_per_forward(2 * N_MIC, 2 * N_SPK, T)
+    by3 = conv_bytes_per_forward(2 * (N_MIC + 2), 2, T)
+    flops_step = B * (N_MIC * fl1 + N_SPK * fl3)
+    bytes_step = B * (N_MIC * by1 + N_SPK * by3)
+    conv_s = dt_conv_ms / 1e3
+    ach_tf = flops_step * steps / conv_s / 1e12
+    ach_tb = bytes_step * steps / conv_s / 1e12
+    traffic, busy = None, None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))[precision]
+        traffic, busy = tj["bytes_per_launch"], tj.get("mfma_busy_frac")
+    except Exception:
+        pass
+    common = {"kernel": "conv3x3_mfma" if precision == "f32" else "conv3x3_bf16x3",
+              "launches_per_step": int(n_launch // steps), "avg_launch_ms": round(dt_conv_ms / max(n_launch, 1), 4),
+              "algorithmic_gflop_per_launch": round(flops_step * steps / max(n_launch, 1) / 1e9, 2),
+              "algorithmic_gbyte_per_launch": round(bytes_step * steps / max(n_launch, 1) / 1e9, 3),
+              "traffic": traffic, "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, x2 fetch correction)",
+              "mfma_busy_frac_pmc": busy}
+    mfma_peak = PEAK_F32_MFMA_TF if precision == "f32" else PEAK_BF16_MFMA_TF
+    r_mfma = dict(common, bound="mfma", achieved=round(ach_tf, 3), peak=mfma_peak, unit="TFLOP/s",
+                  frac=round(ach_tf / mfma_peak, 4))
+    if precision != "f32":
+        r_mfma["issued_tflops"] = round(3 * ach_tf, 1)          # 3 bf16 MFMAs per algorithmic product
+        r_mfma["frac_issued"] = round(3 * ach_tf / mfma_peak, 4)
+    r_hbm = dict(common, bound="hbm", achieved=round(ach_tb * 1e3, 1), peak=PEAK_HBM_TBS * 1e3, unit="GB/s",
+                 frac=round(ach_tb / PEAK_HBM_TBS, 4))
+    # binding roofline: arithmetic intensity of the layer vs the ridge of the mode's effective matrix peak
+    eff_peak = mfma_peak if precision == "f32" else mfma_peak / 3.0
+    ai = flops_step / bytes_step
+    binding = r_mfma if ai >= eff_peak * 1e12 / (PEAK_HBM_TBS * 1e12) else r_hbm
+    return binding, (r_hbm if binding is r_mfma else r_mfma)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -64,7 +150,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=16, help="utterances per GPU per step (BASELINE configs[3]: 16)")
     ap.add_argument("--frames", type=int, default=1001)
-    ap.add_argument("--precision", choices=["f32", "bf16x3"], default="f32", help="arithmetic of the 3x3 convs")
+    ap.add_argument("--precision", choices=["f32", "bf16x3"], default="bf16x3",
+                    help="arithmetic of the 3x3 convs: exact f32 MFMA, or 3-term bf16 split on the bf16 MFMA (default)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the short run of the other precision mode (N = 1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket launches with HIP events")
     args = ap.parse_args()
@@ -109,30 +197,9 @@ def main():
     clean = torch.stack(cleans).contiguous()
     out = torch.empty((B, N_SPK, T, 129), dtype=torch.complex64, device=dev)
 
-    def step():
-        enh.enhance(mix, clean, check_nan=False, out=out)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
     L = _lib.lib()
     profile = not args.no_profile
-    if profile:
-        _lib.check(L.misonet_profile_begin(args.steps * 200))
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    ms = (C.c_double * 4)()
-    cnt = (C.c_longlong * 4)()
-    if profile:
-        _lib.check(L.misonet_profile_end(ms, cnt))
+    dt, ms, cnt = run_steps(enh, mix, clean, out, args.steps, args.warmup, dist, L, _lib, profile)
     if not os.environ.get("MISONET_BENCH_NOCHECK"):      # (timing experiments with deliberately wrong results)
         _lib.check(L.misonet_pipeline_check(enh._pipe, enh.workspace(B, T).data_ptr(), _lib.stream_ptr(dev)))
     if dist is not None:
@@ -143,22 +210,24 @@ def main():
     if rank == 0:
         utt = world * B * args.steps
         value = utt / dt
-        fl1 = conv_flops_per_forward(2 * N_MIC, 2 * N_SPK, T)
-        fl3 = conv_flops_per_forward(2 * (N_MIC + 2), 2, T)
-        conv_flops_step = B * (N_MIC * fl1 + N_SPK * fl3)                # this rank, per step
-        roof = None
+        roof, roof2 = None, None
         if profile and cnt[0] > 0:
-            conv_s = ms[0] / 1e3
-            ach = conv_flops_step * args.steps / conv_s / 1e12
-            roof = {"bound": "mfma", "kernel": "conv3x3_mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TF,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TF, 4), "traffic": None,
-                    "launches_per_step": int(cnt[0] // args.steps),
-                    "avg_launch_ms": round(ms[0] / cnt[0], 4),
-                    "algorithmic_gflop_per_launch": round(conv_flops_step * args.steps / cnt[0] / 1e9, 2),
-                    "time_share": {"conv_ms_per_step": round(ms[0] / args.steps, 2),
-                                   "tcn_ms_per_step": round(ms[1] / args.steps, 2),
-                                   "mvdr_ms_per_step": round(ms[2] / args.steps, 2)},
-                    "hbm_frac_pipeline": round(ALGO_BYTES_PER_UTT * (value / world) / (PEAK_HBM_TBS * 1e12), 4)}
+            roof, roof2 = roofline_objects(args.precision, B, T, args.steps, ms[0], cnt[0], value / world)
+            roof["time_share"] = {"conv_ms_per_step": round(ms[0] / args.steps, 2),
+                                  "tcn_ms_per_step": round(ms[1] / args.steps, 2),
+                                  "mvdr_ms_per_step": round(ms[2] / args.steps, 2)}
+            roof["hbm_frac_pipeline"] = round(ALGO_BYTES_PER_UTT * (value / world) / (PEAK_HBM_TBS * 1e12), 4)
+        alt = None
+        if world == 1 and not args.no_alt and profile:
+            other = "f32" if args.precision == "bf16x3" else "bf16x3"
+            m1.set_precision(other)
+            m3.set_precision(other)
+            k = max(2, min(3, args.steps))
+            dt2, ms2, cnt2 = run_steps(enh, mix, clean, out, k, 1, None, L, _lib, True)
+            r2, _ = roofline_objects(other, B, T, k, ms2[0], cnt2[0], B * k / dt2)
+            alt = {"dtype": other, "value": round(B * k / dt2, 3), "unit": "utt/s", "steps": k, "roofline": r2}
+            m1.set_precision(args.precision)
+            m3.set_precision(args.precision)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(sd1, sd3, T)
@@ -170,7 +239,7 @@ def main():
             "config": {"workload": "BASELINE configs[3]: synthetic 6-mic 16 kHz 4 s, full MISO1x6 -> align -> MVDRx2 -> MISO3x2",
                        "batch_per_gpu": B, "frames": T, "freq_bins": 129, "parallelism": f"utterance-shard x{world}"},
             "realtime_factor": round(value * (n / 16000.0), 2),
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_other": roof2, "alt_precision": alt, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

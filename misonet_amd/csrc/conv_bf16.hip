@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256, (NCO == 1 ? 2 : 1)) void conv3x3_bf16x3(const 
   const int fin0 = TR2 ? (f0 >> 1) - 1 : SF * f0 - a.padf;
 
   for (int c = tid; c < nchunk * CKB; c += 256) {
-    float mean = 0.f, rstd = 1.f;
+    float mean = 0.f, rstd = (c < Cin) ? 1.f : 0.f;       // channels beyond Cin stage as zeros
     if (c >= a.ident_c && c < Cin) {
       const double* st = a.in_stats + ((long long)n * a.in_sstride + a.in_c0 + c) * 2;
       const double cnt = (double)Fin * (double)T;
@@ -147,25 +147,32 @@ __global__ __launch_bounds__(256, (NCO == 1 ? 2 : 1)) void conv3x3_bf16x3(const 
       mean = (float)m;
       rstd = (float)(1.0 / sqrt(var + (double)IN_EPS));
     }
-    s_nrm[c] = make_float2(mean, rstd);
+    s_nrm[c] = make_float2(rstd, -mean * rstd);            // (scale, shift): x_norm = fma(x, scale, shift)
   }
 
   const float* in_n = a.in + (long long)n * a.in_bstride + (long long)a.in_c0 * Fin * Tp;
   const u32x4* w_g = reinterpret_cast<const u32x4*>(a.w16) + (long long)cg * nchunk * (2 * WN);
 
-  // ---- staging roles ----
+  // ---- staging roles: uniform buffer descriptor + per-lane byte offset (VGPR) + per-channel byte offset (SGPR) ----
   const unsigned row_e = (unsigned)Tp;
   const unsigned plane_e = (unsigned)Fin * row_e;
+  const unsigned long long pa = reinterpret_cast<unsigned long long>(in_n);
+  const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pa);
+  const unsigned phi = __builtin_amdgcn_readfirstlane((unsigned)(pa >> 32));
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<void*>(((unsigned long long)phi << 32) | plo), 0,
+      __builtin_amdgcn_readfirstlane((int)((unsigned)Cin * plane_e * 4u)), 0x00020000);
   const int tl = t0 + 2 * lane;                                  // this lane's first frame
   const unsigned tl_e = (unsigned)(tl < Tp ? tl : Tp - 2);
-  unsigned poff_e[NPW];                                          // row offset of each owned pair (clamped)
+  const bool full_t = (t0 + TT <= T);
+  unsigned poff_b[NPW];                                          // byte offset of each owned pair's row (clamped)
 #pragma unroll
   for (int i = 0; i < NPW; ++i) {
     int p = wave + 4 * i;
     p = p < NPAIR ? p : NPAIR - 1;
     int fin = fin0 + (p >> 1);
     fin = fin < 0 ? 0 : (fin >= Fin ? Fin - 1 : fin);
-    poff_e[i] = (unsigned)fin * row_e + tl_e;
+    poff_b[i] = ((unsigned)fin * row_e + tl_e) * 4u;
   }
   f32x2 pf[NPW][8];
   float ph[NHT];
@@ -179,7 +186,9 @@ __global__ __launch_bounds__(256, (NCO == 1 ? 2 : 1)) void conv3x3_bf16x3(const 
       _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                  \
         int c_ = (KC) * CKB + 8 * h_ + e;                                                              \
         c_ = c_ < Cin ? c_ : Cin - 1;                                                                  \
-        pf[i][e] = *reinterpret_cast<const f32x2*>(in_n + ((unsigned)c_ * plane_e + poff_e[i]));       \
+        const u32x2 v_ = __builtin_amdgcn_raw_buffer_load_b64(                                         \
+            rs_in, poff_b[i], __builtin_amdgcn_readfirstlane((unsigned)c_ * plane_e * 4u), 0);         \
+        pf[i][e] = __builtin_bit_cast(f32x2, v_);                                                      \
       }                                                                                                \
     }                                                                                                  \
     _Pragma("unroll") for (int i = 0; i < NHT; ++i) {                                                  \
@@ -193,7 +202,8 @@ __global__ __launch_bounds__(256, (NCO == 1 ? 2 : 1)) void conv3x3_bf16x3(const 
       fin_ = fin_ < 0 ? 0 : (fin_ >= Fin ? Fin - 1 : fin_);                                            \
       int th_ = side_ ? t0 + TT : t0 - 1;                                                              \
       th_ = th_ < 0 ? 0 : (th_ >= Tp ? Tp - 1 : th_);                                                  \
-      ph[i] = in_n[(unsigned)c_ * plane_e + (unsigned)fin_ * row_e + (unsigned)th_];                   \
+      const unsigned ho_ = ((unsigned)c_ * plane_e + (unsigned)fin_ * row_e + (unsigned)th_) * 4u;     \
+      ph[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, ho_, 0, 0));       \
     }                                                                                                  \
     const u32x4* wsrc_ = w_g + (unsigned)(KC) * (unsigned)(2 * WN);                                    \
     _Pragma("unroll") for (int i = 0; i < NWI; ++i) {                                                  \
@@ -211,20 +221,34 @@ __global__ __launch_bounds__(256, (NCO == 1 ? 2 : 1)) void conv3x3_bf16x3(const 
         const int r_ = p_ >> 1, h_ = p_ & 1;                                                           \
         const int fin_ = fin0 + r_;                                                                    \
         const bool rok_ = fin_ >= 0 && fin_ < Fin;                                                     \
-        bf16x8 h0_, l0_, h1_, l1_;                                                                     \
-        _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                \
-          const int c_ = (KC) * CKB + 8 * h_ + e;                                                      \
-          const float2 m_ = s_nrm[c_];                                                                 \
-          const bool ok_ = rok_ && c_ < Cin;                                                           \
-          const float x0_ = (ok_ && tl + 0 < T) ? (pf[i][e].x - m_.x) * m_.y : 0.f;                    \
-          const float x1_ = (ok_ && tl + 1 < T) ? (pf[i][e].y - m_.x) * m_.y : 0.f;                    \
-          __bf16 a_, b_;                                                                               \
-          split2(x0_, a_, b_); h0_[e] = a_; l0_[e] = b_;                                               \
-          split2(x1_, a_, b_); h1_[e] = a_; l1_[e] = b_;                                               \
-        }                                                                                              \
         const int o_ = (r_ * 2 + h_) * TW + 4 + 2 * lane;                                              \
-        s_xhi[o_] = h0_; s_xhi[o_ + 1] = h1_;                                                          \
-        s_xlo[o_] = l0_; s_xlo[o_ + 1] = l1_;                                                          \
+        if (rok_) {                                                                                    \
+          float y0_[8], y1_[8];                                                                        \
+          _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                              \
+            const float2 m_ = s_nrm[(KC) * CKB + 8 * h_ + e];                                          \
+            y0_[e] = fmaf(pf[i][e].x, m_.x, m_.y);                                                     \
+            y1_[e] = fmaf(pf[i][e].y, m_.x, m_.y);                                                     \
+          }                                                                                            \
+          if (!full_t) {                                                                               \
+            const bool k0_ = tl + 0 < T, k1_ = tl + 1 < T;                                             \
+            _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                            \
+              y0_[e] = k0_ ? y0_[e] : 0.f;                                                             \
+              y1_[e] = k1_ ? y1_[e] : 0.f;                                                             \
+            }                                                                                          \
+          }                                                                                            \
+          u32x4 h0_, l0_, h1_, l1_;                                                                    \
+          _Pragma("unroll") for (int e2 = 0; e2 < 4; ++e2) {                                           \
+            unsigned a_, b_;                                                                           \
+            split_pair(y0_[2 * e2], y0_[2 * e2 + 1], a_, b_); h0_[e2] = a_; l0_[e2] = b_;              \
+            split_pair(y1_[2 * e2], y1_[2 * e2 + 1], a_, b_); h1_[e2] = a_; l1_[e2] = b_;              \
+          }                                                                                            \
+          reinterpret_cast<u32x4*>(s_xhi)[o_] = h0_; reinterpret_cast<u32x4*>(s_xhi)[o_ + 1] = h1_;    \
+          reinterpret_cast<u32x4*>(s_xlo)[o_] = l0_; reinterpret_cast<u32x4*>(s_xlo)[o_ + 1] = l1_;    \
+        } else {                                                                                       \
+          const u32x4 z_ = {0u, 0u, 0u, 0u};                                                           \
+          reinterpret_cast<u32x4*>(s_xhi)[o_] = z_; reinterpret_cast<u32x4*>(s_xhi)[o_ + 1] = z_;      \
+          reinterpret_cast<u32x4*>(s_xlo)[o_] = z_; reinterpret_cast<u32x4*>(s_xlo)[o_ + 1] = z_;      \
+        }                                                                                              \
       }                                                                                                \
     }                                                                                                  \
     _Pragma("unroll") for (int i = 0; i < NHT; ++i) {                                                  \
@@ -236,9 +260,9 @@ __global__ __launch_bounds__(256, (NCO == 1 ? 2 : 1)) void conv3x3_bf16x3(const 
         const int c_ = (KC) * CKB + 8 * h_ + e_;                                                       \
         const int fin_ = fin0 + r_;                                                                    \
         const int th_ = side_ ? t0 + TT : t0 - 1;                                                      \
-        const bool ok_ = fin_ >= 0 && fin_ < Fin && c_ < Cin && th_ >= 0 && th_ < T;                   \
+        const bool ok_ = fin_ >= 0 && fin_ < Fin && th_ >= 0 && th_ < T;                               \
         const float2 m_ = s_nrm[c_];                                                                   \
-        const float x_ = ok_ ? (ph[i] - m_.x) * m_.y : 0.f;                                            \
+        const float x_ = ok_ ? fmaf(ph[i], m_.x, m_.y) : 0.f;                                          \
         __bf16 a_, b_;                                                                                 \
         split2(x_, a_, b_);                                                                            \
         const int o_ = ((r_ * 2 + h_) * TW + (side_ ? TT + 4 : 3)) * 8 + e_;                           \
@@ -627,7 +651,7 @@ static size_t ws_lds_bytes(int NR) {
 }
 
 static int g_ws_cus = 0;
-static int g_ws_enabled = 1;
+static int g_ws_enabled = 0;   // measured slower than the 2-blocks-per-CU kernel (profiles/): opt-in via MISONET_WS=1
 void conv_bf16_ws_enable(int on) { g_ws_enabled = on; }
 
 static size_t bf_lds_bytes(int NR, int cop, int Cin) {
@@ -665,6 +689,8 @@ hipError_t launch_conv_bf16(const ConvArgs& a_in, int n_samples, hipStream_t s) 
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("MISONET_WS_DEBUG"); dbg = e ? atoi(e) : 0; }
     a.dbg = dbg;
+    static int ws_env = -1;
+    if (ws_env < 0) { const char* e = getenv("MISONET_WS"); ws_env = e ? atoi(e) : 0; g_ws_enabled = ws_env; }
   }
   dim3 grid((a.T + TT - 1) / TT, (a.Fout + FT - 1) / FT, n_samples * a.ncg);
   const size_t lds = bf_lds_bytes(a.NR, a.cop, a.Cin);

@@ -6,6 +6,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -299,7 +300,7 @@ static inline long long bstride(const misonet_net* n, const Layout& L, int b) {
   return (long long)n->bufs[b].C * n->bufs[b].F * L.Tp;
 }
 
-static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL& c, hipStream_t s) {
+static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL& c, hipStream_t s, int n0 = 0, int nb = -1) {
   ConvArgs a;
   a.in = buf_ptr(L, ws, c.in_buf);
   a.in_stats = stats_ptr(L, ws, c.in_buf);
@@ -319,11 +320,16 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
   a.NR = conv_rows(c.sf, c.tr2);
   a.ncg = c.ncg; a.cop = c.cop;
   a.dbg = 0;
+  if (nb < 0) nb = L.N;
+  a.in += (long long)n0 * a.in_bstride;
+  a.out += (long long)n0 * a.out_bstride;
+  a.in_stats += (long long)n0 * a.in_sstride * 2;
+  a.out_stats += (long long)n0 * a.out_sstride * 2;
   if (a.w16) { a.cop = 32; a.ncg = (c.Cout + 31) / 32; }
   {
     ProfScope ps(s, PK_CONV);
-    if (a.w16) HIPCHK(launch_conv_bf16(a, L.N, s));
-    else HIPCHK(launch_conv(a, L.N, s));
+    if (a.w16) HIPCHK(launch_conv_bf16(a, nb, s));
+    else HIPCHK(launch_conv(a, nb, s));
   }
   return MISONET_OK;
 }
@@ -331,7 +337,32 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
 // IN buffer already filled (planar).  Leaves the result (raw) in B_OUT.
 static int forward_planar(misonet_net* n, const Layout& L, void* ws, hipStream_t s) {
   HIPCHK(hipMemsetAsync(ws, 0, (size_t)(256 + L.stats_doubles * 8), s));
-  for (const ConvL& c : n->enc) { int r = run_conv(n, L, ws, c, s); if (r) return r; }
+  // Optional sample sub-batching of the conv stacks (MISONET_SUBBATCH = samples per pass at F = 127; deeper levels take
+  // proportionally more): keeps a level's producer->consumer traffic inside the 256 MiB Infinity Cache.
+  static int sub_env = -2;
+  if (sub_env == -2) { const char* e = getenv("MISONET_SUBBATCH"); sub_env = e ? atoi(e) : 0; }
+  auto run_stack = [&](const std::vector<ConvL>& v) -> int {
+    if (sub_env <= 0) {
+      for (const ConvL& c : v) { int r = run_conv(n, L, ws, c, s); if (r) return r; }
+      return MISONET_OK;
+    }
+    // group consecutive layers by output frequency size; sub-batch each group
+    size_t i = 0;
+    while (i < v.size()) {
+      const int Fg = n->bufs[v[i].out_buf].F;
+      size_t j = i;
+      while (j < v.size() && n->bufs[v[j].out_buf].F == Fg) ++j;
+      int sb = sub_env * (127 / (Fg > 0 ? Fg : 1));
+      if (sb < 1) sb = 1;
+      for (int n0 = 0; n0 < L.N; n0 += sb) {
+        const int nb = (L.N - n0) < sb ? (L.N - n0) : sb;
+        for (size_t k = i; k < j; ++k) { int r = run_conv(n, L, ws, v[k], s, n0, nb); if (r) return r; }
+      }
+      i = j;
+    }
+    return MISONET_OK;
+  };
+  { int r = run_stack(n->enc); if (r) return r; }
   // ---- TCN ----
   {
     ProfScope ps_tcn(s, PK_TCN);
@@ -366,7 +397,7 @@ static int forward_planar(misonet_net* n, const Layout& L, void* ws, hipStream_t
       float* t = cur; cur = nxt; nxt = t;
     }
   }
-  for (const ConvL& c : n->dec) { int r = run_conv(n, L, ws, c, s); if (r) return r; }
+  { int r = run_stack(n->dec); if (r) return r; }
   return MISONET_OK;
 }
 
