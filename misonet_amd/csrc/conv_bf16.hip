@@ -107,7 +107,7 @@ __device__ __forceinline__ void split2(float x, __bf16& hi, __bf16& lo) {
 }
 
 template <int NCO, int MODE>
-__global__ __launch_bounds__(256, (NCO == 1 ? 2 : 1)) void conv3x3_bf16x3(const ConvArgs a) {
+__global__ __launch_bounds__(256, ((NCO == 1 && MODE != 1) ? 2 : 1)) void conv3x3_bf16x3(const ConvArgs a) {
   constexpr int COP = NCO * 32;
   constexpr int NR = MODE == 0 ? 6 : (MODE == 1 ? 9 : 3);
   constexpr int SF = MODE == 1 ? 2 : 1;
@@ -298,12 +298,14 @@ __global__ __launch_bounds__(256, (NCO == 1 ? 2 : 1)) void conv3x3_bf16x3(const 
     const bool more = (kc + 1 < nchunk);
     if (more) BF_ISSUE(kc + 1)
     if (row_ok) {
+      __builtin_amdgcn_s_setprio(1);       // MFMA phase outranks the co-resident block's staging phase (+1 % measured)
       if (TR2) {
         if ((f - f0) & 1) chunk_mfma_bf16<NCO, NR, SF, TR2, 2>(acc, s_xhi, s_xlo, s_whi, s_wlo, f - f0, half, l31);
         else chunk_mfma_bf16<NCO, NR, SF, TR2, 5>(acc, s_xhi, s_xlo, s_whi, s_wlo, f - f0, half, l31);
       } else {
         chunk_mfma_bf16<NCO, NR, SF, TR2, 7>(acc, s_xhi, s_xlo, s_whi, s_wlo, f - f0, half, l31);
       }
+      __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
     if (more) {

@@ -7,6 +7,7 @@
 //   tcn_pw : g = gLN(d) on the fly -> 128x128 point-wise conv on the fp32 matrix cores (+ residual) ; IN1d sums
 // All sums are float64.  Activations are planar [n][c][Tp] (F = 1).
 #include "kernels.hpp"
+#include "conv_epilogue.hpp"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 namespace mn {
@@ -58,47 +59,72 @@ __global__ __launch_bounds__(256) void tcn_prepare_k(const float* raw, long long
 }
 
 // d = PReLU(dwconv(ELU(IN1d(x)))), kernel 3, dilation = padding = dil, no bias (model.py:556-558)
+// One workgroup per 4 channels of one sample, one WAVE per (n, c) row: a = ELU(IN1d(x)) is computed once per frame
+// into the wave's LDS row (zero outside [0, T): Conv1d pads its input, i.e. the ELU output), then every lane produces
+// 4 consecutive frames per pass from LDS.  One float64 atomic pair per workgroup for the gLN sums.
+constexpr int DW_MAXT = 2048;          // frames per row kept in LDS (4 rows x 8 KB)
 __global__ __launch_bounds__(256) void tcn_dw_k(const float* x, const double* x_stats, const float* wdw,
                                                 const float* prelu, float* d, double* gln_stats, int C, int T,
                                                 int Tp, int dil) {
-  __shared__ double s_tmp[4];
-  const int c = blockIdx.x, n = blockIdx.y;
+  __shared__ double s_tmp[4][2];
+  __shared__ __align__(16) float s_a[4][DW_MAXT];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 4 + wave, n = blockIdx.y;
   float mean, rstd;
   in_params(x_stats + ((long long)n * C + c) * 2, T, mean, rstd);
+  const float sc = rstd, sh = -mean * rstd;
   const float w0 = wdw[c * 3 + 0], w1 = wdw[c * 3 + 1], w2 = wdw[c * 3 + 2];
   const float slope = prelu[0];
   const float* src = x + ((long long)n * C + c) * Tp;
   float* dst = d + ((long long)n * C + c) * Tp;
-  double s1 = 0.0, s2 = 0.0;
-  for (int t = threadIdx.x; t < T; t += 256) {
-    float acc = 0.f;
-    {
-      const int tt = t - dil;
-      if (tt >= 0) { float v = (src[tt] - mean) * rstd; v = v > 0.f ? v : expm1f(v); acc = w0 * v; }
-    }
-    {
-      float v = (src[t] - mean) * rstd; v = v > 0.f ? v : expm1f(v); acc = fmaf(w1, v, acc);
-    }
-    {
-      const int tt = t + dil;
-      if (tt < T) { float v = (src[tt] - mean) * rstd; v = v > 0.f ? v : expm1f(v); acc = fmaf(w2, v, acc); }
-    }
-    acc = acc > 0.f ? acc : slope * acc;
-    dst[t] = acc;
-    s1 += acc;
-    s2 += (double)acc * acc;
+  float* a = s_a[wave];
+  const int Tq = (T + 3) & ~3;
+  for (int t = lane * 4; t < Tq; t += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(src + t);          // Tp is a multiple of 32 >= Tq
+    float4 o;
+    o.x = (t + 0 < T) ? elu_fast(fmaf(v.x, sc, sh)) : 0.f;
+    o.y = (t + 1 < T) ? elu_fast(fmaf(v.y, sc, sh)) : 0.f;
+    o.z = (t + 2 < T) ? elu_fast(fmaf(v.z, sc, sh)) : 0.f;
+    o.w = (t + 3 < T) ? elu_fast(fmaf(v.w, sc, sh)) : 0.f;
+    *reinterpret_cast<float4*>(a + t) = o;
   }
-  s1 = block_sum_256(s1, s_tmp);
-  s2 = block_sum_256(s2, s_tmp);
-  if (threadIdx.x == 0) {
-    unsafeAtomicAdd(gln_stats + (long long)n * 2 + 0, s1);
-    unsafeAtomicAdd(gln_stats + (long long)n * 2 + 1, s2);
+  __syncthreads();
+  float s1 = 0.f, s2 = 0.f;
+  for (int t = lane * 4; t < Tq; t += 256) {
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int tc = t + i;
+      const int tl = tc - dil, tr = tc + dil;
+      float acc = w1 * a[tc];
+      if (tl >= 0) acc = fmaf(w0, a[tl], acc);
+      if (tr < Tq) acc = fmaf(w2, a[tr], acc);                             // a[] is zero for T <= t < Tq
+      acc = acc > 0.f ? acc : slope * acc;
+      o[i] = acc;
+      if (tc < T) { s1 += acc; s2 = fmaf(acc, acc, s2); }
+    }
+    *reinterpret_cast<float4*>(dst + t) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+  // per-lane partials hold <= 16 terms in float; reduce in float64
+  double r1 = s1, r2 = s2;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    r1 += __shfl_xor(r1, m, 64);
+    r2 += __shfl_xor(r2, m, 64);
+  }
+  if (lane == 0) { s_tmp[wave][0] = r1; s_tmp[wave][1] = r2; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const double tot = s_tmp[0][threadIdx.x] + s_tmp[1][threadIdx.x] + s_tmp[2][threadIdx.x] + s_tmp[3][threadIdx.x];
+    unsafeAtomicAdd(gln_stats + (long long)n * 2 + threadIdx.x, tot);
   }
 }
 
 // y[co][t] = sum_ci W[co][ci] * (gamma[ci] * (d[ci][t] - mean_n) * rstd_n + beta[ci])  (+ residual[co][t])
-// C must be 128.  Workgroup: 128 output channels x 64 frames; wave w owns channels 32w..32w+31, two 32-frame tiles.
-constexpr int PW_TT = 64;
+// C must be 128.  Workgroup: 128 output channels x 128 frames; wave w owns channels 32w..32w+31 and four 32-frame
+// tiles (fp32 MFMA 32x32x2, exact).  K is consumed in 4 chunks of 32 input channels; per chunk every thread stages
+// 4 float4 of gLN-normalised input and 4 float4 of the transposed weights (unrolled, all loads issued first).
+constexpr int PW_TT = 128;
 constexpr int PW_KC = 32;
 __global__ __launch_bounds__(256) void tcn_pw_k(const float* d, const double* gln_stats, const float* gamma,
                                                 const float* beta, const float* wt /*[ci][co]*/,
@@ -118,28 +144,45 @@ __global__ __launch_bounds__(256) void tcn_pw_k(const float* d, const double* gl
   const float rstd = (float)(1.0 / sqrt(gv + (double)GLN_EPS));
   const float* dn = d + (long long)n * C * Tp;
 
-  f32x16 acc[2];
+  f32x16 acc[4];
 #pragma unroll
-  for (int s = 0; s < 2; ++s)
+  for (int s = 0; s < 4; ++s)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
 
+  // staging roles: thread (q = tid & 31 -> frames 4q..4q+3, g = tid >> 5 -> channels g, g+8, g+16, g+24 of the chunk)
+  const int sq = tid & 31, sg = tid >> 5;
+  const int tg = t0 + 4 * sq;
+  const bool tok = tg < Tp;
+
   for (int k0 = 0; k0 < C; k0 += PW_KC) {
-    __syncthreads();
-    for (int i = tid; i < PW_KC * PW_TT; i += 256) {
-      const int ci = i / PW_TT, tl = i % PW_TT;
-      const int t = t0 + tl;
-      float v = 0.f;
-      if (t < T) v = gamma[k0 + ci] * ((dn[(long long)(k0 + ci) * Tp + t] - mean) * rstd) + beta[k0 + ci];
-      s_g[ci][tl] = v;
+    float4 gi[4], wi[4];
+    float ga[4], be[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ci = k0 + sg + 8 * i;
+      gi[i] = tok ? *reinterpret_cast<const float4*>(dn + (long long)ci * Tp + tg) : make_float4(0.f, 0.f, 0.f, 0.f);
+      wi[i] = *reinterpret_cast<const float4*>(wt + (long long)(k0 + sg + 8 * i) * C + 4 * sq);
+      ga[i] = gamma[ci] * rstd;
+      be[i] = beta[ci] - gamma[ci] * rstd * mean;
     }
-    for (int i = tid; i < PW_KC * C; i += 256) s_w[i / C][i % C] = wt[(long long)(k0 + i / C) * C + (i % C)];
+    __syncthreads();                       // previous chunk consumed
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float4 v;
+      v.x = (tg + 0 < T) ? fmaf(gi[i].x, ga[i], be[i]) : 0.f;
+      v.y = (tg + 1 < T) ? fmaf(gi[i].y, ga[i], be[i]) : 0.f;
+      v.z = (tg + 2 < T) ? fmaf(gi[i].z, ga[i], be[i]) : 0.f;
+      v.w = (tg + 3 < T) ? fmaf(gi[i].w, ga[i], be[i]) : 0.f;
+      *reinterpret_cast<float4*>(&s_g[sg + 8 * i][4 * sq]) = v;
+      *reinterpret_cast<float4*>(&s_w[sg + 8 * i][4 * sq]) = wi[i];
+    }
     __syncthreads();
 #pragma unroll
     for (int kk = 0; kk < PW_KC; kk += 2) {
       const float av = s_w[kk + half][wave * 32 + l31];
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+      for (int s = 0; s < 4; ++s) {
         const float bv = s_g[kk + half][s * 32 + l31];
         acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[s], 0, 0, 0);
       }
@@ -152,7 +195,7 @@ __global__ __launch_bounds__(256) void tcn_pw_k(const float* d, const double* gl
 #pragma unroll
   for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
+  for (int s = 0; s < 4; ++s) {
     const int t = t0 + s * 32 + l31;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -162,20 +205,16 @@ __global__ __launch_bounds__(256) void tcn_pw_k(const float* d, const double* gl
         if (rn) v += rn[(long long)co * Tp + t];
         yn[(long long)co * Tp + t] = v;
         s1[r] += v;
-        s2[r] += v * v;
+        s2[r] = fmaf(v, v, s2[r]);
       }
     }
   }
   if (y_stats) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float x1 = s1[r], x2 = s2[r];
-#pragma unroll
-      for (int m = 16; m >= 1; m >>= 1) {
-        x1 += __shfl_xor(x1, m, 64);
-        x2 += __shfl_xor(x2, m, 64);
-      }
-      if (l31 == 0) {
+      const float x1 = half_wave_sum(s1[r]);
+      const float x2 = half_wave_sum(s2[r]);
+      if (l31 == 31) {
         const int co = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         double* o = y_stats + ((long long)n * C + co) * 2;
         unsafeAtomicAdd(o + 0, (double)x1);
@@ -195,7 +234,9 @@ hipError_t launch_tcn_prepare(const float* raw, long long raw_bstride, int raw_c
 
 hipError_t launch_tcn_dw(const float* x, const double* x_stats, const float* wdw, const float* prelu, float* d,
                          double* gln_stats, int C, int T, int Tp, int dilation, int n_samples, hipStream_t s) {
-  hipLaunchKernelGGL(tcn_dw_k, dim3(C, n_samples), dim3(256), 0, s, x, x_stats, wdw, prelu, d, gln_stats, C, T, Tp,
+  if (((T + 3) & ~3) > DW_MAXT) return hipErrorInvalidValue;
+  if (C % 4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(tcn_dw_k, dim3(C / 4, n_samples), dim3(256), 0, s, x, x_stats, wdw, prelu, d, gln_stats, C, T, Tp,
                      dilation);
   return hipGetLastError();
 }

@@ -116,3 +116,36 @@ def test_product_does_not_import_oracle():
             src = open(os.path.join(pkg, fn)).read()
             assert not re.search(r"^\s*(from|import)\s+\.*oracle", src, flags=re.M), fn
             assert "import oracle" not in src and "from oracle" not in src, fn
+
+
+def test_precision_switch_host_side():
+    L, rc, h = _make()
+    lib = L.lib()
+    assert lib.misonet_net_get_precision(h) == 0                 # exact f32 by default
+    assert lib.misonet_net_set_precision(h, 1) == 0 and lib.misonet_net_get_precision(h) == 1
+    assert lib.misonet_net_set_precision(h, 7) == L.EINVAL
+    lib.misonet_net_destroy(h)
+    import misonet_amd as mz
+    from misonet_amd import weights as W
+    m = mz.MISO_3(1, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN")
+    assert m.precision == "f32"
+    m.set_precision("bf16x3")
+    assert m.precision == "bf16x3"
+    with pytest.raises(ValueError):
+        m.set_precision("fp8")
+
+
+def test_reference_checkpoint_format_roundtrip(tmp_path):
+    """run.py:139-151 loads torch.load(path)['model_state_dict'] (format written by trainer.py:340-347)."""
+    import torch
+    import misonet_amd as mz
+    from misonet_amd import weights as W
+    sd = {k: torch.from_numpy(v) for k, v in W.make_state_dict(W.miso1_spec(), 3).items()}
+    path = str(tmp_path / "ckpt.pt")
+    torch.save({"model_state_dict": sd, "optimizer": {}, "epoch": 7, "tr_avg_loss": 0.1, "val_avg_loss": 0.2}, path)
+    package = torch.load(path, map_location="cpu")
+    m = mz.MISO_1(2, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN")
+    m.load_state_dict(package["model_state_dict"])
+    back = m.state_dict()
+    for k in sd:
+        assert torch.equal(back[k], sd[k])
