@@ -25,6 +25,7 @@ namespace mn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 
 int conv_cop(int Cout) { return Cout <= 32 ? 32 : 64; }
 int conv_rows(int sf, int tr2) { return tr2 ? 3 : sf * (FT - 1) + 3; }
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2) ? 3 : 2)) void conv3x
 
   // instance-norm parameters of the input channels (normalise-on-load)
   for (int c = tid; c < nchunk * CK; c += 256) {
-    float mean = 0.f, rstd = 1.f;
+    float mean = 0.f, rstd = (c < Cin) ? 1.f : 0.f;       // channels beyond Cin stage as zeros
     if (c >= a.ident_c && c < Cin) {
       const double* st = a.in_stats + ((long long)n * a.in_sstride + a.in_c0 + c) * 2;
       const double cnt = (double)Fin * (double)T;
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2) ? 3 : 2)) void conv3x
       mean = (float)m;
       rstd = (float)(1.0 / sqrt(var + (double)IN_EPS));
     }
-    s_nrm[c] = make_float2(mean, rstd);
+    s_nrm[c] = make_float2(rstd, -mean * rstd);            // (scale, shift): x_norm = fma(x, scale, shift)
   }
 
   const float* in_n = a.in + (long long)n * a.in_bstride + (long long)a.in_c0 * Fin * Tp;
@@ -149,37 +150,45 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2) ? 3 : 2)) void conv3x
   float ph = 0.f;
   f32x4 pw[NWI];
 
-  // All prefetch loads are unconditional with clamped 32-bit offsets from wave-uniform bases (no 64-bit address
-  // VGPRs, no branches); validity is re-derived in STAGE_COMMIT.
+  // All prefetch loads are unconditional buffer loads (one readfirstlane'd descriptor per sample, clamped 32-bit byte
+  // offsets: no 64-bit address VGPRs, no branches); validity is re-derived in STAGE_COMMIT.
   const unsigned row_e = (unsigned)Tp;
   const unsigned plane_e = (unsigned)Fin * row_e;
+  const unsigned long long pa = reinterpret_cast<unsigned long long>(in_n);
+  const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pa);
+  const unsigned phi = __builtin_amdgcn_readfirstlane((unsigned)(pa >> 32));
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<void*>(((unsigned long long)phi << 32) | plo), 0,
+      __builtin_amdgcn_readfirstlane((int)((unsigned)Cin * plane_e * 4u)), 0x00020000);
   const unsigned tg_e = (unsigned)(tg < Tp ? tg : Tp - 4);
-  unsigned hoff_e;
+  const bool full_t = (t0 + TT <= T);
+  unsigned hoff_b;
   {
     int fh = fin0 + (hr < NR ? hr : NR - 1);
     fh = fh < 0 ? 0 : (fh >= Fin ? Fin - 1 : fh);
     const int th = htg < 0 ? 0 : (htg >= Tp ? Tp - 1 : htg);
-    hoff_e = (unsigned)fh * row_e + (unsigned)th;
+    hoff_b = ((unsigned)fh * row_e + (unsigned)th) * 4u;
   }
-  unsigned roff_e[NR];
+  unsigned roff_b[NR];
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     int fin = fin0 + r;
     fin = fin < 0 ? 0 : (fin >= Fin ? Fin - 1 : fin);
-    roff_e[r] = (unsigned)fin * row_e + tg_e;
+    roff_b[r] = ((unsigned)fin * row_e + tg_e) * 4u;
   }
 
 #define STAGE_ISSUE(KC)                                                                          \
   {                                                                                              \
     int c_ = (KC) * CK + sci;                                                                    \
     c_ = c_ < Cin ? c_ : Cin - 1;                                                                \
-    const float* cb_ = in_n + (unsigned)c_ * plane_e;                                            \
-    _Pragma("unroll") for (int r = 0; r < NR; ++r)                                               \
-        pin[r] = *reinterpret_cast<const f32x4*>(cb_ + roff_e[r]);                              \
+    const unsigned cb_ = (unsigned)c_ * plane_e * 4u;                                            \
+    _Pragma("unroll") for (int r = 0; r < NR; ++r) pin[r] = __builtin_bit_cast(                  \
+        f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, cb_ + roff_b[r], 0, 0));             \
     int c2_ = (KC) * CK + hci;                                                                   \
     c2_ = c2_ < Cin ? c2_ : Cin - 1;                                                             \
-    ph = in_n[(unsigned)c2_ * plane_e + hoff_e];                                                 \
-    const f32x4* wsrc_ = w_g + (unsigned)(KC) * (unsigned)NW4;                                  \
+    ph = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(                         \
+        rs_in, (unsigned)c2_ * plane_e * 4u + hoff_b, 0, 0));                                    \
+    const f32x4* wsrc_ = w_g + (unsigned)(KC) * (unsigned)NW4;                                   \
     _Pragma("unroll") for (int i = 0; i < NWI; ++i) {                                            \
       unsigned idx_ = tid + 256 * i;                                                             \
       if (NW4 % 256 != 0) idx_ = idx_ < (unsigned)NW4 ? idx_ : (unsigned)(NW4 - 1);              \
@@ -189,27 +198,31 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2) ? 3 : 2)) void conv3x
 
 #define STAGE_COMMIT(KC)                                                                         \
   {                                                                                              \
-    const int c_ = (KC) * CK + sci;                                                              \
-    const bool cok_ = (c_ < Cin) && tok;                                                         \
-    const float2 m_ = s_nrm[c_];                                                                 \
+    const float2 m_ = s_nrm[(KC) * CK + sci];                                                    \
     _Pragma("unroll") for (int r = 0; r < NR; ++r) {                                             \
       const int fin_ = fin0 + r;                                                                 \
-      const bool ok_ = cok_ && fin_ >= 0 && fin_ < Fin;                                          \
-      f32x4 v_ = pin[r];                                                                         \
-      v_.x = (ok_ && tg + 0 < T) ? (v_.x - m_.x) * m_.y : 0.f;                                   \
-      v_.y = (ok_ && tg + 1 < T) ? (v_.y - m_.x) * m_.y : 0.f;                                   \
-      v_.z = (ok_ && tg + 2 < T) ? (v_.z - m_.x) * m_.y : 0.f;                                   \
-      v_.w = (ok_ && tg + 3 < T) ? (v_.w - m_.x) * m_.y : 0.f;                                   \
+      f32x4 v_ = {0.f, 0.f, 0.f, 0.f};                                                           \
+      if (fin_ >= 0 && fin_ < Fin) {                      /* uniform */                          \
+        v_.x = fmaf(pin[r].x, m_.x, m_.y);                                                       \
+        v_.y = fmaf(pin[r].y, m_.x, m_.y);                                                       \
+        v_.z = fmaf(pin[r].z, m_.x, m_.y);                                                       \
+        v_.w = fmaf(pin[r].w, m_.x, m_.y);                                                       \
+        if (!full_t) {                                                                           \
+          v_.x = (tg + 0 < T) ? v_.x : 0.f;                                                      \
+          v_.y = (tg + 1 < T) ? v_.y : 0.f;                                                      \
+          v_.z = (tg + 2 < T) ? v_.z : 0.f;                                                      \
+          v_.w = (tg + 3 < T) ? v_.w : 0.f;                                                      \
+        }                                                                                        \
+      }                                                                                          \
       *reinterpret_cast<f32x4*>(s_in + (sci * NR + r) * TW + 4 + 4 * sq) = v_;                   \
     }                                                                                            \
     if (hr < NR) {                                                                               \
-      const int c2_ = (KC) * CK + hci;                                                           \
-      const float2 m2_ = s_nrm[c2_];                                                             \
-      s_in[(hci * NR + hr) * TW + (hside ? TT + 4 : 3)] = (hok && c2_ < Cin) ? (ph - m2_.x) * m2_.y : 0.f; \
+      const float2 m2_ = s_nrm[(KC) * CK + hci];                                                 \
+      s_in[(hci * NR + hr) * TW + (hside ? TT + 4 : 3)] = hok ? fmaf(ph, m2_.x, m2_.y) : 0.f;    \
     }                                                                                            \
     _Pragma("unroll") for (int i = 0; i < NWI; ++i) {                                            \
       const int idx_ = tid + 256 * i;                                                            \
-      if (NW4 % 256 == 0 || idx_ < NW4) reinterpret_cast<f32x4*>(s_w)[idx_] = pw[i];            \
+      if (NW4 % 256 == 0 || idx_ < NW4) reinterpret_cast<f32x4*>(s_w)[idx_] = pw[i];             \
     }                                                                                            \
   }
 

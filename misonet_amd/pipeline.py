@@ -129,6 +129,35 @@ class Enhancer:
             return out, dict(bf=bf, miso1=m1)
         return out
 
+    def inference(self, data_loader, saveDir, fs=16000, write=True):
+        """Drop-in for ``Tester_Enhance.inference(data_loader, saveDir)`` (tester.py:846-975): the loader yields
+        ``(split_observe_dict, split_clean_s0_dict, split_clean_s1_dict, gap, wav_name)`` with dict values complex
+        ``[B, Ch, T, F]`` keyed '0', '1', ... (dataloader/data.py:524-597).  Every split runs through
+        :meth:`enhance`; the int16 waves of the splits are stitched (last split trimmed by ``gap``) and written as
+        ``<saveDir>/<wav_name>_{0,1}.wav`` (PCM-24).  Returns {wav_name: int16 [2, n_samples]}."""
+        import os
+        os.makedirs(saveDir, exist_ok=True)
+        results = {}
+        for (obs_d, s0_d, s1_d, gap, wav_name) in data_loader:
+            n_split = len(obs_d)
+            per_split = []
+            for k in range(n_split):
+                obs = torch.as_tensor(obs_d[str(k)]).to(self.device)
+                s0 = torch.as_tensor(s0_d[str(k)])[:, self.ref_ch].to(self.device)          # tester.py:889-890
+                s1 = torch.as_tensor(s1_d[str(k)])[:, self.ref_ch].to(self.device)
+                clean = torch.stack((s0, s1), dim=1)
+                per_split.append(self.enhance(obs, clean))                                  # [B,S,T,F]
+            B = per_split[0].shape[0]
+            for b in range(B):
+                g = int(gap[b]) if hasattr(gap, "__len__") else int(gap)
+                wav = self.to_wav_int16([sp[b] for sp in per_split], g)                     # [S, n]
+                name = wav_name[b] if not isinstance(wav_name, str) else wav_name
+                results[name] = wav
+                if write:
+                    for s in range(self.num_spks):
+                        S.write_wav_pcm24(os.path.join(saveDir, f"{name}_{s}.wav"), wav[s], fs)
+        return results
+
     def to_wav_int16(self, enhanced_chunks: List[torch.Tensor], gap: int) -> np.ndarray:
         """tester.py:949-969 for one recording: list over 4 s splits of complex [S,T,F] -> int16 [S, n_samples]."""
         per_spk = []

@@ -72,3 +72,37 @@ def stitch_int16(chunks: List[np.ndarray], gap: int) -> np.ndarray:
     if gap:
         chunks[-1] = chunks[-1][: len(chunks[-1]) - gap]
     return np.concatenate(chunks)
+
+
+def write_wav_pcm24(path: str, samples_int16: np.ndarray, fs: int) -> None:
+    """tester.py:972-974: ``sf.write(path, int16_array.T, fs, 'PCM_24')``.  libsndfile widens int16 to 24-bit PCM by a
+    left shift of 8 bits, so each sample is written as the 3 little-endian bytes of ``int16 << 8``.
+    samples_int16: [n_samples] (mono) or [n_samples, n_channels]."""
+    import wave
+    x = np.asarray(samples_int16)
+    if x.dtype != np.int16:
+        raise TypeError("expected int16 samples (tester.py:952 casts before writing)")
+    if x.ndim == 1:
+        x = x[:, None]
+    v = (x.astype(np.int32) << 8)
+    b = np.empty(x.shape + (3,), dtype=np.uint8)
+    b[..., 0] = v & 0xFF
+    b[..., 1] = (v >> 8) & 0xFF
+    b[..., 2] = (v >> 16) & 0xFF
+    with wave.open(path, "wb") as w:
+        w.setnchannels(x.shape[1])
+        w.setsampwidth(3)
+        w.setframerate(int(fs))
+        w.writeframes(b.tobytes())
+
+
+def read_wav_pcm24(path: str):
+    """Inverse of :func:`write_wav_pcm24` (tests): returns (int32 samples [n, ch] in 24-bit range, fs)."""
+    import wave
+    with wave.open(path, "rb") as w:
+        assert w.getsampwidth() == 3
+        ch, fs, n = w.getnchannels(), w.getframerate(), w.getnframes()
+        raw = np.frombuffer(w.readframes(n), dtype=np.uint8).reshape(n, ch, 3).astype(np.int32)
+    v = raw[..., 0] | (raw[..., 1] << 8) | (raw[..., 2] << 16)
+    v = np.where(v >= 1 << 23, v - (1 << 24), v)
+    return v, fs

@@ -234,3 +234,53 @@ def test_full_size_properties(nets, sd1):
     assert rel_l2(yb[0].cpu().numpy(), y1[0].cpu().numpy()) < 1e-5
     y3 = m1(torch.roll(x, 1, dims=1))
     assert rel_l2(yb[2].cpu().numpy(), y3[0].cpu().numpy()) < 1e-5
+
+
+def test_config1_sample_clean_8khz(nets):
+    """BASELINE.json configs[0]: first 4 s of the reference's sample/Clean recording (8 kHz, 6 mics, T = 501) through
+    one MISO_1 forward, against the golden produced by the real reference (G8)."""
+    from oracle import pipeline_oracle
+    m1, _ = nets
+    g = golden("g8_sample_clean_miso1.npz")
+    x = pipeline_oracle.stft_chunk(g["obs_wav_f16"].astype(np.float32), 8000)[None]
+    y = m1(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert y.shape == (1, 2, 501, 129)
+    _assert_parity(y[:, :, 200:232], g["y_slice"], "config-1 sample/Clean slice vs reference golden")
+    assert rel_l2(np.abs(y).sum(-1), g["mag_sum_per_frame"]) < 1e-4
+
+
+def test_inference_loader_two_splits(nets, sd1, sd3, tmp_path):
+    """Enhancer.inference as a drop-in for Tester_Enhance.inference (tester.py:846-975): a recording of two 4 s-style
+    splits (here 48 frames each) with a zero-padded tail; waves vs the oracle run split by split."""
+    import misonet_amd as mz
+    from misonet_amd import stft as S
+    from oracle import pipeline_oracle
+    m1, m3 = nets
+    enh = mz.Enhancer(m1, m3, num_spks=2, ref_ch=0)
+    chunk = 47 * 64
+    from misonet_amd.weights import synthetic_utterance
+    obs, s0, s1 = synthetic_utterance(21, 2 * chunk - 500)
+    parts_o, gap = S.split_chunks(obs, chunk)
+    parts_0, _ = S.split_chunks(s0, chunk)
+    parts_1, _ = S.split_chunks(s1, chunk)
+    assert gap == 500 and len(parts_o) == 2
+    od, d0, d1 = {}, {}, {}
+    for k in range(2):
+        od[str(k)] = torch.from_numpy(pipeline_oracle.stft_chunk(parts_o[k]))[None]
+        d0[str(k)] = torch.from_numpy(pipeline_oracle.stft_chunk(parts_0[k]))[None]
+        d1[str(k)] = torch.from_numpy(pipeline_oracle.stft_chunk(parts_1[k]))[None]
+    res = enh.inference([(od, d0, d1, [gap], ["rec"])], str(tmp_path), fs=16000)
+    wav = res["rec"]
+    assert wav.shape == (2, 2 * chunk - 500) and wav.dtype == np.int16
+    ref = []
+    for k in range(2):
+        r = pipeline_oracle.enhance_utterance(od[str(k)][0].numpy(), np.stack([d0[str(k)][0, 0].numpy(), d1[str(k)][0, 0].numpy()]),
+                                              sd1, sd3, ref_ch=0)
+        ref.append([pipeline_oracle.istft_int16(r["out"][s]) for s in range(2)])
+    for s in range(2):
+        full = np.concatenate([ref[0][s], ref[1][s][: chunk - gap]])
+        d = np.abs(wav[s].astype(np.int32) - full.astype(np.int32))
+        print(f"[inference] spk{s}: max |diff| {d.max()} LSB")
+        assert d.max() <= 3
+        v, fs = S.read_wav_pcm24(str(tmp_path / f"rec_{s}.wav"))
+        assert fs == 16000 and np.array_equal(v[:, 0], wav[s].astype(np.int32) << 8)

@@ -41,3 +41,19 @@ def test_chunking_and_stitching():
     assert len(chunks2) == 2 and gap2 == 0
     pcs = [np.arange(4, dtype=np.int16), np.arange(4, dtype=np.int16)]
     assert S.stitch_int16(pcs, 3).tolist() == [0, 1, 2, 3, 0]
+
+
+def test_pcm24_writer_roundtrip(tmp_path):
+    """tester.py:972-974 writes int16 data with subtype PCM_24: samples become int16 << 8."""
+    x = np.array([[0, 1], [-1, 32767], [-32768, 1234], [77, -77]], dtype=np.int16)
+    p = str(tmp_path / "a_0.wav")
+    S.write_wav_pcm24(p, x, 8000)
+    v, fs = S.read_wav_pcm24(p)
+    assert fs == 8000 and v.shape == (4, 2)
+    assert np.array_equal(v, x.astype(np.int32) << 8)
+    S.write_wav_pcm24(p, x[:, 0], 16000)
+    v, fs = S.read_wav_pcm24(p)
+    assert v.shape == (4, 1) and fs == 16000
+    import pytest
+    with pytest.raises(TypeError):
+        S.write_wav_pcm24(p, x.astype(np.float32), 8000)
