@@ -114,6 +114,21 @@ int misonet_pipeline_run(misonet_pipeline* p, const void* mix_dev, const void* c
                          void* out_dev, void* bf_dev, void* miso1_dev, void* ws_dev, long long ws_bytes,
                          misonet_stream stream);
 int misonet_pipeline_check(misonet_pipeline* p, const void* ws_dev, misonet_stream stream);
+/* same pipeline fed with waveforms: wav_dev float32 [B, n_samples, M] (time-major, microphones interleaved: the
+ * librosa.load(...).T array of dataloader/data.py:605-616), clean_wav_dev float32 [B, n_samples, S] (clean sources at
+ * ref_ch) or NULL.  The STFT front-end (data.py:505-522,540-544) runs on the device straight into the kernels' layout;
+ * T = n_samples/64 + 1 frames (misonet_pipeline_workspace_bytes takes that T). */
+int misonet_pipeline_run_wav(misonet_pipeline* p, const float* wav_dev, const float* clean_wav_dev, int B,
+                             int n_samples, void* out_dev, void* bf_dev, void* miso1_dev, void* ws_dev,
+                             long long ws_bytes, misonet_stream stream);
+
+/* ---- STFT front-end alone: AudioDataset_Test.STFT + "/scale" + permute (dataloader/data.py:505-522, 540-544) ------ */
+/* wav_dev float32 [B, n_samples, M] -> out_dev complex64 [B, M, T, 129], T = n_samples/64 + 1: hann-256, hop 64,
+ * zero boundary padding, un-normalised.  The twiddle table (295 KB) is allocated on first use. */
+int misonet_stft_frames(int n_samples);
+long long misonet_stft_workspace_bytes(int B, int M, int n_samples);
+int misonet_stft(const float* wav_dev, int B, int n_samples, int M, void* out_dev, void* ws_dev, long long ws_bytes,
+                 misonet_stream stream);
 
 /* ---- per-launch timing (bench.py roofline leg): while enabled, the library brackets every conv launch, the TCN
  * section and the MVDR section of each forward with HIP events on the caller's stream.  kinds: 0 = conv3x3_mfma

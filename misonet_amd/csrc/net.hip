@@ -19,6 +19,11 @@ hipError_t launch_compose_sel(const int* shift_sel, const int* clean_sel, int B,
 hipError_t launch_assemble3(const float* in1, long long in1_bstride, const float* out1, long long out1_bstride,
                             const int* sel, int B, int M, int S, int ref_ch, int F, int Tp, float* in3,
                             long long in3_bstride, hipStream_t s);
+hipError_t launch_stft_pack(const float* wav, int B, int L, int Mw, int T, const float* twid, float* dst,
+                            long long dst_bstride, int Tp, int F, int c_re, int c_im, int nshift, hipStream_t s);
+hipError_t stft_init();
+void stft_build_twiddles(float* tw);
+int stft_twiddle_count();
 }  // namespace mn
 
 using namespace mn;
@@ -695,6 +700,45 @@ int misonet_pit_select(const void* anchor, const void* cand, int B, int S, int T
   return MISONET_OK;
 }
 
+// ---- STFT front-end ------------------------------------------------------------------------------------------------
+static float* g_twid = nullptr;
+static int get_twiddles(const float** out) {
+  if (!g_twid) {
+    std::vector<float> tw((size_t)stft_twiddle_count());
+    stft_build_twiddles(tw.data());
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&g_twid), tw.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(g_twid, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(stft_init());
+  }
+  *out = g_twid;
+  return MISONET_OK;
+}
+
+int misonet_stft_frames(int n_samples) { return n_samples > 0 ? n_samples / 64 + 1 : -1; }
+
+long long misonet_stft_workspace_bytes(int B, int M, int n_samples) {
+  const int T = misonet_stft_frames(n_samples);
+  if (B <= 0 || M <= 0 || T <= 0) return -1;
+  return (long long)B * 2 * M * 129 * frames_pitch(T) * 4;
+}
+
+int misonet_stft(const float* wav_dev, int B, int n_samples, int M, void* out_c64, void* ws, long long ws_bytes,
+                 misonet_stream stream) {
+  if (!wav_dev || !out_c64 || !ws) return fail(MISONET_EINVAL, "null argument");
+  if (B <= 0 || M <= 0 || M > 64 || n_samples <= 0) return fail(MISONET_EINVAL, "bad B / M / n_samples");
+  if (ws_bytes < misonet_stft_workspace_bytes(B, M, n_samples)) return fail(MISONET_ENOMEM, "workspace too small");
+  const int T = misonet_stft_frames(n_samples), Tp = frames_pitch(T), F = 129;
+  const float* tw;
+  int r = get_twiddles(&tw);
+  if (r) return r;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  float* planar = reinterpret_cast<float*>(ws);
+  const long long bs = 2LL * M * F * Tp;
+  HIPCHK(launch_stft_pack(wav_dev, B, n_samples, M, T, tw, planar, bs, Tp, F, 0, M, 1, s));
+  HIPCHK(launch_unpack(planar, bs, Tp, M, T, F, reinterpret_cast<float2*>(out_c64), B, nullptr, s));
+  return MISONET_OK;
+}
+
 // ---- fused pipeline ----------------------------------------------------------------------------------------------
 struct misonet_pipeline {
   misonet_net* n1;
@@ -747,9 +791,10 @@ long long misonet_pipeline_workspace_bytes(const misonet_pipeline* p, int B, int
   return pipe_layout(p, B, T).total;
 }
 
-int misonet_pipeline_run(misonet_pipeline* p, const void* mix, const void* clean, int B, int T, void* out, void* bf_out,
-                         void* miso1_out, void* ws, long long ws_bytes, misonet_stream stream) {
-  if (!p || !mix || !out || !ws) return fail(MISONET_EINVAL, "null argument");
+static int pipeline_run_impl(misonet_pipeline* p, const void* mix, const void* clean, const float* wav,
+                             const float* clean_wav, int n_samples, int B, int T, void* out, void* bf_out,
+                             void* miso1_out, void* ws, long long ws_bytes, misonet_stream stream) {
+  if (!p || (!mix && !wav) || !out || !ws) return fail(MISONET_EINVAL, "null argument");
   if (!p->n1->committed || !p->n3->committed) return fail(MISONET_ESTATE, "networks not committed");
   if (B <= 0 || T <= 0) return fail(MISONET_EINVAL, "B and T must be positive");
   const PipeLayout P = pipe_layout(p, B, T);
@@ -770,7 +815,10 @@ int misonet_pipeline_run(misonet_pipeline* p, const void* mix, const void* clean
   // 1. MISO1_Inference: the M circular shifts as one batch of B*M samples (tester.py:1033-1051)
   float* in1 = buf_ptr(P.L1, ws1, B_IN);
   const long long in1_bs = bstride(n1, P.L1, B_IN);
-  HIPCHK(launch_pack(reinterpret_cast<const float2*>(mix), B, M, T, F, in1, in1_bs, Tp, 0, M, M, s));
+  const float* tw = nullptr;
+  if (wav) { int rt = get_twiddles(&tw); if (rt) return rt; }
+  if (wav) HIPCHK(launch_stft_pack(wav, B, n_samples, M, T, tw, in1, in1_bs, Tp, F, 0, M, M, s));
+  else HIPCHK(launch_pack(reinterpret_cast<const float2*>(mix), B, M, T, F, in1, in1_bs, Tp, 0, M, M, s));
   int r = forward_planar(n1, P.L1, ws1, s);
   if (r) return r;
   float* out1 = buf_ptr(P.L1, ws1, B_OUT);
@@ -788,9 +836,10 @@ int misonet_pipeline_run(misonet_pipeline* p, const void* mix, const void* clean
     HIPCHK(launch_pit_pick(dist_shift, B * M, sel_shift, s));
   }
   // 3. align to the clean references at ref_ch (tester.py:889-915), optional
-  if (clean) {
+  if (clean || clean_wav) {
     float* cl = reinterpret_cast<float*>(base + P.off_clean);
-    HIPCHK(launch_pack(reinterpret_cast<const float2*>(clean), B, S, T, F, cl, P.clean_bstride, Tp, 0, S, 1, s));
+    if (clean_wav) HIPCHK(launch_stft_pack(clean_wav, B, n_samples, S, T, tw, cl, P.clean_bstride, Tp, F, 0, S, 1, s));
+    else HIPCHK(launch_pack(reinterpret_cast<const float2*>(clean), B, S, T, F, cl, P.clean_bstride, Tp, 0, S, 1, s));
     // anchors = clean sources; candidates = shift-aligned ref-mic estimates.  The ref-mic forward is never
     // permuted by step 2 (its distance matrix has a zero diagonal), so the raw OUT1 planes are the candidates.
     PitArgs q;
@@ -801,7 +850,7 @@ int misonet_pipeline_run(misonet_pipeline* p, const void* mix, const void* clean
     HIPCHK(launch_pit_dist_k(q, 1, dist_clean, s));
     HIPCHK(launch_pit_pick(dist_clean, B, sel_clean, s));
   }
-  HIPCHK(launch_compose_sel(sel_shift, clean ? sel_clean : nullptr, B, M, S, sel_final, s));
+  HIPCHK(launch_compose_sel(sel_shift, (clean || clean_wav) ? sel_clean : nullptr, B, M, S, sel_final, s));
 
   // 4. MISO3 input = [mixture | beamformer | MISO1 estimate at ref_ch] (tester.py:936-939), B*S samples
   float* in3 = buf_ptr(P.L3, ws3, B_IN);
@@ -831,6 +880,19 @@ int misonet_pipeline_run(misonet_pipeline* p, const void* mix, const void* clean
     HIPCHK(launch_unpack_ex(out1, n1->cfg.out_ch, Tp, S, T, F, 0, S, 1, M, sel_final, reinterpret_cast<float2*>(miso1_out),
                             B * S * M, reinterpret_cast<int*>(base), s));
   return MISONET_OK;
+}
+
+int misonet_pipeline_run(misonet_pipeline* p, const void* mix, const void* clean, int B, int T, void* out, void* bf_out,
+                         void* miso1_out, void* ws, long long ws_bytes, misonet_stream stream) {
+  return pipeline_run_impl(p, mix, clean, nullptr, nullptr, 0, B, T, out, bf_out, miso1_out, ws, ws_bytes, stream);
+}
+
+int misonet_pipeline_run_wav(misonet_pipeline* p, const float* wav, const float* clean_wav, int B, int n_samples,
+                             void* out, void* bf_out, void* miso1_out, void* ws, long long ws_bytes,
+                             misonet_stream stream) {
+  if (n_samples <= 0) return fail(MISONET_EINVAL, "n_samples must be positive");
+  return pipeline_run_impl(p, nullptr, nullptr, wav, clean_wav, n_samples, B, misonet_stft_frames(n_samples), out, bf_out,
+                           miso1_out, ws, ws_bytes, stream);
 }
 
 int misonet_pipeline_check(misonet_pipeline* p, const void* ws, misonet_stream stream) {

@@ -129,6 +129,38 @@ class Enhancer:
             return out, dict(bf=bf, miso1=m1)
         return out
 
+    def enhance_wav(self, wav: torch.Tensor, clean_wav: Optional[torch.Tensor] = None, want_bf=False, want_miso1=False,
+                    check_nan=True):
+        """Waveform entry: wav float32 [B, n_samples, M] on the device (one 4 s chunk per row,
+        time-major as ``librosa.load(...).T``), clean_wav float32 [B, n_samples, S] = the clean sources at ref_ch, or
+        None.  The STFT front-end runs as a HIP kernel straight into the network's layout; returns what
+        :meth:`enhance` returns (T = n_samples // 64 + 1 frames)."""
+        wav = wav.to(torch.float32).contiguous()
+        B, Ls, M = wav.shape
+        if M != self.num_ch:
+            raise ValueError(f"expected {self.num_ch} microphones, got {M}")
+        if clean_wav is not None:
+            clean_wav = clean_wav.to(torch.float32).contiguous()
+            if tuple(clean_wav.shape) != (B, Ls, self.num_spks):
+                raise ValueError("clean_wav must be [B, n_samples, num_spks]")
+        L = _lib.lib()
+        T = L.misonet_stft_frames(Ls)
+        ws = self.workspace(B, T)
+        out = torch.empty((B, self.num_spks, T, 129), dtype=torch.complex64, device=self.device)
+        bf = torch.empty_like(out) if want_bf else None
+        m1 = torch.empty((B, self.num_spks, M, T, 129), dtype=torch.complex64, device=self.device) if want_miso1 else None
+        with torch.cuda.device(self.device):
+            st = _lib.stream_ptr(self.device)
+            _lib.check(L.misonet_pipeline_run_wav(self._pipe, wav.data_ptr(),
+                                                  clean_wav.data_ptr() if clean_wav is not None else None, B, Ls,
+                                                  out.data_ptr(), bf.data_ptr() if want_bf else None,
+                                                  m1.data_ptr() if want_miso1 else None, ws.data_ptr(), ws.numel(), st))
+            if check_nan:
+                _lib.check(L.misonet_pipeline_check(self._pipe, ws.data_ptr(), st))
+        if want_bf or want_miso1:
+            return out, dict(bf=bf, miso1=m1)
+        return out
+
     def inference(self, data_loader, saveDir, fs=16000, write=True):
         """Drop-in for ``Tester_Enhance.inference(data_loader, saveDir)`` (tester.py:846-975): the loader yields
         ``(split_observe_dict, split_clean_s0_dict, split_clean_s1_dict, gap, wav_name)`` with dict values complex

@@ -24,6 +24,26 @@ def _window(device, dtype=torch.float32):
     return torch.hann_window(NPERSEG, periodic=True, device=device, dtype=dtype)
 
 
+def stft_hip(wav: torch.Tensor) -> torch.Tensor:
+    """The hand-written HIP front-end (csrc/stft.hip, C ABI ``misonet_stft``): wav float32 [B, L, M] on the device
+    (time-major, microphones interleaved -- the ``librosa.load(...).T`` array of dataloader/data.py:605-616) ->
+    complex64 [B, M, T, 129], T = L // 64 + 1.  Same transform as :func:`stft` (DFT on the fp32 matrix cores)."""
+    import ctypes as C
+    from . import _lib
+    if wav.dim() != 3 or not wav.is_cuda:
+        raise ValueError("expected a device tensor [B, n_samples, n_mic]")
+    w = wav.to(torch.float32).contiguous()
+    B, L, M = w.shape
+    lib = _lib.lib()
+    T = lib.misonet_stft_frames(L)
+    out = torch.empty((B, M, T, 129), dtype=torch.complex64, device=w.device)
+    ws = torch.empty(lib.misonet_stft_workspace_bytes(B, M, L), dtype=torch.uint8, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(lib.misonet_stft(w.data_ptr(), B, L, M, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                    _lib.stream_ptr(w.device)))
+    return out
+
+
 def stft(wav: torch.Tensor) -> torch.Tensor:
     """wav float [..., L] -> complex64 [..., T, F] with T = L // 64 + 1, F = 129 (un-normalised, as fed to MISO_1)."""
     lead = wav.shape[:-1]

@@ -1,0 +1,56 @@
+"""GPU tests of the on-device STFT front-end (csrc/stft.hip) against the reference's SciPy contract
+(dataloader/data.py:505-522,540-544, restated in oracle/pipeline_oracle.stft_chunk) and of the waveform entry of the
+pipeline."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from test_gpu_parity import nets, _assert_parity, _need_gpu      # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("L,M,B", [(63 * 64, 6, 2), (64000, 6, 1), (1000, 3, 2), (64 * 5 + 17, 1, 1)])
+def test_stft_hip_vs_scipy_contract(L, M, B):
+    _need_gpu()
+    from misonet_amd import stft as S
+    from oracle import pipeline_oracle
+    r = np.random.default_rng(L + M)
+    wav = (0.05 * r.standard_normal((B, L, M))).astype(np.float32)
+    got = S.stft_hip(torch.from_numpy(wav).cuda()).cpu().numpy()
+    T = L // 64 + 1
+    assert got.shape == (B, M, T, 129)
+    for b in range(B):
+        # scipy pads the tail to a whole hop ("padded=True"): same frames as the zero-extended signal
+        ref = pipeline_oracle.stft_chunk(wav[b])
+        assert ref.shape[1] >= T - 1
+        n = min(T, ref.shape[1])
+        e = rel_l2(got[b][:, :n], ref[:, :n])
+        print(f"[stft] L={L} M={M} b={b}: rel_l2 {e:.3e}")
+        assert e < 2e-6
+    # and against the torch front-end used elsewhere
+    tor = S.stft(torch.from_numpy(wav).cuda().permute(0, 2, 1)).cpu().numpy()
+    assert rel_l2(got, tor) < 2e-6
+
+
+def test_enhance_wav_equals_enhance_on_stft(nets):
+    """Waveform entry == spectrogram entry fed with the reference-contract STFT (both precisions of the same chunk)."""
+    import misonet_amd as mz
+    from misonet_amd.weights import synthetic_utterance
+    from oracle import pipeline_oracle
+    m1, m3 = nets
+    enh = mz.Enhancer(m1, m3, num_spks=2, ref_ch=0)
+    n = 63 * 64
+    utts = [synthetic_utterance(u, n) for u in (7, 11)]
+    wav = torch.from_numpy(np.stack([u[0] for u in utts])).cuda()                         # [B, L, 6]
+    cwav = torch.from_numpy(np.stack([np.stack([u[1][:, 0], u[2][:, 0]], axis=1) for u in utts])).cuda()   # [B, L, 2]
+    out_w, ex = enh.enhance_wav(wav, cwav, want_bf=True)
+    mix = torch.from_numpy(np.stack([pipeline_oracle.stft_chunk(u[0]) for u in utts])).cuda()
+    clean = torch.from_numpy(np.stack([np.stack([pipeline_oracle.stft_chunk(u[1])[0], pipeline_oracle.stft_chunk(u[2])[0]])
+                                       for u in utts])).cuda()
+    out_s, ex_s = enh.enhance(mix, clean, want_bf=True)
+    _assert_parity(out_w.cpu().numpy(), out_s.cpu().numpy(), "enhance_wav vs enhance(stft)")
+    _assert_parity(ex["bf"].cpu().numpy(), ex_s["bf"].cpu().numpy(), "enhance_wav bf vs enhance(stft) bf")
+    with pytest.raises(ValueError):
+        enh.enhance_wav(wav[:, :, :5])
