@@ -109,7 +109,9 @@ int misonet_pipeline_create(misonet_net* miso1, misonet_net* miso3, int num_mic,
 int misonet_pipeline_destroy(misonet_pipeline* p);
 long long misonet_pipeline_workspace_bytes(const misonet_pipeline* p, int B, int T);
 /* mix_dev complex64 [B,M,T,F]; clean_dev complex64 [B,S,T,F] or NULL; out_dev complex64 [B,S,T,F] (MISO3);
- * optional outputs (may be NULL): bf_dev complex64 [B,S,T,F] (MVDR), miso1_dev complex64 [B,S,M,T,F] (aligned). */
+ * optional outputs (may be NULL): bf_dev complex64 [B,S,T,F] (MVDR), miso1_dev complex64 [B,S,M,T,F] (aligned).
+ * out_dev == NULL with miso1_dev != NULL runs the separation stage only (MISO1_Inference + alignments): the input of
+ * the utterance-wise beamformer of Tester_Beamforming (tester.py:340-449). */
 int misonet_pipeline_run(misonet_pipeline* p, const void* mix_dev, const void* clean_dev, int B, int T,
                          void* out_dev, void* bf_dev, void* miso1_dev, void* ws_dev, long long ws_bytes,
                          misonet_stream stream);

@@ -794,7 +794,7 @@ long long misonet_pipeline_workspace_bytes(const misonet_pipeline* p, int B, int
 static int pipeline_run_impl(misonet_pipeline* p, const void* mix, const void* clean, const float* wav,
                              const float* clean_wav, int n_samples, int B, int T, void* out, void* bf_out,
                              void* miso1_out, void* ws, long long ws_bytes, misonet_stream stream) {
-  if (!p || (!mix && !wav) || !out || !ws) return fail(MISONET_EINVAL, "null argument");
+  if (!p || (!mix && !wav) || (!out && !miso1_out) || !ws) return fail(MISONET_EINVAL, "null argument");
   if (!p->n1->committed || !p->n3->committed) return fail(MISONET_ESTATE, "networks not committed");
   if (B <= 0 || T <= 0) return fail(MISONET_EINVAL, "B and T must be positive");
   const PipeLayout P = pipe_layout(p, B, T);
@@ -852,30 +852,32 @@ static int pipeline_run_impl(misonet_pipeline* p, const void* mix, const void* c
   }
   HIPCHK(launch_compose_sel(sel_shift, (clean || clean_wav) ? sel_clean : nullptr, B, M, S, sel_final, s));
 
-  // 4. MISO3 input = [mixture | beamformer | MISO1 estimate at ref_ch] (tester.py:936-939), B*S samples
-  float* in3 = buf_ptr(P.L3, ws3, B_IN);
-  const long long in3_bs = bstride(n3, P.L3, B_IN);
-  HIPCHK(launch_assemble3(in1, in1_bs, out1, out1_bs, sel_final, B, M, S, p->ref_ch, F, Tp, in3, in3_bs, s));
+  if (out) {   // out == NULL: separation only (MISO1_Inference + alignments), e.g. for the utterance-wise beamformer
+    // 4. MISO3 input = [mixture | beamformer | MISO1 estimate at ref_ch] (tester.py:936-939), B*S samples
+    float* in3 = buf_ptr(P.L3, ws3, B_IN);
+    const long long in3_bs = bstride(n3, P.L3, B_IN);
+    HIPCHK(launch_assemble3(in1, in1_bs, out1, out1_bs, sel_final, B, M, S, p->ref_ch, F, Tp, in3, in3_bs, s));
 
-  // 5. MVDR per aligned speaker (tester.py:917-924, 1071-1136); writes the beamformer planes of the MISO3 input
-  {
-    MvdrArgs a;
-    a.mix = {in1, in1 + (long long)M * plane, (long long)M * in1_bs, Tp, plane, 1};   // shift-0 sample = un-rolled mixture
-    a.est = out1; a.est_bstride = out1_bs; a.sel = sel_final;
-    a.src = {nullptr, nullptr, 0, 0, 0, 1};
-    a.S = S; a.B = B; a.F = F; a.M = M; a.T = T; a.Tp = Tp; a.epsi = p->epsi;
-    COut co = {in3 + (long long)M * plane, in3 + (long long)(2 * M + 2) * plane, (long long)S * in3_bs, in3_bs, 1, Tp};
-    ProfScope ps(s, PK_MVDR);
-    HIPCHK(launch_mvdr(a, co, base + P.off_mvdr, s));
+    // 5. MVDR per aligned speaker (tester.py:917-924, 1071-1136); writes the beamformer planes of the MISO3 input
+    {
+      MvdrArgs a;
+      a.mix = {in1, in1 + (long long)M * plane, (long long)M * in1_bs, Tp, plane, 1};   // shift-0 sample = un-rolled mixture
+      a.est = out1; a.est_bstride = out1_bs; a.sel = sel_final;
+      a.src = {nullptr, nullptr, 0, 0, 0, 1};
+      a.S = S; a.B = B; a.F = F; a.M = M; a.T = T; a.Tp = Tp; a.epsi = p->epsi;
+      COut co = {in3 + (long long)M * plane, in3 + (long long)(2 * M + 2) * plane, (long long)S * in3_bs, in3_bs, 1, Tp};
+      ProfScope ps(s, PK_MVDR);
+      HIPCHK(launch_mvdr(a, co, base + P.off_mvdr, s));
+    }
+    // 6. MISO3 per speaker (tester.py:1231-1244)
+    r = forward_planar(n3, P.L3, ws3, s);
+    if (r) return r;
+    HIPCHK(launch_unpack(buf_ptr(P.L3, ws3, B_OUT), bstride(n3, P.L3, B_OUT), Tp, 1, T, F, reinterpret_cast<float2*>(out),
+                         B * S, reinterpret_cast<int*>(base), s));
+    if (bf_out)
+      HIPCHK(launch_unpack_ex(in3, n3->cfg.in_ch, Tp, 1, T, F, M, 2 * M + 2, 0, 1, nullptr,
+                              reinterpret_cast<float2*>(bf_out), B * S, reinterpret_cast<int*>(base), s));
   }
-  // 6. MISO3 per speaker (tester.py:1231-1244)
-  r = forward_planar(n3, P.L3, ws3, s);
-  if (r) return r;
-  HIPCHK(launch_unpack(buf_ptr(P.L3, ws3, B_OUT), bstride(n3, P.L3, B_OUT), Tp, 1, T, F, reinterpret_cast<float2*>(out),
-                       B * S, reinterpret_cast<int*>(base), s));
-  if (bf_out)
-    HIPCHK(launch_unpack_ex(in3, n3->cfg.in_ch, Tp, 1, T, F, M, 2 * M + 2, 0, 1, nullptr, reinterpret_cast<float2*>(bf_out),
-                            B * S, reinterpret_cast<int*>(base), s));
   if (miso1_out)
     HIPCHK(launch_unpack_ex(out1, n1->cfg.out_ch, Tp, S, T, F, 0, S, 1, M, sel_final, reinterpret_cast<float2*>(miso1_out),
                             B * S * M, reinterpret_cast<int*>(base), s));

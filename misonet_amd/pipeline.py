@@ -161,6 +161,58 @@ class Enhancer:
             return out, dict(bf=bf, miso1=m1)
         return out
 
+    def separate(self, mix: torch.Tensor, clean: Optional[torch.Tensor] = None, check_nan=True) -> torch.Tensor:
+        """Separation stage only: MISO1_Inference over the circular shifts + alignments (tester.py:1014-1068, 889-915).
+        mix complex [B,M,T,F] -> aligned estimates complex64 [B,S,M,T,F] (speaker, microphone)."""
+        mix = mix.to(torch.complex64).contiguous()
+        B, M, T, F = mix.shape
+        if clean is not None:
+            clean = clean.to(torch.complex64).contiguous()
+        ws = self.workspace(B, T)
+        m1 = torch.empty((B, self.num_spks, M, T, F), dtype=torch.complex64, device=self.device)
+        L = _lib.lib()
+        with torch.cuda.device(self.device):
+            st = _lib.stream_ptr(self.device)
+            _lib.check(L.misonet_pipeline_run(self._pipe, mix.data_ptr(), clean.data_ptr() if clean is not None else None,
+                                              B, T, None, None, m1.data_ptr(), ws.data_ptr(), ws.numel(), st))
+            if check_nan:
+                _lib.check(L.misonet_pipeline_check(self._pipe, ws.data_ptr(), st))
+        return m1
+
+    def beamform_utterance(self, obs_splits: List[torch.Tensor], clean_splits: List[torch.Tensor], gap: int,
+                           epsi: float = 1e-6) -> np.ndarray:
+        """Utterance-wise MVDR of the reference's Tester_Beamforming (tester.py:340-449, ``utterance_flag``) for ONE
+        recording: every split is separated (:meth:`separate`), all (speaker, mic) estimates and the observation go
+        back to the time domain, the splits are stitched (last one trimmed by ``gap``), the whole recording is
+        re-analysed by the HIP STFT front-end and ONE MVDR per speaker is solved over all its frames (spatial
+        covariances accumulated over the full utterance instead of per 4 s chunk).
+        obs_splits: list of complex [M,T,F]; clean_splits: list of complex [S,T,F].  Returns int16 [S, n]."""
+        from .beamform import Apply_Beamforming
+        est_t, obs_t = [], []
+        for k, (obs, cl) in enumerate(zip(obs_splits, clean_splits)):
+            obs = torch.as_tensor(obs).to(self.device)[None]
+            cl = torch.as_tensor(cl).to(self.device)[None]
+            est = self.separate(obs, cl)[0]                                   # [S,M,T,F]
+            e = S.istft(est)                                                  # [S,M,chunk]
+            o = S.istft(obs[0])                                               # [M,chunk]
+            if k == len(obs_splits) - 1 and gap:
+                e, o = e[..., : e.shape[-1] - gap], o[..., : o.shape[-1] - gap]
+            est_t.append(e)
+            obs_t.append(o)
+        est_t = torch.cat(est_t, dim=-1)                                      # [S,M,L]
+        obs_t = torch.cat(obs_t, dim=-1)                                      # [M,L]
+        Ls = obs_t.shape[-1]
+        pad = (-Ls) % S.HOP                                                   # scipy's padded=True: whole hops
+        sig = torch.cat([obs_t[None], est_t], dim=0)                          # [1+S, M, L]
+        sig = torch.nn.functional.pad(sig, (0, pad)).permute(0, 2, 1).contiguous()      # [1+S, Lp, M]
+        spec = S.stft_hip(sig)                                                # [1+S, M, Tt, F]
+        mix_bf = spec[0].permute(2, 0, 1)[None]                               # [1,F,M,Tt]
+        out = []
+        for s in range(self.num_spks):
+            bf = Apply_Beamforming(spec[1 + s].permute(2, 0, 1)[None], mix_bf, epsi)     # [1,Tt,F]
+            out.append(S.istft_int16(bf[0]).cpu().numpy())
+        return np.stack(out)
+
     def inference(self, data_loader, saveDir, fs=16000, write=True):
         """Drop-in for ``Tester_Enhance.inference(data_loader, saveDir)`` (tester.py:846-975): the loader yields
         ``(split_observe_dict, split_clean_s0_dict, split_clean_s1_dict, gap, wav_name)`` with dict values complex

@@ -78,3 +78,42 @@ def enhance_utterance(mix, clean, sd1, sd3, ref_ch=0, epsi=1e-6) -> Dict[str, np
                                       torch.from_numpy(est[s, ref_ch])[None, None], sd3)   # tester.py:937-939,1242
         out.append(o[0, 0].numpy())
     return dict(miso1=est, bf=np.stack(bf), out=np.stack(out), sel_clean=sel[0], sel_shift=sel_shift)
+
+
+def beamform_utterance(obs_splits, clean_splits, gap, sd1, ref_ch=0, epsi=1e-6, fs=16000):
+    """Utterance-wise MVDR of Tester_Beamforming (tester.py:340-449, utterance_flag): per split MISO1_Inference +
+    clean alignment, iSTFT every (speaker, mic) estimate and the observation, stitch the splits (last one trimmed by
+    ``gap``), re-STFT the whole recording, one MVDR per speaker over all frames, iSTFT -> int16.
+
+    obs_splits: list of complex [M,T,F]; clean_splits: list of complex [S,T,F] (clean sources at ref_ch).
+    Returns int16 [S, n] (n = recording length rounded up to a whole hop, as scipy's padded STFT/iSTFT pair gives)."""
+    n_split = len(obs_splits)
+    est_t, obs_t = None, None
+    for k in range(n_split):
+        est, _ = miso1_inference(obs_splits[k], sd1, ref_ch)                               # [S,M,T,F]
+        sel, _ = mvdr_oracle.pit_select(np.asarray(clean_splits[k])[None], est[None, :, ref_ch])
+        est = est[sel[0]]
+        S, M = est.shape[:2]
+        def to_time(x_mtf):                                                                # [M,T,F] -> [M, chunk]
+            _, t_sig = scipy.signal.istft(np.transpose(x_mtf, (0, 2, 1)) * SCALE, fs=fs, window=WINDOW,
+                                          nperseg=NPERSEG, noverlap=NOVERLAP)
+            return t_sig
+        e_t = [to_time(est[s]) for s in range(S)]
+        o_t = to_time(np.asarray(obs_splits[k]))
+        if k == n_split - 1 and gap:
+            e_t = [e[:, : e.shape[1] - gap] for e in e_t]
+            o_t = o_t[:, : o_t.shape[1] - gap]
+        est_t = e_t if est_t is None else [np.append(a, b, axis=1) for a, b in zip(est_t, e_t)]
+        obs_t = o_t if obs_t is None else np.append(obs_t, o_t, axis=1)
+
+    def stft_utt(x_ml):                                                                    # [M, L] float64 -> [1,F,M,T]
+        z = np.stack([scipy.signal.stft(x_ml[c], fs=fs, window=WINDOW, nperseg=NPERSEG, noverlap=NOVERLAP)[2]
+                      for c in range(x_ml.shape[0])]) / SCALE                              # [M,F,T] complex128
+        return np.transpose(z, (1, 0, 2))[None]
+    mix = stft_utt(obs_t)
+    out = []
+    for s in range(len(est_t)):
+        bf = mvdr_oracle.mvdr_parts(stft_utt(est_t[s]), mix, epsi, dtype=np.complex128)["out"][0]   # [T,F]
+        _, t_sig = scipy.signal.istft(bf.T * SCALE, fs=fs, window=WINDOW, nperseg=NPERSEG, noverlap=NOVERLAP)
+        out.append((t_sig * np.iinfo(np.int16).max).astype(np.int16))
+    return np.stack(out)

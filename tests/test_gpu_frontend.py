@@ -54,3 +54,31 @@ def test_enhance_wav_equals_enhance_on_stft(nets):
     _assert_parity(ex["bf"].cpu().numpy(), ex_s["bf"].cpu().numpy(), "enhance_wav bf vs enhance(stft) bf")
     with pytest.raises(ValueError):
         enh.enhance_wav(wav[:, :, :5])
+
+
+def test_utterance_wise_mvdr_vs_reference_golden(nets, sd1):
+    """Tester_Beamforming's utterance_flag mode (tester.py:340-449) -- SCMs over the whole recording.
+    Against the golden produced by the real reference (G9) and the oracle."""
+    import misonet_amd as mz
+    from conftest import golden
+    from misonet_amd.weights import synthetic_utterance
+    from misonet_amd.stft import split_chunks
+    from oracle import pipeline_oracle
+    m1, m3 = nets
+    enh = mz.Enhancer(m1, m3, num_spks=2, ref_ch=0)
+    g = golden("g9_utterance_mvdr.npz")
+    frames, gap = int(g["frames"]), int(g["gap"])
+    chunk = (frames - 1) * 64
+    obs, s0, s1 = synthetic_utterance(int(g["utt"]), 2 * chunk - gap)
+    po, _ = split_chunks(obs, chunk)
+    p0, _ = split_chunks(s0, chunk)
+    p1, _ = split_chunks(s1, chunk)
+    obs_s = [pipeline_oracle.stft_chunk(p) for p in po]
+    cl_s = [np.stack([pipeline_oracle.stft_chunk(a)[0], pipeline_oracle.stft_chunk(b)[0]]) for a, b in zip(p0, p1)]
+    wav = enh.beamform_utterance([torch.from_numpy(o) for o in obs_s], [torch.from_numpy(c) for c in cl_s], gap)
+    assert wav.shape == (2, g["wav0"].shape[0]) and wav.dtype == np.int16
+    for s in range(2):
+        d = np.abs(wav[s].astype(np.int32) - g[f"wav{s}"].astype(np.int32))
+        scale = np.abs(g[f"wav{s}"].astype(np.int32)).max()
+        print(f"[utt-mvdr] spk{s}: max |diff| {d.max()} LSB of peak {scale}")
+        assert d.max() <= max(3, int(1e-3 * scale))

@@ -91,3 +91,24 @@ def test_g8_sample_clean_config1(sd1):
     y = miso_oracle.miso1_forward(torch.from_numpy(x), sd1).numpy()
     assert rel_l2(y[:, :, 200:232], g["y_slice"]) < 5e-5
     assert rel_l2(np.abs(y).sum(-1), g["mag_sum_per_frame"]) < 2e-5
+
+
+def test_g9_utterance_wise_mvdr(sd1):
+    """Tester_Beamforming's utterance_flag path (tester.py:340-449): golden from the real reference."""
+    from misonet_amd.weights import synthetic_utterance
+    from misonet_amd.stft import split_chunks
+    g = golden("g9_utterance_mvdr.npz")
+    frames, gap = int(g["frames"]), int(g["gap"])
+    chunk = (frames - 1) * 64
+    obs, s0, s1 = synthetic_utterance(int(g["utt"]), 2 * chunk - gap)
+    po, gap2 = split_chunks(obs, chunk)
+    p0, _ = split_chunks(s0, chunk)
+    p1, _ = split_chunks(s1, chunk)
+    assert gap2 == gap
+    obs_s = [pipeline_oracle.stft_chunk(p) for p in po]
+    cl_s = [np.stack([pipeline_oracle.stft_chunk(a)[0], pipeline_oracle.stft_chunk(b)[0]]) for a, b in zip(p0, p1)]
+    wav = pipeline_oracle.beamform_utterance(obs_s, cl_s, gap, sd1)
+    assert wav.shape == (2, g["wav0"].shape[0])
+    for s in range(2):
+        d = np.abs(wav[s].astype(np.int32) - g[f"wav{s}"].astype(np.int32))
+        assert d.max() <= 2, d.max()
