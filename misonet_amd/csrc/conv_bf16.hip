@@ -16,6 +16,7 @@
 #include "kernels.hpp"
 #include "conv_epilogue.hpp"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace mn {
@@ -125,6 +126,7 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 1) ? 2 : 1)) void conv3x
   bf16x8* s_wlo = s_whi + WN;
   float2* s_nrm = reinterpret_cast<float2*>(s_wlo + WN);
 
+  const unsigned long long ts0 = clock64();
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -289,14 +291,21 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 1) ? 2 : 1)) void conv3x
 
   const int half = lane >> 5, l31 = lane & 31;
 
+  const bool stamp = a.dbg_buf && tid == 0 && blockIdx.x == 3 && blockIdx.y == 5 && blockIdx.z == 7;
+  int si = 0;
+#define STAMP() do { if (stamp && si < 60) a.dbg_buf[si++] = clock64() - ts0; } while (0)
+  STAMP();
   BF_ISSUE(0)
   __syncthreads();          // s_nrm visible
+  STAMP();
   BF_COMMIT(0)
   __syncthreads();
+  STAMP();
 
   for (int kc = 0; kc < nchunk; ++kc) {
     const bool more = (kc + 1 < nchunk);
     if (more) BF_ISSUE(kc + 1)
+    STAMP();
     if (row_ok) {
       __builtin_amdgcn_s_setprio(1);       // MFMA phase outranks the co-resident block's staging phase (+1 % measured)
       if (TR2) {
@@ -307,10 +316,14 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 1) ? 2 : 1)) void conv3x
       }
       __builtin_amdgcn_s_setprio(0);
     }
+    STAMP();
     __syncthreads();
+    STAMP();
     if (more) {
       BF_COMMIT(kc + 1)
+      STAMP();
       __syncthreads();
+      STAMP();
     }
   }
 #undef BF_ISSUE
@@ -319,6 +332,7 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 1) ? 2 : 1)) void conv3x
   // ---- epilogue (conv_epilogue.hpp) ----
   float* s_red = reinterpret_cast<float*>(smem_b);   // [FT][COP][2]
   conv_epilogue<NCO>(a, acc, n, cg, f, t0, row_ok, lane, s_red + wave * (COP * 2));
+  STAMP();
   if (a.act) {
     __syncthreads();
     if (tid < COP * 2) {
@@ -332,6 +346,9 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 1) ? 2 : 1)) void conv3x
       }
     }
   }
+  STAMP();
+  if (stamp) a.dbg_buf[63] = si;
+#undef STAMP
 }
 
 // =====================================================================================================================
@@ -677,6 +694,7 @@ hipError_t conv_bf16_init() {
   if ((e = bf_set_attr<2, 2>()) != hipSuccess) return e;
   if ((e = ws_set_attr<0>()) != hipSuccess) return e;
   if ((e = ws_set_attr<2>()) != hipSuccess) return e;
+  if ((e = conv_bf16_r8_init()) != hipSuccess) return e;
   int dev = 0;
   if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
   hipDeviceProp_t prop;
@@ -698,6 +716,20 @@ hipError_t launch_conv_bf16(const ConvArgs& a_in, int n_samples, hipStream_t s) 
   const size_t lds = bf_lds_bytes(a.NR, a.cop, a.Cin);
   const int mode = a.tr2 ? 2 : (a.sf == 2 ? 1 : 0);
   if (a.NR != conv_rows(a.sf, a.tr2) || !a.w16) return hipErrorInvalidValue;
+  {
+    static int r8_env = -1;
+    if (r8_env < 0) { const char* e = getenv("MISONET_R8"); r8_env = e ? atoi(e) : 0; }
+    if (r8_env && mode == 0 && a.cop == 32 && !g_ws_enabled) return launch_conv_bf16_r8(a, n_samples, s);
+  }
+  static int tl_env = -1;
+  static int tl_done = 0;
+  static unsigned long long* tl_buf = nullptr;
+  if (tl_env < 0) { const char* e = getenv("MISONET_TIMELINE"); tl_env = e ? atoi(e) : 0; }
+  const bool do_tl = tl_env && tl_done < 3 && mode == 0 && a.Cin == 96 && a.Fout == 63 && n_samples >= 8;
+  if (do_tl) {
+    if (!tl_buf && hipMalloc(reinterpret_cast<void**>(&tl_buf), 64 * 8) != hipSuccess) tl_buf = nullptr;
+    if (tl_buf) { (void)hipMemsetAsync(tl_buf, 0, 64 * 8, s); a.dbg_buf = tl_buf; }
+  }
   if (g_ws_enabled && mode != 1 && a.cop == 32 && a.Cin <= 256 && g_ws_cus > 0) {
     const int ntt = (a.T + TT - 1) / TT, ntf = (a.Fout + FT - 1) / FT;
     const int ntiles = ntt * ntf * n_samples * a.ncg;
@@ -714,6 +746,15 @@ hipError_t launch_conv_bf16(const ConvArgs& a_in, int n_samples, hipStream_t s) 
     if (mode == 0) MN_LAUNCH(2, 0); else if (mode == 1) MN_LAUNCH(2, 1); else MN_LAUNCH(2, 2);
   }
 #undef MN_LAUNCH
+  if (do_tl && tl_buf) {
+    unsigned long long h[64];
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h, tl_buf, sizeof(h), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[timeline] Cin=%d Fout=%d n=%d stamps=%llu:", a.Cin, a.Fout, n_samples, h[63]);
+    for (unsigned long long i = 0; i < h[63] && i < 60; ++i) fprintf(stderr, " %llu", h[i]);
+    fprintf(stderr, "\n");
+    ++tl_done;
+  }
   return hipGetLastError();
 }
 

@@ -3,7 +3,8 @@
 // One wave owns one output row f and NCO x 4 accumulator tiles of 32 channels x 32 frames in the MFMA C/D layout
 // (register r of lane l: channel (r&3) + 8*(r>>2) + 4*(l>>5), frame l&31).  Everything that is uniform goes through
 // the scalar unit:
-//   * stores are buffer stores: one descriptor per sample (readfirstlane'd, so no waterfall loop), the per-lane part
+//   * stores are 16-byte buffer stores after an in-register 4x4 quad transpose (4 consecutive frames of one channel per
+//     lane): one descriptor per sample (readfirstlane'd, so no waterfall loop), the per-lane part
 //     (row, frame, half-wave channel offset) is ONE VGPR byte offset per frame tile plus the (uniform) channel-plane
 //     offset of the accumulator register -- added in the VGPR, because the SGPR soffset of a raw buffer is not
 //     bounds-checked.  Channels >= Cout fall outside num_records and frames >= T get an out-of-range offset: the
@@ -18,6 +19,7 @@
 namespace mn {
 
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
 // ELU(alpha = 1) = x > 0 ? x : exp(x) - 1 (reference model.py:412,429,444) on the hardware exp2: absolute error
 // ~1e-7, far below the path's tolerance; ocml expm1f costs ~50 instructions per element.
@@ -33,10 +35,64 @@ __device__ __forceinline__ float half_wave_sum(float v) {
   return v;
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// 16 per-lane partial sums v[0..15] -> the sum of v[q] over the 32 lanes of this half-wave, returned in the lane whose
+// (lane & 15) == q (both 16-lane rows of the half-wave return it).  Reduce-scatter over DPP pairings (row_mirror,
+// row_half_mirror, quad_perm xor 2, xor 1): each step halves the registers a lane is responsible for, so the whole
+// reduction is 15 DPP moves + 15 adds + 30 selects instead of 16 x 5 dependent DPP adds.
+__device__ __forceinline__ float reduce16_halfwave(const float (&v)[16], int lane) {
+  const bool bA = (lane & 8) != 0, bB = (lane & 4) != 0, bC = (lane & 2) != 0, bD = (lane & 1) != 0;
+  float a[8], b[4], c[2];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float keep = bA ? v[k + 8] : v[k];
+    const float send = bA ? v[k] : v[k + 8];
+    a[k] = keep + dpp_get<0x140>(send);            // row_mirror: q <-> 15 - q
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float keep = bB ? a[k + 4] : a[k];
+    const float send = bB ? a[k] : a[k + 4];
+    b[k] = keep + dpp_get<0x141>(send);            // row_half_mirror: q <-> q ^ 7
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float keep = bC ? b[k + 2] : b[k];
+    const float send = bC ? b[k] : b[k + 2];
+    c[k] = keep + dpp_get<0x4E>(send);             // quad_perm [2,3,0,1]: q <-> q ^ 2
+  }
+  const float keep = bD ? c[1] : c[0];
+  const float send = bD ? c[0] : c[1];
+  float r = keep + dpp_get<0xB1>(send);            // quad_perm [1,0,3,2]: q <-> q ^ 1
+  r += __shfl_xor(r, 16, 64);                      // the other 16-lane row of this half-wave
+  return r;
+}
+
+// In-register 4x4 transpose inside every lane quad (two xor butterflies over DPP quad_perm): on entry lane i of a quad
+// holds x[k] = value of channel k at frame 4q+i; on exit x[j] = value of channel i at frame 4q+j, i.e. 4 consecutive
+// frames of ONE channel -> one 16-byte store per lane instead of four 4-byte stores (the epilogue was store-issue bound).
+__device__ __forceinline__ void quad_transpose4(float (&x)[4], int lane) {
+  const bool o1 = (lane & 1) != 0, o2 = (lane & 2) != 0;
+  {  // xor 1: 2x2 blocks (x0,x1) and (x2,x3)
+    const float g0 = dpp_get<0xB1>(o1 ? x[0] : x[1]);
+    const float g1 = dpp_get<0xB1>(o1 ? x[2] : x[3]);
+    if (o1) { x[0] = g0; x[2] = g1; } else { x[1] = g0; x[3] = g1; }
+  }
+  {  // xor 2: 2x2 blocks (x0,x2) and (x1,x3)
+    const float g0 = dpp_get<0x4E>(o2 ? x[0] : x[2]);
+    const float g1 = dpp_get<0x4E>(o2 ? x[1] : x[3]);
+    if (o2) { x[0] = g0; x[1] = g1; } else { x[2] = g0; x[3] = g1; }
+  }
+}
+
 // s_red: [COP][2] floats of THIS wave's row (the caller adds the rows of a tile).  COP = NCO * 32.
-template <int NCO>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16_t (&acc)[NCO][4], int n, int cg, int f, int t0,
-                                              bool row_ok, int lane, float* s_red) {
+template <int NCO, int NSEG = 4>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16_t (&acc)[NCO][NSEG], int n, int cg, int f,
+                                              int t0, bool row_ok, int lane, float* s_red) {
   constexpr int COP = NCO * 32;
   const int half = lane >> 5, l31 = lane & 31;
   const int T = a.T, Tp = a.Tp;
@@ -50,14 +106,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16_t (&acc)
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
       reinterpret_cast<void*>(((unsigned long long)phi << 32) | plo), 0,
       __builtin_amdgcn_readfirstlane((int)((unsigned)a.Cout * P4)), 0x00020000);
-  // ---- per-lane byte offsets, one per frame tile; out-of-range when the frame is >= T or the row is off ----
-  unsigned voff[4];
-  bool tm[4];
+  // ---- per-lane masks / byte offsets, one per frame tile ----
+  // statistics use the MFMA layout (lane <-> frame t0 + 32 s + l31); stores happen after a 4x4 quad transpose, where
+  // lane (q = l31 >> 2, i = l31 & 3) holds frames t0 + 32 s + 4q .. +3 of channel (4-group base + i).  A quad is stored
+  // when its first frame is < T (frames T..Tp-1 of a row are padding that no consumer reads unmasked).
+  bool tm[NSEG];
+  unsigned voff[NSEG];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
+  for (int s = 0; s < NSEG; ++s) {
     const int t = t0 + s * 32 + l31;
     tm[s] = row_ok && (t < T);
-    voff[s] = tm[s] ? ((unsigned)(f * Tp + t) * 4u + (unsigned)(4 * half) * P4) : 0x80000000u;
+    const int tq = t0 + s * 32 + (l31 & ~3);
+    voff[s] = (row_ok && tq < T) ? ((unsigned)(f * Tp + tq) * 4u + (unsigned)(4 * half + (l31 & 3)) * P4) : 0x80000000u;
   }
   const bool full_c = (cbase + COP <= a.Cout);                              // uniform: every channel of the group exists
   const int cmax = a.Cout - cbase - 4 * half;                               // lane's channel k_r + 32j is valid iff < cmax
@@ -69,33 +129,38 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16_t (&acc)
     for (int r = 0; r < 16; ++r) bs[r] = a.bias[cbase + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
     float s1[16], s2[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int kr = j * 32 + (r & 3) + 8 * (r >> 2);
-      const unsigned coff = (unsigned)(cbase + kr) * P4;                      // uniform plane offset
-      const bool cok = full_c || (kr < cmax);
-      float a1 = 0.f, a2 = 0.f;
+    for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        float v = acc[j][s][r] + bs[r];
-        if (a.act) v = elu_fast(v);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff[s] + coff, 0, 0);
-        const float vm = (tm[s] && cok) ? v : 0.f;
-        a1 += vm;
-        a2 = fmaf(vm, vm, a2);
-      }
-      s1[r] = a1;
-      s2[r] = a2;
-    }
-    if (a.act) {
+    for (int g = 0; g < 4; ++g) {                                            // register group g: channels 8g + 0..3 (+4*half)
+      const unsigned coff = (unsigned)(cbase + j * 32 + 8 * g) * P4;          // uniform plane offset of the group
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float x1 = half_wave_sum(s1[r]);
-        const float x2 = half_wave_sum(s2[r]);
-        if (l31 == 31) {
-          const int co_l = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          s_red[co_l * 2 + 0] = x1;
-          s_red[co_l * 2 + 1] = x2;
+      for (int s = 0; s < NSEG; ++s) {
+        float x[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int r = 4 * g + k;
+          float v = acc[j][s][r] + bs[r];
+          if (a.act) v = elu_fast(v);
+          const bool cok = full_c || ((j * 32 + 8 * g + k) < cmax);
+          const float vm = (tm[s] && cok) ? v : 0.f;
+          s1[r] += vm;
+          s2[r] = fmaf(vm, vm, s2[r]);
+          x[k] = v;
         }
+        quad_transpose4(x, lane);
+        u32x4_t pk = {__builtin_bit_cast(unsigned, x[0]), __builtin_bit_cast(unsigned, x[1]),
+                      __builtin_bit_cast(unsigned, x[2]), __builtin_bit_cast(unsigned, x[3])};
+        if (!(a.dbg & 8)) __builtin_amdgcn_raw_buffer_store_b128(pk, rs, voff[s] + coff, 0, 0);
+      }
+    }
+    if (a.act && !(a.dbg & 16)) {
+      const float x1 = reduce16_halfwave(s1, lane);
+      const float x2 = reduce16_halfwave(s2, lane);
+      if ((lane & 16) == 0) {
+        const int q = lane & 15;
+        const int co_l = j * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
+        s_red[co_l * 2 + 0] = x1;
+        s_red[co_l * 2 + 1] = x2;
       }
     }
   }

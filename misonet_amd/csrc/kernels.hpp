@@ -44,6 +44,7 @@ struct ConvArgs {
   int NR;                   // staged input rows per workgroup
   int ncg;                  // output-channel groups (grid.z = n_samples * ncg)
   int cop;                  // 32 or 64 output channels per group
+  unsigned long long* dbg_buf;   // timeline stamps of one workgroup (MISONET_TIMELINE=1, experiments only)
   int dbg;                  // timing experiments only (MISONET_WS_DEBUG bits): 1 = consumers skip MFMAs, 2 = producers idle, 4 = skip epilogue
 };
 int conv_cop(int Cout);                      // 32 (Cout <= 32) or 64
@@ -52,6 +53,8 @@ hipError_t launch_conv(const ConvArgs& a, int n_samples, hipStream_t s);
 hipError_t conv_init();                      // dynamic-LDS attributes
 hipError_t launch_conv_bf16(const ConvArgs& a, int n_samples, hipStream_t s);   // conv_bf16.hip (needs a.w16)
 hipError_t conv_bf16_init();
+hipError_t launch_conv_bf16_r8(const ConvArgs& a, int n_samples, hipStream_t s);   // conv_bf16_r8.hip: stride-1 layers
+hipError_t conv_bf16_r8_init();
 
 // ---- TCN (reference model.py:486-632) -----------------------------------------------------------------------------
 // x0 = IN2d(raw) materialised as the residual stream + its per-(n,c) statistics

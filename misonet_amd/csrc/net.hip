@@ -325,6 +325,7 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
   a.NR = conv_rows(c.sf, c.tr2);
   a.ncg = c.ncg; a.cop = c.cop;
   a.dbg = 0;
+  a.dbg_buf = nullptr;
   if (nb < 0) nb = L.N;
   a.in += (long long)n0 * a.in_bstride;
   a.out += (long long)n0 * a.out_bstride;
