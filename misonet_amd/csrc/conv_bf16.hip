@@ -125,6 +125,7 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 1) ? 2 : 1)) void conv3x
   bf16x8* s_whi = s_xlo + XN;                        // hi image followed by lo image (as packed in HBM)
   bf16x8* s_wlo = s_whi + WN;
   float2* s_nrm = reinterpret_cast<float2*>(s_wlo + WN);
+  float* s_bias = reinterpret_cast<float*>(s_nrm + ((a.Cin + CKB - 1) / CKB) * CKB);   // [COP]
 
   const unsigned long long ts0 = clock64();
   const int tid = threadIdx.x;
@@ -151,6 +152,8 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 1) ? 2 : 1)) void conv3x
     }
     s_nrm[c] = make_float2(rstd, -mean * rstd);            // (scale, shift): x_norm = fma(x, scale, shift)
   }
+
+  if (tid < COP) s_bias[tid] = a.bias[cg * COP + tid];
 
   const float* in_n = a.in + (long long)n * a.in_bstride + (long long)a.in_c0 * Fin * Tp;
   const u32x4* w_g = reinterpret_cast<const u32x4*>(a.w16) + (long long)cg * nchunk * (2 * WN);
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 1) ? 2 : 1)) void conv3x
 
   // ---- epilogue (conv_epilogue.hpp) ----
   float* s_red = reinterpret_cast<float*>(smem_b);   // [FT][COP][2]
-  conv_epilogue<NCO>(a, acc, n, cg, f, t0, row_ok, lane, s_red + wave * (COP * 2));
+  conv_epilogue<NCO>(a, acc, n, cg, f, t0, row_ok, lane, s_red + wave * (COP * 2), s_bias);
   STAMP();
   if (a.act) {
     __syncthreads();
@@ -675,7 +678,7 @@ void conv_bf16_ws_enable(int on) { g_ws_enabled = on; }
 
 static size_t bf_lds_bytes(int NR, int cop, int Cin) {
   const int nchunk = (Cin + CKB - 1) / CKB;
-  return (size_t)(2 * NR * 2 * TW + 2 * 9 * 2 * cop) * 16 + (size_t)nchunk * CKB * sizeof(float2);
+  return (size_t)(2 * NR * 2 * TW + 2 * 9 * 2 * cop) * 16 + (size_t)nchunk * CKB * sizeof(float2) + (size_t)cop * sizeof(float);
 }
 
 template <int NCO, int MODE>
@@ -751,7 +754,8 @@ hipError_t launch_conv_bf16(const ConvArgs& a_in, int n_samples, hipStream_t s) 
     (void)hipStreamSynchronize(s);
     (void)hipMemcpy(h, tl_buf, sizeof(h), hipMemcpyDeviceToHost);
     fprintf(stderr, "[timeline] Cin=%d Fout=%d n=%d stamps=%llu:", a.Cin, a.Fout, n_samples, h[63]);
-    for (unsigned long long i = 0; i < h[63] && i < 60; ++i) fprintf(stderr, " %llu", h[i]);
+    for (unsigned long long i = 0; i < h[63] && i < 40; ++i) fprintf(stderr, " %llu", h[i]);
+    fprintf(stderr, " | epi: %llu %llu %llu", h[41] - h[40], h[42] - h[41], h[43] - h[42]);
     fprintf(stderr, "\n");
     ++tl_done;
   }

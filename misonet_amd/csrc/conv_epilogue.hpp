@@ -3,8 +3,7 @@
 // One wave owns one output row f and NCO x 4 accumulator tiles of 32 channels x 32 frames in the MFMA C/D layout
 // (register r of lane l: channel (r&3) + 8*(r>>2) + 4*(l>>5), frame l&31).  Everything that is uniform goes through
 // the scalar unit:
-//   * stores are 16-byte buffer stores after an in-register 4x4 quad transpose (4 consecutive frames of one channel per
-//     lane): one descriptor per sample (readfirstlane'd, so no waterfall loop), the per-lane part
+//   * stores are buffer stores: one descriptor per sample (readfirstlane'd, so no waterfall loop), the per-lane part
 //     (row, frame, half-wave channel offset) is ONE VGPR byte offset per frame tile plus the (uniform) channel-plane
 //     offset of the accumulator register -- added in the VGPR, because the SGPR soffset of a raw buffer is not
 //     bounds-checked.  Channels >= Cout fall outside num_records and frames >= T get an out-of-range offset: the
@@ -92,7 +91,8 @@ __device__ __forceinline__ void quad_transpose4(float (&x)[4], int lane) {
 // s_red: [COP][2] floats of THIS wave's row (the caller adds the rows of a tile).  COP = NCO * 32.
 template <int NCO, int NSEG = 4>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16_t (&acc)[NCO][NSEG], int n, int cg, int f,
-                                              int t0, bool row_ok, int lane, float* s_red) {
+                                              int t0, bool row_ok, int lane, float* s_red,
+                                              const float* s_bias = nullptr) {
   constexpr int COP = NCO * 32;
   const int half = lane >> 5, l31 = lane & 31;
   const int T = a.T, Tp = a.Tp;
@@ -106,52 +106,58 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16_t (&acc)
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
       reinterpret_cast<void*>(((unsigned long long)phi << 32) | plo), 0,
       __builtin_amdgcn_readfirstlane((int)((unsigned)a.Cout * P4)), 0x00020000);
-  // ---- per-lane masks / byte offsets, one per frame tile ----
-  // statistics use the MFMA layout (lane <-> frame t0 + 32 s + l31); stores happen after a 4x4 quad transpose, where
-  // lane (q = l31 >> 2, i = l31 & 3) holds frames t0 + 32 s + 4q .. +3 of channel (4-group base + i).  A quad is stored
-  // when its first frame is < T (frames T..Tp-1 of a row are padding that no consumer reads unmasked).
+  // ---- per-lane masks / byte offsets, one per frame tile; an offset is out of range (store dropped) when the frame is
+  // >= T or the row is off ----
   bool tm[NSEG];
   unsigned voff[NSEG];
 #pragma unroll
   for (int s = 0; s < NSEG; ++s) {
     const int t = t0 + s * 32 + l31;
     tm[s] = row_ok && (t < T);
-    const int tq = t0 + s * 32 + (l31 & ~3);
-    voff[s] = (row_ok && tq < T) ? ((unsigned)(f * Tp + tq) * 4u + (unsigned)(4 * half + (l31 & 3)) * P4) : 0x80000000u;
+    voff[s] = tm[s] ? ((unsigned)(f * Tp + t) * 4u + (unsigned)(4 * half) * P4) : 0x80000000u;
   }
+  const bool all_t = row_ok && (t0 + NSEG * 32 <= T);                                  // uniform: every frame of the tile exists
   const bool full_c = (cbase + COP <= a.Cout);                              // uniform: every channel of the group exists
   const int cmax = a.Cout - cbase - 4 * half;                               // lane's channel k_r + 32j is valid iff < cmax
+  const bool unmasked = all_t && full_c;
 
 #pragma unroll
   for (int j = 0; j < NCO; ++j) {
     float bs[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bs[r] = a.bias[cbase + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+    for (int r = 0; r < 16; ++r) {
+      const int bi = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      bs[r] = s_bias ? s_bias[bi] : a.bias[cbase + bi];      // LDS copy made at kernel start, or global
+    }
     float s1[16], s2[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) {
+      const int kr = j * 32 + (r & 3) + 8 * (r >> 2);
+      const unsigned coff = (unsigned)(cbase + kr) * P4;                      // uniform plane offset
+      float a1 = 0.f, a2 = 0.f;
+      if (unmasked) {                                                         // the common case: no masks at all
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {                                            // register group g: channels 8g + 0..3 (+4*half)
-      const unsigned coff = (unsigned)(cbase + j * 32 + 8 * g) * P4;          // uniform plane offset of the group
-#pragma unroll
-      for (int s = 0; s < NSEG; ++s) {
-        float x[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int r = 4 * g + k;
+        for (int s = 0; s < NSEG; ++s) {
           float v = acc[j][s][r] + bs[r];
           if (a.act) v = elu_fast(v);
-          const bool cok = full_c || ((j * 32 + 8 * g + k) < cmax);
-          const float vm = (tm[s] && cok) ? v : 0.f;
-          s1[r] += vm;
-          s2[r] = fmaf(vm, vm, s2[r]);
-          x[k] = v;
+          if (!(a.dbg & 8)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff[s] + coff, 0, 0);
+          a1 += v;
+          a2 = fmaf(v, v, a2);
         }
-        quad_transpose4(x, lane);
-        u32x4_t pk = {__builtin_bit_cast(unsigned, x[0]), __builtin_bit_cast(unsigned, x[1]),
-                      __builtin_bit_cast(unsigned, x[2]), __builtin_bit_cast(unsigned, x[3])};
-        if (!(a.dbg & 8)) __builtin_amdgcn_raw_buffer_store_b128(pk, rs, voff[s] + coff, 0, 0);
+      } else {
+        const bool cok = full_c || (kr < cmax);
+#pragma unroll
+        for (int s = 0; s < NSEG; ++s) {
+          float v = acc[j][s][r] + bs[r];
+          if (a.act) v = elu_fast(v);
+          if (!(a.dbg & 8)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff[s] + coff, 0, 0);
+          const float vm = (tm[s] && cok) ? v : 0.f;
+          a1 += vm;
+          a2 = fmaf(vm, vm, a2);
+        }
       }
+      s1[r] = a1;
+      s2[r] = a2;
     }
     if (a.act && !(a.dbg & 16)) {
       const float x1 = reduce16_halfwave(s1, lane);
