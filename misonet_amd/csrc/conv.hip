@@ -18,6 +18,7 @@
 // Epilogue: + bias, ELU (model.py:412,429,444), raw store, per-(n,co) sum / sum^2 for the instance norm that the
 // NEXT layer applies while staging (model.py:413,430,445).
 #include "kernels.hpp"
+#include <stdlib.h>
 #include "conv_epilogue.hpp"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
@@ -112,10 +113,12 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2) ? 3 : 2)) void conv3x
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int t0 = blockIdx.x * TT;
-  const int f0 = blockIdx.y * FT;
-  const int n = blockIdx.z / a.ncg;
-  const int cg = blockIdx.z - n * a.ncg;
+  const ConvTile ct = conv_tile(a);
+  if (!ct.valid) return;
+  const int t0 = ct.t_tile * TT;
+  const int f0 = ct.f_tile * FT;
+  const int n = ct.n;
+  const int cg = ct.cg;
   const int T = a.T, Tp = a.Tp, Fin = a.Fin, Cin = a.Cin;
   const int nchunk = (Cin + CK - 1) / CK;
   const int fin0 = TR2 ? (f0 >> 1) - 1 : SF * f0 - a.padf;
@@ -305,8 +308,15 @@ hipError_t conv_init() {
   return set_lds_attr<2, 2>();
 }
 
-hipError_t launch_conv(const ConvArgs& a, int n_samples, hipStream_t s) {
-  dim3 grid((a.T + TT - 1) / TT, (a.Fout + FT - 1) / FT, n_samples * a.ncg);
+int conv_xcd_env() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MISONET_XCD"); v = e ? atoi(e) : 1; }
+  return v;
+}
+
+hipError_t launch_conv(const ConvArgs& a_in, int n_samples, hipStream_t s) {
+  ConvArgs a = a_in;
+  const dim3 grid = conv_grid(a, n_samples, TT, FT, conv_xcd_env());
   const size_t lds = conv_lds_bytes(a.NR, a.cop, a.Cin);
   const int mode = a.tr2 ? 2 : (a.sf == 2 ? 1 : 0);
   if (a.NR != conv_rows(a.sf, a.tr2)) return hipErrorInvalidValue;

@@ -131,10 +131,12 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 1) ? 2 : 1)) void conv3x
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int t0 = blockIdx.x * TT;
-  const int f0 = blockIdx.y * FT;
-  const int n = blockIdx.z / a.ncg;
-  const int cg = blockIdx.z - n * a.ncg;
+  const ConvTile ct = conv_tile(a);
+  if (!ct.valid) return;
+  const int t0 = ct.t_tile * TT;
+  const int f0 = ct.f_tile * FT;
+  const int n = ct.n;
+  const int cg = ct.cg;
   const int T = a.T, Tp = a.Tp, Fin = a.Fin, Cin = a.Cin;
   const int nchunk = (Cin + CKB - 1) / CKB;
   const int fin0 = TR2 ? (f0 >> 1) - 1 : SF * f0 - a.padf;
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 1) ? 2 : 1)) void conv3x
 
   const int half = lane >> 5, l31 = lane & 31;
 
-  const bool stamp = a.dbg_buf && tid == 0 && blockIdx.x == 3 && blockIdx.y == 5 && blockIdx.z == 7;
+  const bool stamp = a.dbg_buf && tid == 0 && ct.t_tile == 3 && ct.f_tile == 5 && n == 7 && cg == 0;
   int si = 0;
 #define STAMP() do { if (stamp && si < 60) a.dbg_buf[si++] = clock64() - ts0; } while (0)
   STAMP();
@@ -715,7 +717,7 @@ hipError_t launch_conv_bf16(const ConvArgs& a_in, int n_samples, hipStream_t s) 
     static int ws_env = -1;
     if (ws_env < 0) { const char* e = getenv("MISONET_WS"); ws_env = e ? atoi(e) : 0; g_ws_enabled = ws_env; }
   }
-  dim3 grid((a.T + TT - 1) / TT, (a.Fout + FT - 1) / FT, n_samples * a.ncg);
+  const dim3 grid = conv_grid(a, n_samples, TT, FT, conv_xcd_env());
   const size_t lds = bf_lds_bytes(a.NR, a.cop, a.Cin);
   const int mode = a.tr2 ? 2 : (a.sf == 2 ? 1 : 0);
   if (a.NR != conv_rows(a.sf, a.tr2) || !a.w16) return hipErrorInvalidValue;

@@ -44,9 +44,45 @@ struct ConvArgs {
   int NR;                   // staged input rows per workgroup
   int ncg;                  // output-channel groups (grid.z = n_samples * ncg)
   int cop;                  // 32 or 64 output channels per group
+  int xcd;                  // 1: 1-D grid with the XCD-aware tile order of conv_tile() (ntx, nty, nsamp valid)
+  int ntx, nty, nsamp;      // frame tiles, row tiles, samples of this launch
   unsigned long long* dbg_buf;   // timeline stamps of one workgroup (MISONET_TIMELINE=1, experiments only)
   int dbg;                  // timing experiments only (MISONET_WS_DEBUG bits): 1 = consumers skip MFMAs, 2 = producers idle, 4 = skip epilogue
 };
+// Workgroup -> tile.  Hardware hands consecutive workgroup ids to the 8 XCDs round-robin and every XCD has its own
+// L2, so with the natural (t, f, n) order the 8 frame tiles of a row sit on 8 different XCDs and every halo line is
+// fetched twice.  XCD order: id & 7 picks the XCD, id >> 3 walks that XCD's own samples (n % 8 == xcd) tile by
+// tile (frame tile fastest, then output-channel group, then row tile): all tiles that share halos or re-read the same
+// input with another channel group are co-resident on ONE XCD.
+struct ConvTile { int t_tile, f_tile, n, cg; bool valid; };
+__device__ __forceinline__ ConvTile conv_tile(const ConvArgs& a) {
+  ConvTile r;
+  if (a.xcd) {
+    const unsigned id = blockIdx.x;
+    const unsigned xcd = id & 7u, k = id >> 3;
+    const unsigned per = (unsigned)(a.ntx * a.nty * a.ncg);
+    const unsigned grp = k / per;
+    unsigned tile = k - grp * per;
+    r.n = (int)(grp * 8u + xcd);
+    r.t_tile = (int)(tile % (unsigned)a.ntx);
+    tile /= (unsigned)a.ntx;
+    r.cg = (int)(tile % (unsigned)a.ncg);
+    r.f_tile = (int)(tile / (unsigned)a.ncg);
+    r.valid = r.n < a.nsamp;
+  } else {
+    r.t_tile = blockIdx.x; r.f_tile = blockIdx.y;
+    r.n = blockIdx.z / a.ncg; r.cg = blockIdx.z - r.n * a.ncg;
+    r.valid = true;
+  }
+  return r;
+}
+// fills xcd/ntx/nty/nsamp and returns the launch grid
+inline dim3 conv_grid(ConvArgs& a, int n_samples, int tt, int ft, int xcd) {
+  a.ntx = (a.T + tt - 1) / tt; a.nty = (a.Fout + ft - 1) / ft; a.nsamp = n_samples; a.xcd = xcd;
+  if (xcd) return dim3((unsigned)(8 * ((n_samples + 7) / 8) * a.ntx * a.nty * a.ncg), 1, 1);
+  return dim3(a.ntx, a.nty, n_samples * a.ncg);
+}
+int conv_xcd_env();                          // MISONET_XCD (default 1)
 int conv_cop(int Cout);                      // 32 (Cout <= 32) or 64
 int conv_rows(int sf, int tr2);              // NR for the mode
 hipError_t launch_conv(const ConvArgs& a, int n_samples, hipStream_t s);

@@ -326,6 +326,7 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
   a.ncg = c.ncg; a.cop = c.cop;
   a.dbg = 0;
   a.dbg_buf = nullptr;
+  a.xcd = 0; a.ntx = a.nty = a.nsamp = 0;
   if (nb < 0) nb = L.N;
   a.in += (long long)n0 * a.in_bstride;
   a.out += (long long)n0 * a.out_bstride;
