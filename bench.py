@@ -150,7 +150,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=16, help="utterances per GPU per step (BASELINE configs[3]: 16)")
     ap.add_argument("--frames", type=int, default=1001)
-    ap.add_argument("--precision", choices=["f32", "bf16x3"], default="bf16x3",
+    ap.add_argument("--precision", choices=["f32", "bf16x3", "bf16x3d"], default="bf16x3",
                     help="arithmetic of the 3x3 convs: exact f32 MFMA, or 3-term bf16 split on the bf16 MFMA (default)")
     ap.add_argument("--no-alt", action="store_true", help="skip the short run of the other precision mode (N = 1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

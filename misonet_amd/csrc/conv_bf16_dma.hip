@@ -1,0 +1,293 @@
+// conv3x3_bf16x3_dma: the bf16x3 3x3 convolution (conv_bf16.hip; reference model.py:401-482) fed by LDS-DMA.
+//
+// conv3x3_bf16x3 is bound by the per-lane work of staging its input -- 24 buffer loads, 48 FMAs, 24 bf16 splits and 12
+// LDS writes per lane and K-chunk -- not by the matrix pipe (48 % busy) or HBM (profiles/r01_final_bf16x3_*).  This
+// kernel removes that work from the consumer altogether:
+//   * activations travel in the "oct" layout (kernels.hpp): the PRODUCER's epilogue stores bias + ELU output already
+//     split into bf16 hi / lo, 8 channels of one frame per 16-byte unit -- exactly one lane's MFMA B operand;
+//   * the instance norm of the input, x_n = x * scale[n][ci] + shift[n][ci], is folded into the weights instead of the
+//     data: conv_wprep_k scales the weights per sample (W'[n] = W * scale[n]), splits them into bf16 hi / lo in LDS
+//     image order, and reduces the shift term to a 9-entry border-aware bias table per (sample, output channel) --
+//     zero padding is applied AFTER normalisation in the reference, so a tap that falls into the padding must not
+//     contribute its W * shift (conv_epilogue.hpp picks the taps that are inside);
+//   * staging is then a pure copy: `buffer_load_dwordx4 ... lds` moves 1 KB per wave instruction from HBM/L2 straight
+//     into the LDS operand images, no VGPRs, no VALU.  Rows / frames / channel octets outside the image get an
+//     out-of-range offset, for which the hardware writes zeros.
+// Same GEMM roles, tile (4 rows x 128 frames x 32 output channels), LDS images and MFMA loop as conv3x3_bf16x3.
+#include "kernels.hpp"
+#include "conv_epilogue.hpp"
+#include "conv_bf16_core.hpp"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+#include <stdlib.h>
+
+namespace mn {
+
+#define MN_LDS(p) ((__attribute__((address_space(3))) void*)(p))
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_u(unsigned long long pa, unsigned bytes) {
+  const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pa);
+  const unsigned phi = __builtin_amdgcn_readfirstlane((unsigned)(pa >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)phi << 32) | plo), 0,
+                                           __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_dma(const ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (the LDS-DMA builtin has no host form)
+  constexpr int NCO = 1, COP = 32;
+  constexpr int NR = MODE == 0 ? 6 : (MODE == 1 ? 9 : 3);
+  constexpr int SF = MODE == 1 ? 2 : 1;
+  constexpr bool TR2 = MODE == 2;
+  constexpr int NPAIR = 2 * NR;                      // (row, channel-octet) pairs per chunk
+  constexpr int XN = NPAIR * TW;                     // 16-byte units per input image (hi or lo)
+  constexpr int WN = 9 * 2 * COP;                    // 16-byte units per weight image (hi or lo)
+  constexpr int NXI = (XN + 255) / 256;              // DMA instructions per wave and input image
+  constexpr int NWI = (2 * WN + 255) / 256;          // DMA instructions per wave for the weight images
+  extern __shared__ __align__(16) unsigned char smem_b[];
+  bf16x8* s_xhi = reinterpret_cast<bf16x8*>(smem_b);
+  bf16x8* s_xlo = s_xhi + XN;
+  bf16x8* s_whi = s_xlo + XN;                        // hi image followed by lo image (as packed in HBM)
+  bf16x8* s_wlo = s_whi + WN;
+  float* s_b4 = reinterpret_cast<float*>(s_wlo + WN);          // [FT][COP][4]
+  float* s_bt = s_b4 + FT * COP * 4;                           // [COP][9]
+
+  const ConvTile ct = conv_tile(a);
+  if (!ct.valid) return;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t0 = ct.t_tile * TT;
+  const int f0 = ct.f_tile * FT;
+  const int n = ct.n;
+  const int cg = ct.cg;
+  const int T = a.T, Tp = a.Tp, Fin = a.Fin, Cin = a.Cin;
+  const int nchunk = (Cin + CKB - 1) / CKB;
+  const int fin0 = TR2 ? (f0 >> 1) - 1 : SF * f0 - a.padf;
+
+  // ---- descriptors: hi and lo halves of this sample's input (octets beyond the slice are out of range -> zeros) ----
+  const unsigned P16 = (unsigned)Fin * (unsigned)Tp * 16u;                   // bytes per octet plane
+  const unsigned long long in_b = reinterpret_cast<unsigned long long>(a.in) + (unsigned long long)n * a.in_bstride * 4ull;
+  const unsigned in_rec = (unsigned)((a.in_c0 + Cin) >> 3) * P16;
+  const __amdgpu_buffer_rsrc_t rs_hi = make_rsrc_u(in_b, in_rec);
+  const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc_u(in_b + (unsigned long long)(a.in_sstride >> 3) * P16, in_rec);
+  const unsigned wbytes = (unsigned)nchunk * (unsigned)(2 * WN) * 16u;       // one (sample, group) weight image set
+  const __amdgpu_buffer_rsrc_t rs_w = make_rsrc_u(
+      reinterpret_cast<unsigned long long>(a.wps) + (unsigned long long)n * a.wps_nstride + (unsigned long long)cg * wbytes, wbytes);
+
+  // ---- per-lane source offsets of the units this lane copies (unit u -> pair p = u / TW, frame slot j = u % TW) ----
+  unsigned xo[NXI];
+#pragma unroll
+  for (int i = 0; i < NXI; ++i) {
+    const int u = (i * 4 + wave) * 64 + lane;
+    const int p = u / TW, j = u - p * TW;
+    const int fin = fin0 + (p >> 1);
+    const int t = t0 - 4 + j;
+    const bool ok = u < XN && fin >= 0 && fin < Fin && t >= 0 && t < T && j >= 3 && j <= TT + 4;
+    xo[i] = ok ? ((unsigned)(((a.in_c0 >> 3) + (p & 1)) * Fin + fin) * (unsigned)Tp + (unsigned)t) * 16u : 0x80000000u;
+  }
+  const unsigned xstep = 2u * P16;                                           // two octets per K-chunk
+  const unsigned wo = (unsigned)tid * 16u;
+
+  // ---- bias + folded instance-norm shift of this wave's row: s_b4[wave][co] = (bL, bC, bR, bL + bC + bR) ----
+  const int f = f0 + wave;
+  const bool row_ok = f < a.Fout;
+  if (a.btab) {
+    const float* bt = a.btab + (long long)n * a.btab_nstride + (long long)cg * COP * 9;
+    for (int i = tid; i < COP * 9; i += 256) s_bt[i] = bt[i];
+  }
+  __syncthreads();
+  if (lane < COP) {
+    float b3[3] = {0.f, 0.f, 0.f};
+    if (a.btab) {
+#pragma unroll
+      for (int kf = 0; kf < 3; ++kf) {
+        bool ok;
+        if (TR2) {
+          const int q = f + kf - 2;
+          ok = (q >= 0) && !(q & 1) && (q >> 1) < Fin;
+        } else {
+          const int fi = SF * f + kf - a.padf;
+          ok = fi >= 0 && fi < Fin;
+        }
+        if (ok) {
+#pragma unroll
+          for (int kt = 0; kt < 3; ++kt) b3[kt] += s_bt[lane * 9 + kt * 3 + kf];     // table entries are indexed like the weight images: kt * 3 + kf
+        }
+      }
+    }
+    b3[1] += a.bias[cg * COP + lane];
+    reinterpret_cast<float4*>(s_b4)[wave * COP + lane] = make_float4(b3[0], b3[1], b3[2], b3[0] + b3[1] + b3[2]);
+  }
+
+  f32x16 acc[NCO][4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][s][r] = 0.f;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  for (int kc = 0; kc < nchunk; ++kc) {
+    // ---- stage chunk kc: HBM/L2 -> LDS, no registers ----
+#pragma unroll
+    for (int i = 0; i < NXI; ++i) {
+      const int ub = (i * 4 + wave) * 64;                                    // wave-uniform first unit
+      if (ub < XN) {
+        if (ub + 64 <= XN || ub + lane < XN) {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_hi, MN_LDS(s_xhi + ub), 16, xo[i], 0, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_lo, MN_LDS(s_xlo + ub), 16, xo[i], 0, 0, 0);
+        }
+      }
+      xo[i] += xstep;
+    }
+    const unsigned wsoff = (unsigned)kc * (unsigned)(2 * WN) * 16u;
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) {
+      const int ub = (i * 4 + wave) * 64;
+      if (ub < 2 * WN)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, MN_LDS(s_whi + ub), 16, wo + (unsigned)i * 4096u, wsoff, 0, 0);
+    }
+    __syncthreads();                                                         // vmcnt(0) + barrier: images complete
+    if (row_ok && !(a.dbg & 1)) {
+      __builtin_amdgcn_s_setprio(1);
+      if (TR2) {
+        if ((f - f0) & 1) chunk_mfma_bf16<NCO, NR, SF, TR2, 2>(acc, s_xhi, s_xlo, s_whi, s_wlo, f - f0, half, l31);
+        else chunk_mfma_bf16<NCO, NR, SF, TR2, 5>(acc, s_xhi, s_xlo, s_whi, s_wlo, f - f0, half, l31);
+      } else {
+        chunk_mfma_bf16<NCO, NR, SF, TR2, 7>(acc, s_xhi, s_xlo, s_whi, s_wlo, f - f0, half, l31);
+      }
+      __builtin_amdgcn_s_setprio(0);
+    }
+    __syncthreads();                                                         // every wave is done reading the images
+  }
+
+  // ---- epilogue (conv_epilogue.hpp) ----
+  float* s_red = reinterpret_cast<float*>(smem_b);   // [FT][COP][2]
+  if (!(a.dbg & 4))
+    conv_epilogue<NCO, 4, true>(a, acc, n, cg, f, t0, row_ok, lane, s_red + wave * (COP * 2), nullptr,
+                                s_b4 + wave * (COP * 4));
+  if (a.act) {
+    __syncthreads();
+    if (tid < COP * 2) {
+      const int co_l = tid >> 1, which = tid & 1;
+      const int co = cg * COP + co_l;
+      if (co < a.Cout) {
+        float tot = 0.f;
+        for (int w = 0; w < FT; ++w)
+          if (f0 + w < a.Fout) tot += s_red[(w * COP + co_l) * 2 + which];
+        unsafeAtomicAdd(a.out_stats + ((long long)n * a.out_sstride + a.out_c0 + co) * 2 + which, (double)tot);
+      }
+    }
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// conv_wprep_k: fold the instance norm of a layer's input into per-sample weights.
+//   wf   : [ncg][nchunk][9][2][32][8] float32 (LDS image order, zero padded), shared by all samples
+//   wps  : [n][ncg][nchunk][hi|lo][9][2][32][8] bf16   = split(wf * scale[n][ci])
+//   btab : [n][ncg*32][9] float32                     = sum_ci wf[..ci..] * shift[n][ci]   (float64 accumulation)
+// One workgroup of 288 threads per (sample, group); thread p owns (tap, output channel) = (p / 32, p % 32) and walks the
+// input channels in a fixed order, so the table is deterministic.
+__global__ __launch_bounds__(288) void conv_wprep_k(const float* wf, const double* in_stats, int in_sstride, int in_c0,
+                                                    int Cin, int ident_c, int Fin, int T, int nchunk, int ncg,
+                                                    unsigned short* wps, long long wps_nstride_b, float* btab,
+                                                    long long btab_nstride) {
+  extern __shared__ float2 s_nrm[];                  // [nchunk*16] (scale, shift)
+  const int n = blockIdx.x / ncg, cg = blockIdx.x - n * ncg;
+  const int tid = threadIdx.x;
+  for (int c = tid; c < nchunk * CKB; c += 288) {
+    float mean = 0.f, rstd = (c < Cin) ? 1.f : 0.f;
+    if (c >= ident_c && c < Cin) {
+      const double* st = in_stats + ((long long)n * in_sstride + in_c0 + c) * 2;
+      const double cnt = (double)Fin * (double)T;
+      const double m = st[0] / cnt;
+      double var = st[1] / cnt - m * m;
+      var = var > 0.0 ? var : 0.0;
+      mean = (float)m;
+      rstd = (float)(1.0 / sqrt(var + (double)IN_EPS));
+    }
+    s_nrm[c] = make_float2(rstd, -mean * rstd);
+  }
+  __syncthreads();
+  const int tap = tid >> 5, co = tid & 31;
+  const float* wsrc = wf + (long long)cg * nchunk * (9 * 2 * 32 * 8);
+  unsigned short* wdst = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(wps) + (long long)n * wps_nstride_b) +
+                         (long long)cg * nchunk * (2 * 9 * 2 * 32 * 8);
+  double bsum = 0.0;
+  for (int kc = 0; kc < nchunk; ++kc) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int unit = (tap * 2 + h) * 32 + co;
+      const float4* src = reinterpret_cast<const float4*>(wsrc + ((long long)kc * (9 * 2 * 32) + unit) * 8);
+      const float4 w0 = src[0], w1 = src[1];
+      const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+      float ws[8];
+      float bs = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float2 m = s_nrm[kc * CKB + h * 8 + e];
+        ws[e] = wv[e] * m.x;
+        bs = fmaf(wv[e], m.y, bs);
+      }
+      bsum += (double)bs;
+      u32x4_t hi, lo;
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) {
+        unsigned a_, b_;
+        split_pair_t(ws[2 * e2], ws[2 * e2 + 1], a_, b_);
+        hi[e2] = a_; lo[e2] = b_;
+      }
+      u32x4_t* d = reinterpret_cast<u32x4_t*>(wdst + (long long)kc * (2 * 9 * 2 * 32 * 8));
+      d[unit] = hi;
+      d[9 * 2 * 32 + unit] = lo;
+    }
+  }
+  btab[(long long)n * btab_nstride + (long long)(cg * 32 + co) * 9 + tap] = (float)bsum;
+}
+
+static size_t dma_lds_bytes(int NR) {
+  return (size_t)(2 * NR * 2 * TW + 2 * 9 * 2 * 32) * 16 + (size_t)(FT * 32 * 4 + 32 * 9) * sizeof(float);
+}
+
+template <int MODE>
+static hipError_t dma_set_attr() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x3_dma<MODE>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+}
+
+hipError_t conv_bf16_dma_init() {
+  hipError_t e;
+  if ((e = dma_set_attr<0>()) != hipSuccess) return e;
+  if ((e = dma_set_attr<1>()) != hipSuccess) return e;
+  return dma_set_attr<2>();
+}
+
+hipError_t launch_conv_wprep(const ConvArgs& a, const float* wf, int n_samples, hipStream_t s) {
+  const int nchunk = (a.Cin + CKB - 1) / CKB;
+  hipLaunchKernelGGL(conv_wprep_k, dim3(n_samples * a.ncg), dim3(288), (size_t)nchunk * CKB * sizeof(float2), s, wf,
+                     a.in_stats, a.in_sstride, a.in_c0, a.Cin, a.ident_c, a.Fin, a.T, nchunk, a.ncg,
+                     reinterpret_cast<unsigned short*>(const_cast<void*>(a.wps)), a.wps_nstride,
+                     const_cast<float*>(a.btab), a.btab_nstride);
+  return hipGetLastError();
+}
+
+hipError_t launch_conv_bf16_dma(const ConvArgs& a_in, int n_samples, hipStream_t s) {
+  ConvArgs a = a_in;
+  if (!a.in_oct || !a.wps || a.cop != 32 || (a.Cin & 7) || (a.in_c0 & 7) || (a.in_sstride & 7)) return hipErrorInvalidValue;
+  if (a.out_oct && ((a.Cout & 7) || (a.out_c0 & 7) || (a.out_sstride & 7))) return hipErrorInvalidValue;
+  if (a.NR != conv_rows(a.sf, a.tr2)) return hipErrorInvalidValue;
+  {
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("MISONET_WS_DEBUG"); dbg = e ? atoi(e) : 0; }
+    a.dbg = dbg;
+  }
+  const dim3 grid = conv_grid(a, n_samples, TT, FT, conv_xcd_env());
+  const size_t lds = dma_lds_bytes(a.NR);
+  const int mode = a.tr2 ? 2 : (a.sf == 2 ? 1 : 0);
+  if (mode == 0) hipLaunchKernelGGL((conv3x3_bf16x3_dma<0>), grid, dim3(256), lds, s, a);
+  else if (mode == 1) hipLaunchKernelGGL((conv3x3_bf16x3_dma<1>), grid, dim3(256), lds, s, a);
+  else hipLaunchKernelGGL((conv3x3_bf16x3_dma<2>), grid, dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace mn

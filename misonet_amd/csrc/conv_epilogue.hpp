@@ -88,16 +88,137 @@ __device__ __forceinline__ void quad_transpose4(float (&x)[4], int lane) {
   }
 }
 
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+// two values -> packed (hi, hi) and (lo, lo) bf16 pairs (x = hi + lo + O(2^-17 |x|)); element 0 in the low half
+__device__ __forceinline__ void split_pair_t(float x0, float x1, unsigned& hi, unsigned& lo) {
+  f32x2_t x = {x0, x1};
+  const bf16x2_t h = __builtin_convertvector(x, bf16x2_t);
+  const unsigned hu = __builtin_bit_cast(unsigned, h);
+  f32x2_t r;
+  r.x = x0 - __builtin_bit_cast(float, hu << 16);
+  r.y = x1 - __builtin_bit_cast(float, hu & 0xffff0000u);
+  const bf16x2_t l = __builtin_convertvector(r, bf16x2_t);
+  hi = hu;
+  lo = __builtin_bit_cast(unsigned, l);
+}
+
 // s_red: [COP][2] floats of THIS wave's row (the caller adds the rows of a tile).  COP = NCO * 32.
-template <int NCO, int NSEG = 4>
+// s_bias: optional LDS copy of this group's bias [COP].
+// s_b4:   optional LDS table [COP][4] = (bL, bC, bR, bL + bC + bR) of THIS wave's row: the bias plus the folded
+//         instance-norm shift of the DMA dataflow, split by time tap so that the first / last frame of the utterance
+//         (whose left / right taps fall into the zero padding) can drop their share.
+// OCT:    compile the oct-layout output path (a.out_oct selects it at run time).
+template <int NCO, int NSEG = 4, bool OCT = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16_t (&acc)[NCO][NSEG], int n, int cg, int f,
                                               int t0, bool row_ok, int lane, float* s_red,
-                                              const float* s_bias = nullptr) {
+                                              const float* s_bias = nullptr, const float* s_b4 = nullptr) {
   constexpr int COP = NCO * 32;
   const int half = lane >> 5, l31 = lane & 31;
   const int T = a.T, Tp = a.Tp;
-  const unsigned P4 = (unsigned)a.Fout * (unsigned)Tp * 4u;                 // bytes per channel plane
   const int cbase = cg * COP;                                               // first channel of this group
+  bool tm[NSEG];
+#pragma unroll
+  for (int s = 0; s < NSEG; ++s) tm[s] = row_ok && (t0 + s * 32 + l31 < T);
+  const bool all_t = row_ok && (t0 + NSEG * 32 <= T);                       // uniform: every frame of the tile exists
+  const bool full_c = (cbase + COP <= a.Cout);                              // uniform: every channel of the group exists
+  const int cmax = a.Cout - cbase - 4 * half;                               // lane's channel k_r + 32j is valid iff < cmax
+  const bool unmasked = all_t && full_c;
+  const bool t_edge = s_b4 && (t0 == 0 || t0 + NSEG * 32 >= T);             // uniform: tile holds frame 0 or T - 1
+
+  if (OCT && a.out_oct) {
+    // ---- oct layout: per (octet, frame) one 16-byte unit in the hi half and one in the lo half ----
+    const unsigned P16 = (unsigned)a.Fout * (unsigned)Tp * 16u;             // bytes per octet plane
+    const char* ob = reinterpret_cast<const char*>(a.out) + (long long)n * a.out_bstride * 4 +
+                     (long long)(a.out_c0 >> 3) * P16;
+    const unsigned long long pa = reinterpret_cast<unsigned long long>(ob);
+    const unsigned long long pb = pa + (unsigned long long)(a.out_sstride >> 3) * P16;
+    const int nrec = __builtin_amdgcn_readfirstlane((int)((unsigned)(a.Cout >> 3) * P16));
+    // NB: readfirstlane returns int -- go through unsigned temporaries, an int OR-ed into the 64-bit pointer would be
+    // sign-extended and corrupt the high half whenever bit 31 of the low half is set
+    const unsigned pa_lo = __builtin_amdgcn_readfirstlane((unsigned)pa), pa_hi = __builtin_amdgcn_readfirstlane((unsigned)(pa >> 32));
+    const unsigned pb_lo = __builtin_amdgcn_readfirstlane((unsigned)pb), pb_hi = __builtin_amdgcn_readfirstlane((unsigned)(pb >> 32));
+    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void*>(((unsigned long long)pa_hi << 32) | pa_lo), 0, nrec, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void*>(((unsigned long long)pb_hi << 32) | pb_lo), 0, nrec, 0x00020000);
+    unsigned voff[NSEG];
+#pragma unroll
+    for (int s = 0; s < NSEG; ++s)
+      voff[s] = (unsigned)(f * Tp + t0 + s * 32 + l31) * 16u + (unsigned)half * P16;
+#pragma unroll
+    for (int j = 0; j < NCO; ++j) {
+      float bs[16], bl[16], br[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int bi = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (s_b4) {
+          const float4 q = reinterpret_cast<const float4*>(s_b4)[bi];
+          bs[r] = q.w; bl[r] = q.x; br[r] = q.z;
+        } else {
+          bs[r] = s_bias ? s_bias[bi] : a.bias[cbase + bi];
+          bl[r] = 0.f; br[r] = 0.f;
+        }
+      }
+      float s1[16], s2[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < NSEG; ++s) {
+        float v[16];
+        const int t = t0 + s * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float x = acc[j][s][r] + bs[r];
+          if (t_edge) x -= (t == 0 ? bl[r] : 0.f) + (t == T - 1 ? br[r] : 0.f);
+          if (a.act) x = elu_fast(x);
+          v[r] = x;
+          const int kr = j * 32 + (r & 3) + 8 * (r >> 2);
+          const float vm = (unmasked || (tm[s] && (full_c || kr < cmax))) ? x : 0.f;
+          s1[r] += vm;
+          s2[r] = fmaf(vm, vm, s2[r]);
+        }
+        unsigned H[4][2], L[4][2];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          split_pair_t(v[4 * o + 0], v[4 * o + 1], H[o][0], L[o][0]);
+          split_pair_t(v[4 * o + 2], v[4 * o + 3], H[o][1], L[o][1]);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {                 // octet pair (2k, 2k+1): lanes 0-31 store 2k, lanes 32-63 store 2k+1
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            auto rh = __builtin_amdgcn_permlane32_swap(H[2 * k][d], H[2 * k + 1][d], false, false);
+            H[2 * k][d] = rh[0]; H[2 * k + 1][d] = rh[1];
+            auto rl = __builtin_amdgcn_permlane32_swap(L[2 * k][d], L[2 * k + 1][d], false, false);
+            L[2 * k][d] = rl[0]; L[2 * k + 1][d] = rl[1];
+          }
+          const u32x4_t uh = {H[2 * k][0], H[2 * k][1], H[2 * k + 1][0], H[2 * k + 1][1]};
+          const u32x4_t ul = {L[2 * k][0], L[2 * k][1], L[2 * k + 1][0], L[2 * k + 1][1]};
+          // this lane's octet (2k + half of group j) exists and its frame is inside the utterance
+          const bool ook = tm[s] && (cbase + j * 32 + (2 * k + half) * 8 < a.Cout);
+          const unsigned off = voff[s] + (unsigned)((cbase >> 3) + j * 4 + 2 * k) * P16;
+          if (!(a.dbg & 8) && (unmasked || ook)) {
+            __builtin_amdgcn_raw_buffer_store_b128(uh, rs_h, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(ul, rs_l, off, 0, 0);
+          }
+        }
+      }
+      if (a.act && !(a.dbg & 16)) {
+        const float x1 = reduce16_halfwave(s1, lane);
+        const float x2 = reduce16_halfwave(s2, lane);
+        if ((lane & 16) == 0) {
+          const int q = lane & 15;
+          const int co_l = j * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
+          s_red[co_l * 2 + 0] = x1;
+          s_red[co_l * 2 + 1] = x2;
+        }
+      }
+    }
+    return;
+  }
+
+  const unsigned P4 = (unsigned)a.Fout * (unsigned)Tp * 4u;                 // bytes per channel plane
   // ---- descriptor of this sample's output slice [out_c0, out_c0 + Cout) ----
   const float* ob = a.out + (long long)n * a.out_bstride + (long long)a.out_c0 * a.Fout * Tp;
   const unsigned long long pa = reinterpret_cast<unsigned long long>(ob);
@@ -106,28 +227,28 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16_t (&acc)
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
       reinterpret_cast<void*>(((unsigned long long)phi << 32) | plo), 0,
       __builtin_amdgcn_readfirstlane((int)((unsigned)a.Cout * P4)), 0x00020000);
-  // ---- per-lane masks / byte offsets, one per frame tile; an offset is out of range (store dropped) when the frame is
-  // >= T or the row is off ----
-  bool tm[NSEG];
+  // ---- per-lane byte offsets, one per frame tile; an offset is out of range (store dropped) when the frame is >= T or
+  // the row is off ----
   unsigned voff[NSEG];
 #pragma unroll
   for (int s = 0; s < NSEG; ++s) {
     const int t = t0 + s * 32 + l31;
-    tm[s] = row_ok && (t < T);
     voff[s] = tm[s] ? ((unsigned)(f * Tp + t) * 4u + (unsigned)(4 * half) * P4) : 0x80000000u;
   }
-  const bool all_t = row_ok && (t0 + NSEG * 32 <= T);                                  // uniform: every frame of the tile exists
-  const bool full_c = (cbase + COP <= a.Cout);                              // uniform: every channel of the group exists
-  const int cmax = a.Cout - cbase - 4 * half;                               // lane's channel k_r + 32j is valid iff < cmax
-  const bool unmasked = all_t && full_c;
 
 #pragma unroll
   for (int j = 0; j < NCO; ++j) {
-    float bs[16];
+    float bs[16], bl[16], br[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int bi = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      bs[r] = s_bias ? s_bias[bi] : a.bias[cbase + bi];      // LDS copy made at kernel start, or global
+      if (s_b4) {
+        const float4 q = reinterpret_cast<const float4*>(s_b4)[bi];
+        bs[r] = q.w; bl[r] = q.x; br[r] = q.z;
+      } else {
+        bs[r] = s_bias ? s_bias[bi] : a.bias[cbase + bi];      // LDS copy made at kernel start, or global
+        bl[r] = 0.f; br[r] = 0.f;
+      }
     }
     float s1[16], s2[16];
 #pragma unroll
@@ -135,7 +256,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16_t (&acc)
       const int kr = j * 32 + (r & 3) + 8 * (r >> 2);
       const unsigned coff = (unsigned)(cbase + kr) * P4;                      // uniform plane offset
       float a1 = 0.f, a2 = 0.f;
-      if (unmasked) {                                                         // the common case: no masks at all
+      if (unmasked && !t_edge) {                                              // the common case: no masks at all
 #pragma unroll
         for (int s = 0; s < NSEG; ++s) {
           float v = acc[j][s][r] + bs[r];
@@ -148,7 +269,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16_t (&acc)
         const bool cok = full_c || (kr < cmax);
 #pragma unroll
         for (int s = 0; s < NSEG; ++s) {
+          const int t = t0 + s * 32 + l31;
           float v = acc[j][s][r] + bs[r];
+          if (t_edge) v -= (t == 0 ? bl[r] : 0.f) + (t == T - 1 ? br[r] : 0.f);
           if (a.act) v = elu_fast(v);
           if (!(a.dbg & 8)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff[s] + coff, 0, 0);
           const float vm = (tm[s] && cok) ? v : 0.f;

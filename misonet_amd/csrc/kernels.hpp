@@ -44,6 +44,13 @@ struct ConvArgs {
   int NR;                   // staged input rows per workgroup
   int ncg;                  // output-channel groups (grid.z = n_samples * ncg)
   int cop;                  // 32 or 64 output channels per group
+  // "oct" activation layout of the bf16x3 DMA dataflow (conv_bf16_dma.hip): per sample [hi | lo] halves, each
+  // [c/8][f][Tp][8] bf16 (8 channels of one frame = one 16-byte unit), values RAW (bias + ELU, no instance norm).
+  int in_oct, out_oct;      // layout of the input / output buffer: 0 planar float32, 1 oct
+  const void* wps;          // per-sample weights with the instance norm of the input folded in (conv_wprep), LDS image order
+  long long wps_nstride;    // bytes between samples (0: one image shared by all samples)
+  const float* btab;        // [n][ncg*32][9] border-aware shift table: sum_ci W[co][ci][tap] * shift[ci], or nullptr
+  long long btab_nstride;   // floats between samples
   int xcd;                  // 1: 1-D grid with the XCD-aware tile order of conv_tile() (ntx, nty, nsamp valid)
   int ntx, nty, nsamp;      // frame tiles, row tiles, samples of this launch
   unsigned long long* dbg_buf;   // timeline stamps of one workgroup (MISONET_TIMELINE=1, experiments only)
@@ -89,6 +96,9 @@ hipError_t launch_conv(const ConvArgs& a, int n_samples, hipStream_t s);
 hipError_t conv_init();                      // dynamic-LDS attributes
 hipError_t launch_conv_bf16(const ConvArgs& a, int n_samples, hipStream_t s);   // conv_bf16.hip (needs a.w16)
 hipError_t conv_bf16_init();
+hipError_t launch_conv_bf16_dma(const ConvArgs& a, int n_samples, hipStream_t s);   // conv_bf16_dma.hip (oct input)
+hipError_t launch_conv_wprep(const ConvArgs& a, const float* wf, int n_samples, hipStream_t s);
+hipError_t conv_bf16_dma_init();
 hipError_t launch_conv_bf16_r8(const ConvArgs& a, int n_samples, hipStream_t s);   // conv_bf16_r8.hip: stride-1 layers
 hipError_t conv_bf16_r8_init();
 
@@ -115,7 +125,8 @@ hipError_t launch_unpack(const float* src, long long src_bstride, int Tp, int S,
                          int* nan_flag, hipStream_t s);
 // planar view (+ optional instance norm) -> float32 [n][C][T][F]  (diagnostic taps)
 hipError_t launch_export(const float* src, long long src_bstride, int c0, int C, int Fq, int T, int Tp,
-                         const double* stats, int sstride, int ident_c, float* dst, int n_samples, hipStream_t s);
+                         const double* stats, int sstride, int ident_c, float* dst, int n_samples, hipStream_t s,
+                         int oct = 0);   // oct: source in the oct layout (sstride = channels of the whole buffer)
 
 // ---- MVDR + PIT -------------------------------------------------------------------------------------------------
 // Accessor for a multichannel complex STFT with frames contiguous: element (b, f, m, t) =

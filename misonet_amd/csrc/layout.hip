@@ -85,8 +85,10 @@ __global__ __launch_bounds__(256) void unpack_k(const float* src, int Cbuf, int 
   if (nan_flag && bad) atomicOr(nan_flag, 1);
 }
 
+// oct != 0: the source buffer is in the oct layout of the bf16x3 DMA dataflow (kernels.hpp), value = hi + lo
 __global__ __launch_bounds__(256) void export_k(const float* src, long long src_bstride, int c0, int C, int Fq, int T,
-                                                int Tp, const double* stats, int sstride, int ident_c, float* dst) {
+                                                int Tp, const double* stats, int sstride, int ident_c, float* dst,
+                                                int oct) {
   __shared__ float s_v[LFMAX][LT + 1];
   const int t0 = blockIdx.x * LT, c = blockIdx.y, n = blockIdx.z;
   const int tid = threadIdx.x;
@@ -103,8 +105,20 @@ __global__ __launch_bounds__(256) void export_k(const float* src, long long src_
   const float* sp = src + (long long)n * src_bstride + (long long)(c0 + c) * Fq * Tp + t0;
   const int nt = min(LT, T - t0);
   const int tl = tid & 31, fr = tid >> 5;
-  for (int f = fr; f < Fq; f += 8)
-    if (tl < nt) s_v[f][tl] = (sp[(long long)f * Tp + tl] - mean) * rstd;
+  if (oct) {
+    const unsigned short* hb = reinterpret_cast<const unsigned short*>(src + (long long)n * src_bstride);
+    const long long half_e = (long long)(sstride >> 3) * Fq * Tp * 8;       // bf16 elements per half
+    const int ch = c0 + c;
+    for (int f = fr; f < Fq; f += 8)
+      if (tl < nt) {
+        const long long e = (((long long)(ch >> 3) * Fq + f) * Tp + t0 + tl) * 8 + (ch & 7);
+        const float v = __uint_as_float((unsigned)hb[e] << 16) + __uint_as_float((unsigned)hb[half_e + e] << 16);
+        s_v[f][tl] = (v - mean) * rstd;
+      }
+  } else {
+    for (int f = fr; f < Fq; f += 8)
+      if (tl < nt) s_v[f][tl] = (sp[(long long)f * Tp + tl] - mean) * rstd;
+  }
   __syncthreads();
   float* dp = dst + (((long long)n * C + c) * T + t0) * Fq;
   for (int i = tid; i < nt * Fq; i += 256) {
@@ -136,10 +150,11 @@ hipError_t launch_unpack(const float* src, long long src_bstride, int Tp, int S,
 }
 
 hipError_t launch_export(const float* src, long long src_bstride, int c0, int C, int Fq, int T, int Tp,
-                         const double* stats, int sstride, int ident_c, float* dst, int n_samples, hipStream_t s) {
+                         const double* stats, int sstride, int ident_c, float* dst, int n_samples, hipStream_t s,
+                         int oct) {
   if (Fq > LFMAX) return hipErrorInvalidValue;
   hipLaunchKernelGGL(export_k, dim3((T + LT - 1) / LT, C, n_samples), dim3(256), 0, s, src, src_bstride, c0, C, Fq, T,
-                     Tp, stats, sstride, ident_c, dst);
+                     Tp, stats, sstride, ident_c, dst, oct);
   return hipGetLastError();
 }
 

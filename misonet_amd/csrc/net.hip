@@ -90,6 +90,7 @@ struct ConvL {
   int cop, ncg;
   long long w_off = 0, b_off = 0;   // offsets (floats) into the device weight arena
   long long w16_off = 0;            // offset (floats) of the bf16 hi/lo packed weights
+  long long wf_off = 0;             // offset (floats) of the float32 weights in bf16-image order (conv_wprep_k source)
 };
 
 struct TcnHalf { int dw, prelu, gamma, beta, pw; long long o_dw, o_prelu, o_gamma, o_beta, o_pw; };
@@ -104,6 +105,8 @@ struct Layout {
   long long tcn_xs, tcn_ps, tcn_gln;   // doubles: [15][N*128*2], [14][N*128*2], [28][N*2]
   long long stats_doubles;
   long long data_base;           // bytes from ws start to the float arena
+  long long wps_base, wps_nstride;   // bytes: per-sample folded weights of the layer in flight (DMA dataflow)
+  long long btab_base, btab_nstride; // bytes / floats: per-sample border-aware shift table
   long long total_bytes;
 };
 
@@ -292,7 +295,20 @@ static Layout make_layout(const misonet_net* n, int N, int T) {
     L.data_off[b] = d;
     d += align_up((long long)N * n->bufs[b].C * n->bufs[b].F * L.Tp, 64);
   }
-  L.total_bytes = L.data_base + d * 4;
+  long long wmax = 0, cmax = 0;
+  auto scan = [&](const std::vector<ConvL>& v) {
+    for (const ConvL& c : v) {
+      const long long g = (c.Cout + 31) / 32, k = (c.Cin + 15) / 16;
+      wmax = std::max(wmax, g * k * (2LL * 9 * 2 * 32 * 16));
+      cmax = std::max(cmax, g * 32);
+    }
+  };
+  scan(n->enc); scan(n->dec);
+  L.wps_base = align_up(L.data_base + d * 4, 256);
+  L.wps_nstride = wmax;
+  L.btab_base = align_up(L.wps_base + wmax * N, 256);
+  L.btab_nstride = cmax * 9;
+  L.total_bytes = L.btab_base + L.btab_nstride * 4 * N;
   return L;
 }
 
@@ -305,6 +321,13 @@ static inline long long bstride(const misonet_net* n, const Layout& L, int b) {
   return (long long)n->bufs[b].C * n->bufs[b].F * L.Tp;
 }
 
+// precision 2 ("bf16x3" DMA dataflow): the dense-block buffers and everything between them travel in the oct layout;
+// the network input/output, the F <= 3 bottleneck buffers and the TCN stay planar float32.
+static inline bool buf_is_oct(const misonet_net* n, int b) {
+  if (n->precision != 2) return false;
+  return (b >= B_E0 && b <= B_E4) || (b >= B_D2 && b <= B_D6) || (b >= B_X2 && b <= B_X6);
+}
+
 static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL& c, hipStream_t s, int n0 = 0, int nb = -1) {
   ConvArgs a;
   a.in = buf_ptr(L, ws, c.in_buf);
@@ -313,7 +336,7 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
   a.out_stats = stats_ptr(L, ws, c.out_buf);
   a.w = n->w_dev + c.w_off;
   a.bias = n->w_dev + c.b_off;
-  a.w16 = n->precision == 1 ? reinterpret_cast<const unsigned short*>(n->w_dev + c.w16_off) : nullptr;
+  a.w16 = n->precision >= 1 ? reinterpret_cast<const unsigned short*>(n->w_dev + c.w16_off) : nullptr;
   a.in_bstride = bstride(n, L, c.in_buf);
   a.out_bstride = bstride(n, L, c.out_buf);
   a.in_sstride = n->bufs[c.in_buf].C;
@@ -327,12 +350,40 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
   a.dbg = 0;
   a.dbg_buf = nullptr;
   a.xcd = 0; a.ntx = a.nty = a.nsamp = 0;
+  a.in_oct = a.out_oct = 0; a.wps = nullptr; a.wps_nstride = 0; a.btab = nullptr; a.btab_nstride = 0;
   if (nb < 0) nb = L.N;
   a.in += (long long)n0 * a.in_bstride;
   a.out += (long long)n0 * a.out_bstride;
   a.in_stats += (long long)n0 * a.in_sstride * 2;
   a.out_stats += (long long)n0 * a.out_sstride * 2;
   if (a.w16) { a.cop = 32; a.ncg = (c.Cout + 31) / 32; }
+  a.in_oct = buf_is_oct(n, c.in_buf);
+  a.out_oct = buf_is_oct(n, c.out_buf);
+  static int sync_dbg = -1;                 // MISONET_SYNC_DEBUG=1: name every conv launch and wait for it (fault hunting)
+  if (sync_dbg < 0) { const char* e = getenv("MISONET_SYNC_DEBUG"); sync_dbg = e ? atoi(e) : 0; }
+  struct SyncDbg {
+    hipStream_t s; const ConvArgs& a; int on;
+    ~SyncDbg() {
+      if (!on) return;
+      fprintf(stderr, "[conv] Cin=%d Cout=%d Fin=%d Fout=%d T=%d in_oct=%d out_oct=%d mode=%d ... ", a.Cin, a.Cout, a.Fin, a.Fout,
+              a.T, a.in_oct, a.out_oct, a.tr2 ? 2 : (a.sf == 2 ? 1 : 0));
+      const hipError_t e = hipStreamSynchronize(s);
+      fprintf(stderr, "%s\n", hipGetErrorString(e));
+    }
+  } sync_guard{s, a, sync_dbg};
+  if (a.in_oct) {
+    a.wps = reinterpret_cast<char*>(ws) + L.wps_base + (long long)n0 * L.wps_nstride;
+    a.wps_nstride = L.wps_nstride;
+    a.btab = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + L.btab_base) + (long long)n0 * L.btab_nstride;
+    a.btab_nstride = L.btab_nstride;
+    {
+      ProfScope ps(s, PK_OTHER);
+      HIPCHK(launch_conv_wprep(a, n->w_dev + c.wf_off, nb, s));
+    }
+    ProfScope ps(s, PK_CONV);
+    HIPCHK(launch_conv_bf16_dma(a, nb, s));
+    return MISONET_OK;
+  }
   {
     ProfScope ps(s, PK_CONV);
     if (a.w16) HIPCHK(launch_conv_bf16(a, nb, s));
@@ -510,6 +561,7 @@ static void pack_conv_bf16(const misonet_net* n, const ConvL& c, std::vector<flo
   const int COP = 32;                       // the bf16x3 kernels always work on 32-channel output groups
   const int ncg16 = (c.Cout + 31) / 32;
   unsigned short* w = reinterpret_cast<unsigned short*>(arena.data() + c.w16_off);
+  float* wf = arena.data() + c.wf_off;
   const long long img = 9LL * 2 * COP * 8;
   for (int cg = 0; cg < ncg16; ++cg)
     for (int kc = 0; kc < nchunk; ++kc)
@@ -530,6 +582,7 @@ static void pack_conv_bf16(const misonet_net* n, const ConvL& c, std::vector<flo
                 const long long idx = ((((long long)(kt * 3 + kf)) * 2 + h) * COP + col) * 8 + e;
                 w[base + idx] = hi;
                 w[base + img + idx] = lo;
+                wf[((long long)cg * nchunk + kc) * img + idx] = v;
               }
 }
 
@@ -545,6 +598,7 @@ int misonet_net_commit(misonet_net* n) {
       c.w_off = take((long long)c.ncg * nchunk * 9 * CK * c.cop);
       c.b_off = take((long long)c.ncg * c.cop);
       c.w16_off = take((long long)((c.Cout + 31) / 32) * ((c.Cin + 15) / 16) * 2 * 9 * 2 * 32 * 8 / 2);   // u16 -> floats
+      c.wf_off = take((long long)((c.Cout + 31) / 32) * ((c.Cin + 15) / 16) * 9 * 2 * 32 * 8);
     }
   };
   place(n->enc);
@@ -576,13 +630,14 @@ int misonet_net_commit(misonet_net* n) {
   HIPCHK(hipMemcpy(n->w_dev, arena.data(), arena.size() * sizeof(float), hipMemcpyHostToDevice));
   HIPCHK(conv_init());
   HIPCHK(conv_bf16_init());
+  HIPCHK(conv_bf16_dma_init());
   n->committed = true;
   return MISONET_OK;
 }
 
 int misonet_net_set_precision(misonet_net* n, int mode) {
   if (!n) return fail(MISONET_EINVAL, "null argument");
-  if (mode != 0 && mode != 1) return fail(MISONET_EINVAL, "precision mode must be 0 (f32) or 1 (bf16x3)");
+  if (mode < 0 || mode > 2) return fail(MISONET_EINVAL, "precision mode must be 0 (f32), 1 (bf16x3, planar) or 2 (bf16x3, DMA dataflow)");
   n->precision = mode;
   return MISONET_OK;
 }
@@ -645,7 +700,7 @@ int misonet_net_tap(misonet_net* n, const char* name, const void* ws, int B, int
       void* w = const_cast<void*>(ws);
       HIPCHK(launch_export(buf_ptr(L, w, t.buf), bstride(n, L, t.buf), t.c0, t.C, n->bufs[t.buf].F, T, L.Tp,
                            t.normalised ? stats_ptr(L, w, t.buf) : nullptr, n->bufs[t.buf].C, 0, dst, B,
-                           reinterpret_cast<hipStream_t>(stream)));
+                           reinterpret_cast<hipStream_t>(stream), buf_is_oct(n, t.buf) ? 1 : 0));
       return MISONET_OK;
     }
   return fail(MISONET_EINVAL, "unknown tap '%s'", name);

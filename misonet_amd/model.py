@@ -77,7 +77,7 @@ class _Trunk:
         self.training = False
         return self
 
-    PRECISIONS = {"f32": 0, "bf16x3": 1}
+    PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x3d": 2}
 
     def set_precision(self, mode: str):
         """Arithmetic of the 3x3 convolutions: "f32" (exact float32 matrix cores, default) or "bf16x3" (three-term

@@ -10,17 +10,20 @@ from test_gpu_parity import _assert_parity, _utt_inputs, _need_gpu
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def nets_bf(sd1, sd3):
+# "bf16x3": planar float32 activations, normalise-on-load staging (conv_bf16.hip);
+# "bf16x3d": oct-layout activations, instance norm folded into per-sample weights, LDS-DMA staging (conv_bf16_dma.hip)
+@pytest.fixture(scope="module", params=["bf16x3", "bf16x3d"])
+def nets_bf(request, sd1, sd3):
     _need_gpu()
+    PREC = request.param
     import misonet_amd as mz
     from misonet_amd import weights as W
     m1 = mz.MISO_1(2, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN").cuda(0)
     m1.load_state_dict(sd1)
-    m1.eval().set_precision("bf16x3")
+    m1.eval().set_precision(PREC)
     m3 = mz.MISO_3(1, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN").cuda(0)
     m3.load_state_dict(sd3)
-    m3.eval().set_precision("bf16x3")
+    m3.eval().set_precision(PREC)
     return m1, m3
 
 
