@@ -92,7 +92,7 @@ def run_steps(enh, mix, clean, out, steps, warmup, dist, L, _lib, profile):
         enh.enhance(mix, clean, check_nan=False, out=out)
     barrier()
     if profile:
-        _lib.check(L.misonet_profile_begin(steps * 200))
+        _lib.check(L.misonet_profile_begin(steps * 400))
     t0 = time.perf_counter()
     for _ in range(steps):
         enh.enhance(mix, clean, check_nan=False, out=out)

@@ -18,6 +18,7 @@
 #include "conv_epilogue.hpp"
 #include "conv_bf16_core.hpp"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace mn {
@@ -31,10 +32,64 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_u(unsigned long long
                                            __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
 }
 
+// MFMA loop of one K-chunk (16 input channels) with ROW REUSE: wave w owns the 32 frames [t0 + 32w, t0 + 32w + 32) of
+// all four output rows of the tile.  An input fragment B(R, kt) = 16 channels x 32 frames of staged row R, shifted by
+// tap kt, serves every output row f' with f' + kf = R (up to three), and the 18 weight fragments of the chunk stay in
+// registers for the whole chunk.  LDS reads per chunk and wave: 18 (A) + 2 * 3 * NR (B) x 1 KB instead of
+// 18 + 72 with one row per wave -- the one-row mapping ran the LDS at ~100 B/clk/CU of its 128 B/clk, which is what
+// capped the matrix pipe at ~50 % busy.
+template <int NR, int SF, bool TR2>
+__device__ __forceinline__ void chunk_mfma_rows(f32x16 (&acc)[4], const bf16x8* s_xhi, const bf16x8* s_xlo,
+                                                const bf16x8* s_whi, const bf16x8* s_wlo, int wave, int half,
+                                                int l31) {
+  bf16x8 ah[9], al[9];
+  const int wb = half * 32 + l31;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    ah[tap] = s_whi[wb + tap * 64];
+    al[tap] = s_wlo[wb + tap * 64];
+  }
+  const int xb = half * TW + 3 + 32 * wave + l31;        // + R * 2 * TW + kt
+  constexpr int NSTEP = 3 * NR;
+  bf16x8 bh[2], bl[2];
+#pragma unroll
+  for (int st = -1; st < NSTEP; ++st) {
+    if (st + 1 < NSTEP) {
+      const int kt_ = (st + 1) / NR, R_ = (st + 1) % NR;
+      bh[(st + 1) & 1] = s_xhi[xb + R_ * 2 * TW + kt_];
+      bl[(st + 1) & 1] = s_xlo[xb + R_ * 2 * TW + kt_];
+    }
+    __builtin_amdgcn_sched_barrier(0);     // keep the next step's ds_reads AHEAD of this step's MFMAs
+    if (st >= 0) {
+      const int kt = st / NR, R = st % NR;
+      const int cur = st & 1;
+      // three passes (lo x hi, hi x lo, hi x hi) over the output rows fed by this fragment, so consecutive MFMAs hit
+      // different accumulators
+#pragma unroll
+      for (int term = 0; term < 3; ++term) {
+#pragma unroll
+        for (int fr = 0; fr < 4; ++fr) {
+#pragma unroll
+          for (int kf = 0; kf < 3; ++kf) {
+            const bool use = TR2 ? ((((fr + kf) & 1) == 0) && (((fr + kf) >> 1) == R)) : (SF * fr + kf == R);
+            if (use) {
+              const int tap = kt * 3 + kf;
+              if (term == 0) acc[fr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tap], bh[cur], acc[fr], 0, 0, 0);
+              else if (term == 1) acc[fr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tap], bl[cur], acc[fr], 0, 0, 0);
+              else acc[fr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tap], bh[cur], acc[fr], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_dma(const ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (the LDS-DMA builtin has no host form)
-  constexpr int NCO = 1, COP = 32;
+  constexpr int COP = 32;
   constexpr int NR = MODE == 0 ? 6 : (MODE == 1 ? 9 : 3);
   constexpr int SF = MODE == 1 ? 2 : 1;
   constexpr bool TR2 = MODE == 2;
@@ -48,8 +103,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_dma(const ConvArgs a) {
   bf16x8* s_xlo = s_xhi + XN;
   bf16x8* s_whi = s_xlo + XN;                        // hi image followed by lo image (as packed in HBM)
   bf16x8* s_wlo = s_whi + WN;
-  float* s_b4 = reinterpret_cast<float*>(s_wlo + WN);          // [FT][COP][4]
-  float* s_bt = s_b4 + FT * COP * 4;                           // [COP][9]
+  float* s_bs = reinterpret_cast<float*>(s_wlo + WN);          // [FT][2][16]: bias + shift, accumulator order
+  float* s_bl = s_bs + FT * COP;                               // left-tap share
+  float* s_br = s_bl + FT * COP;                               // right-tap share
+  float* s_bt = s_br + FT * COP;                               // [COP][9]
 
   const ConvTile ct = conv_tile(a);
   if (!ct.valid) return;
@@ -88,15 +145,42 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_dma(const ConvArgs a) {
   const unsigned xstep = 2u * P16;                                           // two octets per K-chunk
   const unsigned wo = (unsigned)tid * 16u;
 
-  // ---- bias + folded instance-norm shift of this wave's row: s_b4[wave][co] = (bL, bC, bR, bL + bC + bR) ----
-  const int f = f0 + wave;
-  const bool row_ok = f < a.Fout;
+  // stage chunk KC: HBM/L2 -> LDS, no registers
+#define DMA_STAGE(KC)                                                                                           \
+  {                                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < NXI; ++i) {                                                           \
+      const int ub = (i * 4 + wave) * 64;                                                                       \
+      if (ub < XN) {                                                                                            \
+        if (ub + 64 <= XN || ub + lane < XN) {                                                                  \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_hi, MN_LDS(s_xhi + ub), 16, xo[i], 0, 0, 0);              \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_lo, MN_LDS(s_xlo + ub), 16, xo[i], 0, 0, 0);              \
+        }                                                                                                       \
+      }                                                                                                         \
+      xo[i] += xstep;                                                                                           \
+    }                                                                                                           \
+    const unsigned wsoff_ = (unsigned)(KC) * (unsigned)(2 * WN) * 16u;                                          \
+    _Pragma("unroll") for (int i = 0; i < NWI; ++i) {                                                           \
+      const int ub = (i * 4 + wave) * 64;                                                                       \
+      if (ub < 2 * WN)                                                                                          \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, MN_LDS(s_whi + ub), 16, wo + (unsigned)i * 4096u, wsoff_, 0, 0); \
+    }                                                                                                           \
+  }
+
+  const unsigned long long ts0 = clock64();
+  const bool stamp = a.dbg_buf && tid == 0 && ct.t_tile == 3 && ct.f_tile == 5 && n == 7 && cg == 0;
+  int si = 0;
+#define STAMP() do { if (stamp && si < 60) a.dbg_buf[si++] = clock64() - ts0; } while (0)
+  DMA_STAGE(0)
+  STAMP();
+
+  // ---- bias + folded instance-norm shift per output row (tables of conv_epilogue_rows) ----
   if (a.btab) {
     const float* bt = a.btab + (long long)n * a.btab_nstride + (long long)cg * COP * 9;
     for (int i = tid; i < COP * 9; i += 256) s_bt[i] = bt[i];
   }
   __syncthreads();
   if (lane < COP) {
+    const int f = f0 + wave;
     float b3[3] = {0.f, 0.f, 0.f};
     if (a.btab) {
 #pragma unroll
@@ -116,55 +200,44 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_dma(const ConvArgs a) {
       }
     }
     b3[1] += a.bias[cg * COP + lane];
-    reinterpret_cast<float4*>(s_b4)[wave * COP + lane] = make_float4(b3[0], b3[1], b3[2], b3[0] + b3[1] + b3[2]);
+    // accumulator order: channel co = (i&3) + 8*(i>>2) + 4*h  ->  h = (co>>2)&1, i = (co&3) + 4*(co>>3)
+    const int slot = (wave * 2 + ((lane >> 2) & 1)) * 16 + (lane & 3) + 4 * (lane >> 3);
+    s_bs[slot] = b3[0] + b3[1] + b3[2];
+    s_bl[slot] = b3[0];
+    s_br[slot] = b3[2];
   }
 
-  f32x16 acc[NCO][4];
+  f32x16 acc[4];
 #pragma unroll
-  for (int s = 0; s < 4; ++s)
+  for (int r4 = 0; r4 < 4; ++r4)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][s][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[r4][r] = 0.f;
   const int half = lane >> 5, l31 = lane & 31;
+  const bool wave_live = (t0 + 32 * wave < T);       // this wave's frames exist (ragged last tile)
 
   for (int kc = 0; kc < nchunk; ++kc) {
-    // ---- stage chunk kc: HBM/L2 -> LDS, no registers ----
-#pragma unroll
-    for (int i = 0; i < NXI; ++i) {
-      const int ub = (i * 4 + wave) * 64;                                    // wave-uniform first unit
-      if (ub < XN) {
-        if (ub + 64 <= XN || ub + lane < XN) {
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_hi, MN_LDS(s_xhi + ub), 16, xo[i], 0, 0, 0);
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_lo, MN_LDS(s_xlo + ub), 16, xo[i], 0, 0, 0);
-        }
-      }
-      xo[i] += xstep;
-    }
-    const unsigned wsoff = (unsigned)kc * (unsigned)(2 * WN) * 16u;
-#pragma unroll
-    for (int i = 0; i < NWI; ++i) {
-      const int ub = (i * 4 + wave) * 64;
-      if (ub < 2 * WN)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, MN_LDS(s_whi + ub), 16, wo + (unsigned)i * 4096u, wsoff, 0, 0);
-    }
-    __syncthreads();                                                         // vmcnt(0) + barrier: images complete
-    if (row_ok && !(a.dbg & 1)) {
+    // chunk kc complete (hipcc does not count LDS-DMA loads in its s_waitcnt bookkeeping: wait explicitly)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP();
+    __syncthreads();
+    STAMP();
+    if (wave_live && !(a.dbg & 1)) {
       __builtin_amdgcn_s_setprio(1);
-      if (TR2) {
-        if ((f - f0) & 1) chunk_mfma_bf16<NCO, NR, SF, TR2, 2>(acc, s_xhi, s_xlo, s_whi, s_wlo, f - f0, half, l31);
-        else chunk_mfma_bf16<NCO, NR, SF, TR2, 5>(acc, s_xhi, s_xlo, s_whi, s_wlo, f - f0, half, l31);
-      } else {
-        chunk_mfma_bf16<NCO, NR, SF, TR2, 7>(acc, s_xhi, s_xlo, s_whi, s_wlo, f - f0, half, l31);
-      }
+      chunk_mfma_rows<NR, SF, TR2>(acc, s_xhi, s_xlo, s_whi, s_wlo, wave, half, l31);
       __builtin_amdgcn_s_setprio(0);
     }
-    __syncthreads();                                                         // every wave is done reading the images
+    STAMP();
+    __syncthreads();                                  // every wave is done reading the images
+    STAMP();
+    if (kc + 1 < nchunk) DMA_STAGE(kc + 1)
   }
+#undef DMA_STAGE
+  STAMP();
 
   // ---- epilogue (conv_epilogue.hpp) ----
-  float* s_red = reinterpret_cast<float*>(smem_b);   // [FT][COP][2]
-  if (!(a.dbg & 4))
-    conv_epilogue<NCO, 4, true>(a, acc, n, cg, f, t0, row_ok, lane, s_red + wave * (COP * 2), nullptr,
-                                s_b4 + wave * (COP * 4));
+  float* s_red = reinterpret_cast<float*>(smem_b);   // [4 waves][COP][2]
+  if (!(a.dbg & 4)) conv_epilogue_rows(a, acc, n, cg, f0, t0 + 32 * wave, lane, s_red + wave * (COP * 2), s_bs, s_bl, s_br);
+  STAMP();
   if (a.act) {
     __syncthreads();
     if (tid < COP * 2) {
@@ -172,12 +245,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_dma(const ConvArgs a) {
       const int co = cg * COP + co_l;
       if (co < a.Cout) {
         float tot = 0.f;
-        for (int w = 0; w < FT; ++w)
-          if (f0 + w < a.Fout) tot += s_red[(w * COP + co_l) * 2 + which];
+        for (int w = 0; w < 4; ++w) tot += s_red[(w * COP + co_l) * 2 + which];
         unsafeAtomicAdd(a.out_stats + ((long long)n * a.out_sstride + a.out_c0 + co) * 2 + which, (double)tot);
       }
     }
   }
+  STAMP();
+  if (stamp) a.dbg_buf[63] = si;
+#undef STAMP
 #endif
 }
 
@@ -246,7 +321,7 @@ __global__ __launch_bounds__(288) void conv_wprep_k(const float* wf, const doubl
 }
 
 static size_t dma_lds_bytes(int NR) {
-  return (size_t)(2 * NR * 2 * TW + 2 * 9 * 2 * 32) * 16 + (size_t)(FT * 32 * 4 + 32 * 9) * sizeof(float);
+  return (size_t)(2 * NR * 2 * TW + 2 * 9 * 2 * 32) * 16 + (size_t)(3 * FT * 32 + 32 * 9) * sizeof(float);
 }
 
 template <int MODE>
@@ -284,9 +359,29 @@ hipError_t launch_conv_bf16_dma(const ConvArgs& a_in, int n_samples, hipStream_t
   const dim3 grid = conv_grid(a, n_samples, TT, FT, conv_xcd_env());
   const size_t lds = dma_lds_bytes(a.NR);
   const int mode = a.tr2 ? 2 : (a.sf == 2 ? 1 : 0);
+  // MISONET_TIMELINE=1: clock64() stamps of one workgroup of the first few (Cin = 96, F = 63) launches (experiments only)
+  static int tl_env = -1;
+  static int tl_done = 0;
+  static unsigned long long* tl_buf = nullptr;
+  if (tl_env < 0) { const char* e = getenv("MISONET_TIMELINE"); tl_env = e ? atoi(e) : 0; }
+  const bool do_tl = tl_env && tl_done < 3 && mode == 0 && a.Cin == 96 && a.Fout == 63 && n_samples >= 8;
+  a.dbg_buf = nullptr;
+  if (do_tl) {
+    if (!tl_buf && hipMalloc(reinterpret_cast<void**>(&tl_buf), 64 * 8) != hipSuccess) tl_buf = nullptr;
+    if (tl_buf) { (void)hipMemsetAsync(tl_buf, 0, 64 * 8, s); a.dbg_buf = tl_buf; }
+  }
   if (mode == 0) hipLaunchKernelGGL((conv3x3_bf16x3_dma<0>), grid, dim3(256), lds, s, a);
   else if (mode == 1) hipLaunchKernelGGL((conv3x3_bf16x3_dma<1>), grid, dim3(256), lds, s, a);
   else hipLaunchKernelGGL((conv3x3_bf16x3_dma<2>), grid, dim3(256), lds, s, a);
+  if (do_tl && tl_buf) {
+    unsigned long long h[64];
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h, tl_buf, sizeof(h), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[timeline-dma] Cin=%d Fout=%d n=%d stamps=%llu:", a.Cin, a.Fout, n_samples, h[63]);
+    for (unsigned long long i = 0; i < h[63] && i < 40; ++i) fprintf(stderr, " %llu", h[i]);
+    fprintf(stderr, "\n");
+    ++tl_done;
+  }
   return hipGetLastError();
 }
 

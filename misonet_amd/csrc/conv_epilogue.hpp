@@ -295,4 +295,153 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16_t (&acc)
   }
 }
 
+// Tile epilogue of the row-reuse mapping (conv_bf16_dma.hip): one wave owns 32 frames [tw, tw + 32) of FOUR output rows
+// f0 .. f0 + 3 (acc[r] = 32 channels x 32 frames of row f0 + r).
+//   s_bs / s_bl / s_br: LDS tables [4 rows][2 half-waves][16] in ACCUMULATOR order (entry i of half h = channel
+//   (i&3) + 8*(i>>2) + 4*h): bias + folded instance-norm shift summed over all in-range taps (s_bs), and the shares of
+//   the left / right time tap (s_bl, s_br) that the first / last frame of the utterance must drop (their tap falls into
+//   the zero padding).  A lane reads its 16 values with four 16-byte broadcast reads.
+//   s_red: [32][2] floats of THIS wave (the caller adds the waves of a tile).  Output layout by a.out_oct.
+// Channels >= Cout need no masking in the statistics: their weights and bias are zero-padded, so the value is
+// ELU(0) = 0 exactly.  Everything that depends only on the wave (tile edges) selects between a branch-free fast path
+// and a masked path; nothing is decided per element.
+template <bool MASKED>
+__device__ __forceinline__ void conv_epilogue_rows_impl(const ConvArgs& a, f32x16_t (&acc)[4], int cg, int f0, int tw,
+                                                        int lane, const float* s_bs, const float* s_bl,
+                                                        const float* s_br, const __amdgpu_buffer_rsrc_t rs_h,
+                                                        const __amdgpu_buffer_rsrc_t rs_l, float (&s1)[16],
+                                                        float (&s2)[16]) {
+  constexpr int COP = 32;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int T = a.T, Tp = a.Tp;
+  const int cbase = cg * COP;
+  const int t = tw + l31;
+  const unsigned P16 = (unsigned)a.Fout * (unsigned)Tp * 16u;               // bytes per octet plane (oct)
+  const unsigned P4 = (unsigned)a.Fout * (unsigned)Tp * 4u;                 // bytes per channel plane (planar)
+  const bool oct_ok0 = cbase + (0 + half) * 8 < a.Cout;                      // this lane's octet of pair 0 / 1 exists
+  const bool oct_ok1 = cbase + (2 + half) * 8 < a.Cout;
+  const float e0 = (MASKED && t == 0) ? 1.f : 0.f;                          // drop the left / right tap share
+  const float e1 = (MASKED && t == T - 1) ? 1.f : 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int f = f0 + r;
+    const bool ok = !MASKED || ((f < a.Fout) && (t < T));                   // this lane's (row, frame) exists
+    const float m = ok ? 1.f : 0.f;
+    float bs[16];
+    {
+      const float4* pb = reinterpret_cast<const float4*>(s_bs + (r * 2 + half) * 16);
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const float4 q = pb[q4];
+        bs[4 * q4 + 0] = q.x; bs[4 * q4 + 1] = q.y; bs[4 * q4 + 2] = q.z; bs[4 * q4 + 3] = q.w;
+      }
+      if (MASKED) {
+        const float4* pl = reinterpret_cast<const float4*>(s_bl + (r * 2 + half) * 16);
+        const float4* pr = reinterpret_cast<const float4*>(s_br + (r * 2 + half) * 16);
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const float4 ql = pl[q4], qr = pr[q4];
+          bs[4 * q4 + 0] -= e0 * ql.x + e1 * qr.x; bs[4 * q4 + 1] -= e0 * ql.y + e1 * qr.y;
+          bs[4 * q4 + 2] -= e0 * ql.z + e1 * qr.z; bs[4 * q4 + 3] -= e0 * ql.w + e1 * qr.w;
+        }
+      }
+    }
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float x = acc[r][i] + bs[i];
+      if (a.act) x = elu_fast(x);
+      v[i] = x;
+      const float vm = MASKED ? x * m : x;
+      s1[i] += vm;
+      s2[i] = fmaf(vm, vm, s2[i]);
+    }
+    if (a.dbg & 8) continue;
+    if (a.out_oct) {
+      unsigned H[4][2], L[4][2];
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        split_pair_t(v[4 * o + 0], v[4 * o + 1], H[o][0], L[o][0]);
+        split_pair_t(v[4 * o + 2], v[4 * o + 3], H[o][1], L[o][1]);
+      }
+      const unsigned vo = (unsigned)(f * Tp + t) * 16u + (unsigned)half * P16 + (unsigned)(cbase >> 3) * P16;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {                   // octet pair (2k, 2k+1): lanes 0-31 store 2k, lanes 32-63 store 2k+1
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          auto rh = __builtin_amdgcn_permlane32_swap(H[2 * k][d], H[2 * k + 1][d], false, false);
+          H[2 * k][d] = rh[0]; H[2 * k + 1][d] = rh[1];
+          auto rl = __builtin_amdgcn_permlane32_swap(L[2 * k][d], L[2 * k + 1][d], false, false);
+          L[2 * k][d] = rl[0]; L[2 * k + 1][d] = rl[1];
+        }
+        const u32x4_t uh = {H[2 * k][0], H[2 * k][1], H[2 * k + 1][0], H[2 * k + 1][1]};
+        const u32x4_t ul = {L[2 * k][0], L[2 * k][1], L[2 * k + 1][0], L[2 * k + 1][1]};
+        if (ok && (k == 0 ? oct_ok0 : oct_ok1)) {
+          __builtin_amdgcn_raw_buffer_store_b128(uh, rs_h, vo + (unsigned)(2 * k) * P16, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(ul, rs_l, vo + (unsigned)(2 * k) * P16, 0, 0);
+        }
+      }
+    } else {
+      // planar: channel (i&3) + 8*(i>>2) + 4*half of the group; out-of-range channels fall outside num_records,
+      // missing frames / rows get an out-of-range offset (4-byte stores: dropped by the hardware)
+      const unsigned vo = ok ? ((unsigned)(f * Tp + t) * 4u + (unsigned)(4 * half) * P4) : 0x80000000u;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int kr = (i & 3) + 8 * (i >> 2);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[i]), rs_h, vo + (unsigned)(cbase + kr) * P4, 0, 0);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void conv_epilogue_rows(const ConvArgs& a, f32x16_t (&acc)[4], int n, int cg, int f0, int tw,
+                                                   int lane, float* s_red, const float* s_bs, const float* s_bl,
+                                                   const float* s_br) {
+  const int half = lane >> 5;
+  const int T = a.T, Tp = a.Tp;
+  // uniform per wave: all 32 frames and 4 rows exist and none of the frames is the first / last of the utterance
+  const bool fast = (tw > 0) && (tw + 32 < T) && (f0 + 4 <= a.Fout);
+  float s1[16], s2[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+
+  // descriptors
+  const unsigned P16 = (unsigned)a.Fout * (unsigned)Tp * 16u;
+  const unsigned P4 = (unsigned)a.Fout * (unsigned)Tp * 4u;
+  unsigned long long pa, pb;
+  unsigned nrec;
+  if (a.out_oct) {
+    pa = reinterpret_cast<unsigned long long>(a.out) + (unsigned long long)n * a.out_bstride * 4ull +
+         (unsigned long long)(a.out_c0 >> 3) * P16;
+    pb = pa + (unsigned long long)(a.out_sstride >> 3) * P16;
+    nrec = (unsigned)(a.Cout >> 3) * P16;
+  } else {
+    pa = reinterpret_cast<unsigned long long>(a.out + (long long)n * a.out_bstride + (long long)a.out_c0 * a.Fout * Tp);
+    pb = pa;
+    nrec = (unsigned)a.Cout * P4;
+  }
+  // NB: readfirstlane returns int -- unsigned temporaries, or the OR below sign-extends the low half into the high half
+  const unsigned pa_lo = __builtin_amdgcn_readfirstlane((unsigned)pa), pa_hi = __builtin_amdgcn_readfirstlane((unsigned)(pa >> 32));
+  const unsigned pb_lo = __builtin_amdgcn_readfirstlane((unsigned)pb), pb_hi = __builtin_amdgcn_readfirstlane((unsigned)(pb >> 32));
+  const int nrec_s = __builtin_amdgcn_readfirstlane((int)nrec);
+  const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<void*>(((unsigned long long)pa_hi << 32) | pa_lo), 0, nrec_s, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<void*>(((unsigned long long)pb_hi << 32) | pb_lo), 0, nrec_s, 0x00020000);
+
+  if (fast) conv_epilogue_rows_impl<false>(a, acc, cg, f0, tw, lane, s_bs, s_bl, s_br, rs_h, rs_l, s1, s2);
+  else conv_epilogue_rows_impl<true>(a, acc, cg, f0, tw, lane, s_bs, s_bl, s_br, rs_h, rs_l, s1, s2);
+
+  if (a.act && !(a.dbg & 16)) {
+    const float x1 = reduce16_halfwave(s1, lane);
+    const float x2 = reduce16_halfwave(s2, lane);
+    if ((lane & 16) == 0) {
+      const int q = lane & 15;
+      const int co_l = (q & 3) + 8 * (q >> 2) + 4 * half;
+      s_red[co_l * 2 + 0] = x1;
+      s_red[co_l * 2 + 1] = x2;
+    }
+  }
+}
+
 }  // namespace mn

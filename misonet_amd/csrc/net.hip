@@ -376,10 +376,7 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
     a.wps_nstride = L.wps_nstride;
     a.btab = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + L.btab_base) + (long long)n0 * L.btab_nstride;
     a.btab_nstride = L.btab_nstride;
-    {
-      ProfScope ps(s, PK_OTHER);
-      HIPCHK(launch_conv_wprep(a, n->w_dev + c.wf_off, nb, s));
-    }
+    HIPCHK(launch_conv_wprep(a, n->w_dev + c.wf_off, nb, s));      // not event-timed: part of the step, not of the conv kernel
     ProfScope ps(s, PK_CONV);
     HIPCHK(launch_conv_bf16_dma(a, nb, s));
     return MISONET_OK;
