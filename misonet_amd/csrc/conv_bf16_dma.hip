@@ -38,17 +38,25 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_u(unsigned long long
 // registers for the whole chunk.  LDS reads per chunk and wave: 18 (A) + 2 * 3 * NR (B) x 1 KB instead of
 // 18 + 72 with one row per wave -- the one-row mapping ran the LDS at ~100 B/clk/CU of its 128 B/clk, which is what
 // capped the matrix pipe at ~50 % busy.
-template <int NR, int SF, bool TR2>
-__device__ __forceinline__ void chunk_mfma_rows(f32x16 (&acc)[4], const bf16x8* s_xhi, const bf16x8* s_xlo,
-                                                const bf16x8* s_whi, const bf16x8* s_wlo, int wave, int half,
-                                                int l31) {
-  bf16x8 ah[9], al[9];
+__device__ __forceinline__ void chunk_load_a(bf16x8 (&ah)[9], bf16x8 (&al)[9], const bf16x8* s_whi, const bf16x8* s_wlo,
+                                             int half, int l31) {
   const int wb = half * 32 + l31;
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
     ah[tap] = s_whi[wb + tap * 64];
     al[tap] = s_wlo[wb + tap * 64];
   }
+}
+
+struct NoIssue { __device__ __forceinline__ void operator()(int) const {} };
+
+// `issue(st)` is called once per step, between the step's operand reads and its MFMAs: the software-pipelined kernel
+// uses it to spread the LDS-DMA instructions of the NEXT chunk over the MFMA loop (a burst of 19 DMA instructions
+// costs a wave ~3k cycles of issue time; in the shadow of the matrix pipe it costs nothing).
+template <int NR, int SF, bool TR2, class Issue = NoIssue>
+__device__ __forceinline__ void chunk_mfma_rows_a(f32x16 (&acc)[4], const bf16x8 (&ah)[9], const bf16x8 (&al)[9],
+                                                  const bf16x8* s_xhi, const bf16x8* s_xlo, int wave, int half,
+                                                  int l31, const Issue& issue = Issue()) {
   const int xb = half * TW + 3 + 32 * wave + l31;        // + R * 2 * TW + kt
   constexpr int NSTEP = 3 * NR;
   bf16x8 bh[2], bl[2];
@@ -80,10 +88,20 @@ __device__ __forceinline__ void chunk_mfma_rows(f32x16 (&acc)[4], const bf16x8* 
             }
           }
         }
+        if (term == 0) issue(st);          // behind the first MFMAs of the step: the matrix pipe is busy while these issue
       }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+}
+
+template <int NR, int SF, bool TR2>
+__device__ __forceinline__ void chunk_mfma_rows(f32x16 (&acc)[4], const bf16x8* s_xhi, const bf16x8* s_xlo,
+                                                const bf16x8* s_whi, const bf16x8* s_wlo, int wave, int half,
+                                                int l31) {
+  bf16x8 ah[9], al[9];
+  chunk_load_a(ah, al, s_whi, s_wlo, half, l31);
+  chunk_mfma_rows_a<NR, SF, TR2>(acc, ah, al, s_xhi, s_xlo, wave, half, l31);
 }
 
 template <int MODE>
@@ -257,6 +275,233 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_dma(const ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// conv3x3_bf16x3_dma2: the software-pipelined form of the kernel above (stride-1 and transposed layers).
+//   * ONE persistent workgroup per CU (127 KB of LDS: two input-image buffers, one weight buffer) of 8 waves:
+//     waves 0-3 = CONSUMERS (one per SIMD; MFMAs and the tile epilogue), waves 4-7 = PRODUCERS (one per SIMD; nothing
+//     but LDS-DMA).  A DMA instruction holds its wave until the memory pipeline accepts it (measured: ~130 cycles each
+//     in a burst, ~70 when spread between MFMAs), so it must not come from a wave that feeds the matrix pipe.
+//     Workgroup b belongs to XCD b & 7 and walks that XCD's tile list (conv_tile order) with stride = workgroups per XCD.
+//   * Per K-chunk g: [producers: their DMA of chunk g has landed] -> barrier 1 -> consumers pull the 18 weight fragments
+//     of the chunk into registers -> barrier 2 (weight buffer free; input buffer (g+1)&1 free since barrier 1) ->
+//     producers put chunk g+1 in flight while consumers run the MFMAs of chunk g.
+//   * The last chunk of a tile stages chunk 0 of the NEXT tile, so tile set-up and the first load latency sit behind
+//     the last MFMAs and the epilogue.
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, int nslots) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int COP = 32;
+  constexpr int NR = MODE == 0 ? 6 : 3;
+  constexpr int SF = 1;
+  constexpr bool TR2 = MODE == 2;
+  constexpr int NPAIR = 2 * NR;
+  constexpr int XN = NPAIR * TW;                     // 16-byte units per input image (hi or lo)
+  constexpr int WN = 9 * 2 * COP;                    // 16-byte units per weight image (hi or lo)
+  constexpr int NXI = (XN + 255) / 256;
+  constexpr int NWI = (2 * WN + 255) / 256;
+  extern __shared__ __align__(16) unsigned char smem_b[];
+  bf16x8* s_x = reinterpret_cast<bf16x8*>(smem_b);             // [2 buffers][hi | lo][XN]
+  bf16x8* s_whi = s_x + 4 * XN;
+  bf16x8* s_wlo = s_whi + WN;
+  float* s_bs = reinterpret_cast<float*>(s_wlo + WN);          // [FT][2][16]: bias + shift, accumulator order
+  float* s_bl = s_bs + FT * COP;
+  float* s_br = s_bl + FT * COP;
+  float* s_bt = s_br + FT * COP;                               // [COP][9]
+  float* s_red = s_bt + COP * 9;                               // [4 waves][COP][2]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave >= 4;
+  const int rw = wave & 3;                             // index inside the role
+  const int half = lane >> 5, l31 = lane & 31;
+  const int T = a.T, Tp = a.Tp, Fin = a.Fin, Cin = a.Cin;
+  const int nchunk = (Cin + CKB - 1) / CKB;
+  const unsigned P16 = (unsigned)Fin * (unsigned)Tp * 16u;
+  const unsigned in_rec = (unsigned)((a.in_c0 + Cin) >> 3) * P16;
+  const unsigned wbytes = (unsigned)nchunk * (unsigned)(2 * WN) * 16u;
+  const unsigned xstep = 2u * P16;
+  const unsigned wo = (unsigned)(tid & 255) * 16u;
+
+  const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+  const unsigned per = (unsigned)(a.ntx * a.nty * a.ncg);                    // tiles per sample
+  const unsigned nk = (unsigned)((a.nsamp + 7 - (int)xcd) / 8) * per;        // tiles of this XCD's samples (n % 8 == xcd)
+  unsigned k = slot;
+  if (k >= nk) return;
+
+  int t0, f0, n, cg, fin0;
+  __amdgpu_buffer_rsrc_t rs_hi, rs_lo, rs_w;
+  unsigned xo[NXI];
+
+#define TILE_SETUP(K)                                                                                           \
+  {                                                                                                             \
+    const unsigned grp_ = (K) / per;                                                                            \
+    unsigned tile_ = (K) - grp_ * per;                                                                          \
+    n = (int)(grp_ * 8u + xcd);                                                                                 \
+    t0 = (int)(tile_ % (unsigned)a.ntx) * TT;                                                                   \
+    tile_ /= (unsigned)a.ntx;                                                                                   \
+    cg = (int)(tile_ % (unsigned)a.ncg);                                                                        \
+    f0 = (int)(tile_ / (unsigned)a.ncg) * FT;                                                                   \
+    fin0 = TR2 ? (f0 >> 1) - 1 : SF * f0 - a.padf;                                                              \
+    if (producer) {                                                                                             \
+      const unsigned long long in_b_ =                                                                          \
+          reinterpret_cast<unsigned long long>(a.in) + (unsigned long long)n * a.in_bstride * 4ull;             \
+      rs_hi = make_rsrc_u(in_b_, in_rec);                                                                       \
+      rs_lo = make_rsrc_u(in_b_ + (unsigned long long)(a.in_sstride >> 3) * P16, in_rec);                       \
+      rs_w = make_rsrc_u(reinterpret_cast<unsigned long long>(a.wps) + (unsigned long long)n * a.wps_nstride +  \
+                             (unsigned long long)cg * wbytes, wbytes);                                          \
+      _Pragma("unroll") for (int i = 0; i < NXI; ++i) {                                                         \
+        const int u = (i * 4 + rw) * 64 + lane;                                                                 \
+        const int p = u / TW, j = u - p * TW;                                                                   \
+        const int fin = fin0 + (p >> 1);                                                                        \
+        const int t = t0 - 4 + j;                                                                               \
+        const bool ok = u < XN && fin >= 0 && fin < Fin && t >= 0 && t < T && j >= 3 && j <= TT + 4;            \
+        xo[i] = ok ? ((unsigned)(((a.in_c0 >> 3) + (p & 1)) * Fin + fin) * (unsigned)Tp + (unsigned)t) * 16u    \
+                   : 0x80000000u;                                                                               \
+      }                                                                                                         \
+    }                                                                                                           \
+  }
+
+  // producers: chunk KC of the current tile -> input buffer XB (0 / 1) and the weight buffer
+#define DMA_STAGE(KC, XB)                                                                                       \
+  {                                                                                                             \
+    bf16x8* sxh_ = s_x + (XB) * 2 * XN;                                                                         \
+    _Pragma("unroll") for (int i = 0; i < NXI; ++i) {                                                           \
+      const int ub = (i * 4 + rw) * 64;                                                                         \
+      if (ub < XN) {                                                                                            \
+        if (ub + 64 <= XN || ub + lane < XN) {                                                                  \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_hi, MN_LDS(sxh_ + ub), 16, xo[i], 0, 0, 0);               \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_lo, MN_LDS(sxh_ + XN + ub), 16, xo[i], 0, 0, 0);          \
+        }                                                                                                       \
+      }                                                                                                         \
+      xo[i] += xstep;                                                                                           \
+    }                                                                                                           \
+    const unsigned wsoff_ = (unsigned)(KC) * (unsigned)(2 * WN) * 16u;                                          \
+    _Pragma("unroll") for (int i = 0; i < NWI; ++i) {                                                           \
+      const int ub = (i * 4 + rw) * 64;                                                                         \
+      if (ub < 2 * WN)                                                                                          \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, MN_LDS(s_whi + ub), 16, wo + (unsigned)i * 4096u, wsoff_, 0, 0); \
+    }                                                                                                           \
+  }
+
+  // all waves (two barriers inside)
+#define TILE_TABLES()                                                                                           \
+  {                                                                                                             \
+    if (a.btab) {                                                                                               \
+      const float* bt_ = a.btab + (long long)n * a.btab_nstride + (long long)cg * COP * 9;                      \
+      for (int i = tid; i < COP * 9; i += 512) s_bt[i] = bt_[i];                                                \
+    }                                                                                                           \
+    __syncthreads();                                                                                            \
+    if (!producer && lane < COP) {                                                                              \
+      const int f_ = f0 + wave;                                                                                 \
+      float b3[3] = {0.f, 0.f, 0.f};                                                                            \
+      if (a.btab) {                                                                                             \
+        _Pragma("unroll") for (int kf = 0; kf < 3; ++kf) {                                                      \
+          bool ok_;                                                                                             \
+          if (TR2) {                                                                                            \
+            const int q_ = f_ + kf - 2;                                                                         \
+            ok_ = (q_ >= 0) && !(q_ & 1) && (q_ >> 1) < Fin;                                                    \
+          } else {                                                                                              \
+            const int fi_ = SF * f_ + kf - a.padf;                                                              \
+            ok_ = fi_ >= 0 && fi_ < Fin;                                                                        \
+          }                                                                                                     \
+          if (ok_) {                                                                                            \
+            _Pragma("unroll") for (int kt = 0; kt < 3; ++kt) b3[kt] += s_bt[lane * 9 + kt * 3 + kf];            \
+          }                                                                                                     \
+        }                                                                                                       \
+      }                                                                                                         \
+      b3[1] += a.bias[cg * COP + lane];                                                                         \
+      const int slot_ = (wave * 2 + ((lane >> 2) & 1)) * 16 + (lane & 3) + 4 * (lane >> 3);                     \
+      s_bs[slot_] = b3[0] + b3[1] + b3[2];                                                                      \
+      s_bl[slot_] = b3[0];                                                                                      \
+      s_br[slot_] = b3[2];                                                                                      \
+    }                                                                                                           \
+  }
+
+  const unsigned long long ts0 = clock64();
+  int si = 0;
+  bool stamp = false;
+#define STAMP() do { if (stamp && si < 60) a.dbg_buf[si++] = clock64() - ts0; } while (0)
+
+  unsigned g = 0;                                      // running chunk counter: chunk g lives in input buffer g & 1
+  int tcount = 0;
+  TILE_SETUP(k)
+  if (producer) DMA_STAGE(0, 0)
+  TILE_TABLES()
+
+  for (;;) {
+    stamp = a.dbg_buf && tid == 0 && t0 == 3 * TT && f0 == 5 * FT && n == 7 && cg == 0;
+    if (stamp) { si = 0; a.dbg_buf[62] = clock64() - ts0; }
+    if (a.dbg_buf && tid == 0 && blockIdx.x == 8 && tcount < 10) { a.dbg_buf[40 + tcount] = wall_clock64(); a.dbg_buf[50 + tcount] = clock64(); ++tcount; }
+    f32x16 acc[4];
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r4][r] = 0.f;
+    const bool wave_live = !producer && (t0 + 32 * wave < T);   // this consumer's frames exist (ragged last tile)
+    const int e_n = n, e_cg = cg, e_f0 = f0, e_t0 = t0;
+    bool more = false;
+
+    for (int kc = 0; kc < nchunk; ++kc, ++g) {
+      // producers: the images of chunk g have landed (hipcc does not count LDS-DMA loads: wait explicitly).  Behind
+      // barrier 1 every consumer has also finished the MFMAs of chunk g - 1, i.e. input buffer (g + 1) & 1 is free.
+      if (producer) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      STAMP();
+      __syncthreads();                                 // barrier 1
+      STAMP();
+      bf16x8 ah[9], al[9];
+      if (!producer) {
+        chunk_load_a(ah, al, s_whi, s_wlo, half, l31);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      __syncthreads();                                 // barrier 2: weight buffer free
+      STAMP();
+      int next_kc = kc + 1;
+      bool do_dma = true;
+      if (kc + 1 == nchunk) {                          // stage chunk 0 of the next tile
+        k += (unsigned)nslots;
+        more = k < nk;
+        do_dma = more;
+        next_kc = 0;
+        if (more) TILE_SETUP(k)
+      }
+      if (producer) {
+        if (do_dma) DMA_STAGE(next_kc, (g + 1) & 1)
+      } else if (wave_live && !(a.dbg & 1)) {
+        const bf16x8* sx = s_x + (g & 1) * 2 * XN;
+        __builtin_amdgcn_s_setprio(1);
+        chunk_mfma_rows_a<NR, SF, TR2>(acc, ah, al, sx, sx + XN, wave, half, l31);
+        __builtin_amdgcn_s_setprio(0);
+      }
+      STAMP();
+    }
+
+    // ---- epilogue of the finished tile (conv_epilogue.hpp); chunk 0 of the next tile is already in flight ----
+    if (!producer && !(a.dbg & 4))
+      conv_epilogue_rows(a, acc, e_n, e_cg, e_f0, e_t0 + 32 * wave, lane, s_red + wave * (COP * 2), s_bs, s_bl, s_br);
+    STAMP();
+    __syncthreads();                                   // s_red complete; the tables of the finished tile are free
+    if (a.act && tid < COP * 2) {
+      const int co_l = tid >> 1, which = tid & 1;
+      const int co = e_cg * COP + co_l;
+      if (co < a.Cout) {
+        float tot = 0.f;
+        for (int w = 0; w < 4; ++w) tot += s_red[(w * COP + co_l) * 2 + which];
+        unsafeAtomicAdd(a.out_stats + ((long long)e_n * a.out_sstride + a.out_c0 + co) * 2 + which, (double)tot);
+      }
+    }
+    STAMP();
+    if (stamp) a.dbg_buf[63] = si;
+    if (!more) break;
+    TILE_TABLES()
+  }
+#undef STAMP
+#undef TILE_SETUP
+#undef TILE_TABLES
+#undef DMA_STAGE
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // conv_wprep_k: fold the instance norm of a layer's input into per-sample weights.
 //   wf   : [ncg][nchunk][9][2][32][8] float32 (LDS image order, zero padded), shared by all samples
 //   wps  : [n][ncg][nchunk][hi|lo][9][2][32][8] bf16   = split(wf * scale[n][ci])
@@ -320,6 +565,10 @@ __global__ __launch_bounds__(288) void conv_wprep_k(const float* wf, const doubl
   btab[(long long)n * btab_nstride + (long long)(cg * 32 + co) * 9 + tap] = (float)bsum;
 }
 
+static size_t dma2_lds_bytes(int NR) {
+  return (size_t)(2 * 2 * NR * 2 * TW + 2 * 9 * 2 * 32) * 16 + (size_t)(3 * FT * 32 + 32 * 9 + 4 * 32 * 2) * sizeof(float);
+}
+
 static size_t dma_lds_bytes(int NR) {
   return (size_t)(2 * NR * 2 * TW + 2 * 9 * 2 * 32) * 16 + (size_t)(3 * FT * 32 + 32 * 9) * sizeof(float);
 }
@@ -334,7 +583,11 @@ hipError_t conv_bf16_dma_init() {
   hipError_t e;
   if ((e = dma_set_attr<0>()) != hipSuccess) return e;
   if ((e = dma_set_attr<1>()) != hipSuccess) return e;
-  return dma_set_attr<2>();
+  if ((e = dma_set_attr<2>()) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x3_dma2<0>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x3_dma2<2>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 hipError_t launch_conv_wprep(const ConvArgs& a, const float* wf, int n_samples, hipStream_t s) {
@@ -357,7 +610,12 @@ hipError_t launch_conv_bf16_dma(const ConvArgs& a_in, int n_samples, hipStream_t
     a.dbg = dbg;
   }
   const dim3 grid = conv_grid(a, n_samples, TT, FT, conv_xcd_env());
-  const size_t lds = dma_lds_bytes(a.NR);
+  size_t lds = dma_lds_bytes(a.NR);
+  {
+    static int pad = -1;                          // MISONET_DMA_ONE=1: pad the LDS request so only ONE workgroup fits a CU (experiments)
+    if (pad < 0) { const char* e = getenv("MISONET_DMA_ONE"); pad = e ? atoi(e) : 0; }
+    if (pad && lds < 100 * 1024) lds = 100 * 1024;
+  }
   const int mode = a.tr2 ? 2 : (a.sf == 2 ? 1 : 0);
   // MISONET_TIMELINE=1: clock64() stamps of one workgroup of the first few (Cin = 96, F = 63) launches (experiments only)
   static int tl_env = -1;
@@ -370,7 +628,26 @@ hipError_t launch_conv_bf16_dma(const ConvArgs& a_in, int n_samples, hipStream_t
     if (!tl_buf && hipMalloc(reinterpret_cast<void**>(&tl_buf), 64 * 8) != hipSuccess) tl_buf = nullptr;
     if (tl_buf) { (void)hipMemsetAsync(tl_buf, 0, 64 * 8, s); a.dbg_buf = tl_buf; }
   }
-  if (mode == 0) hipLaunchKernelGGL((conv3x3_bf16x3_dma<0>), grid, dim3(256), lds, s, a);
+  static int dma2_env = -1;
+  if (dma2_env < 0) { const char* e = getenv("MISONET_DMA2"); dma2_env = e ? atoi(e) : 1; }
+  if (dma2_env && mode != 1) {
+    // persistent launch: one workgroup per CU, capped by the largest per-XCD tile list
+    static int g_cus = 0;
+    if (!g_cus) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+      g_cus = prop.multiProcessorCount;
+    }
+    const long long nk_max = (long long)((n_samples + 7) / 8) * a.ntx * a.nty * a.ncg;
+    int nslots = g_cus / 8;
+    if (nslots < 1) nslots = 1;
+    if (nslots > nk_max) nslots = (int)nk_max;
+    const dim3 pgrid((unsigned)(8 * nslots), 1, 1);
+    const size_t lds2 = dma2_lds_bytes(a.NR);
+    if (mode == 0) hipLaunchKernelGGL((conv3x3_bf16x3_dma2<0>), pgrid, dim3(512), lds2, s, a, nslots);
+    else hipLaunchKernelGGL((conv3x3_bf16x3_dma2<2>), pgrid, dim3(512), lds2, s, a, nslots);
+  } else if (mode == 0) hipLaunchKernelGGL((conv3x3_bf16x3_dma<0>), grid, dim3(256), lds, s, a);
   else if (mode == 1) hipLaunchKernelGGL((conv3x3_bf16x3_dma<1>), grid, dim3(256), lds, s, a);
   else hipLaunchKernelGGL((conv3x3_bf16x3_dma<2>), grid, dim3(256), lds, s, a);
   if (do_tl && tl_buf) {
@@ -379,6 +656,8 @@ hipError_t launch_conv_bf16_dma(const ConvArgs& a_in, int n_samples, hipStream_t
     (void)hipMemcpy(h, tl_buf, sizeof(h), hipMemcpyDeviceToHost);
     fprintf(stderr, "[timeline-dma] Cin=%d Fout=%d n=%d stamps=%llu:", a.Cin, a.Fout, n_samples, h[63]);
     for (unsigned long long i = 0; i < h[63] && i < 40; ++i) fprintf(stderr, " %llu", h[i]);
+    fprintf(stderr, " | tile starts (100 MHz wall clock, deltas):");
+    for (int i = 41; i < 50 && h[i]; ++i) fprintf(stderr, " %llu/%llu", h[i] - h[i - 1], h[i + 10] - h[i + 9]);
     fprintf(stderr, "\n");
     ++tl_done;
   }
