@@ -122,7 +122,7 @@ def roofline_objects(precision, B, T, steps, dt_conv_ms, n_launch, value_per_gpu
         traffic, busy = tj["bytes_per_launch"], tj.get("mfma_busy_frac")
     except Exception:
         pass
-    common = {"kernel": "conv3x3_mfma" if precision == "f32" else "conv3x3_bf16x3",
+    common = {"kernel": {"f32": "conv3x3_mfma", "bf16x3": "conv3x3_bf16x3_dma2", "bf16x3p": "conv3x3_bf16x3"}[precision],
               "launches_per_step": int(n_launch // steps), "avg_launch_ms": round(dt_conv_ms / max(n_launch, 1), 4),
               "algorithmic_gflop_per_launch": round(flops_step * steps / max(n_launch, 1) / 1e9, 2),
               "algorithmic_gbyte_per_launch": round(bytes_step * steps / max(n_launch, 1) / 1e9, 3),
@@ -150,7 +150,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=16, help="utterances per GPU per step (BASELINE configs[3]: 16)")
     ap.add_argument("--frames", type=int, default=1001)
-    ap.add_argument("--precision", choices=["f32", "bf16x3", "bf16x3d"], default="bf16x3",
+    ap.add_argument("--precision", choices=["f32", "bf16x3", "bf16x3p"], default="bf16x3",
                     help="arithmetic of the 3x3 convs: exact f32 MFMA, or 3-term bf16 split on the bf16 MFMA (default)")
     ap.add_argument("--no-alt", action="store_true", help="skip the short run of the other precision mode (N = 1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -219,7 +219,7 @@ def main():
             roof["hbm_frac_pipeline"] = round(ALGO_BYTES_PER_UTT * (value / world) / (PEAK_HBM_TBS * 1e12), 4)
         alt = None
         if world == 1 and not args.no_alt and profile:
-            other = "f32" if args.precision == "bf16x3" else "bf16x3"
+            other = "f32" if args.precision != "f32" else "bf16x3"
             m1.set_precision(other)
             m3.set_precision(other)
             k = max(2, min(3, args.steps))

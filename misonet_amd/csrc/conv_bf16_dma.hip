@@ -274,18 +274,69 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_dma(const ConvArgs a) {
 #endif
 }
 
+// MFMA loop of one K-chunk with row reuse, weight fragments read from LDS one time tap ahead (the weight image stays
+// valid for the whole chunk in the fully double-buffered kernel, so only 2 x 6 fragments are live instead of 18).
+template <int NR, int SF, bool TR2>
+__device__ __forceinline__ void chunk_mfma_rows_w(f32x16 (&acc)[4], const bf16x8* s_xhi, const bf16x8* s_xlo,
+                                                  const bf16x8* s_whi, const bf16x8* s_wlo, int wave, int half,
+                                                  int l31) {
+  const int wb = half * 32 + l31;                        // + tap * 64
+  const int xb = half * TW + 3 + 32 * wave + l31;        // + R * 2 * TW + kt
+  constexpr int NSTEP = 3 * NR;
+  bf16x8 ah[2][3], al[2][3], bh[2], bl[2];
+#pragma unroll
+  for (int kf = 0; kf < 3; ++kf) { ah[0][kf] = s_whi[wb + kf * 64]; al[0][kf] = s_wlo[wb + kf * 64]; }
+#pragma unroll
+  for (int st = -1; st < NSTEP; ++st) {
+    if (st + 1 < NSTEP) {
+      const int kt_ = (st + 1) / NR, R_ = (st + 1) % NR;
+      bh[(st + 1) & 1] = s_xhi[xb + R_ * 2 * TW + kt_];
+      bl[(st + 1) & 1] = s_xlo[xb + R_ * 2 * TW + kt_];
+      if (R_ == 1 && kt_ < 2) {                          // next time tap's weights, one tap group ahead
+#pragma unroll
+        for (int kf = 0; kf < 3; ++kf) {
+          ah[(kt_ + 1) & 1][kf] = s_whi[wb + ((kt_ + 1) * 3 + kf) * 64];
+          al[(kt_ + 1) & 1][kf] = s_wlo[wb + ((kt_ + 1) * 3 + kf) * 64];
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);     // keep the next step's ds_reads AHEAD of this step's MFMAs
+    if (st >= 0) {
+      const int kt = st / NR, R = st % NR;
+      const int cur = st & 1;
+#pragma unroll
+      for (int term = 0; term < 3; ++term) {
+#pragma unroll
+        for (int fr = 0; fr < 4; ++fr) {
+#pragma unroll
+          for (int kf = 0; kf < 3; ++kf) {
+            const bool use = TR2 ? ((((fr + kf) & 1) == 0) && (((fr + kf) >> 1) == R)) : (SF * fr + kf == R);
+            if (use) {
+              if (term == 0) acc[fr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[kt & 1][kf], bh[cur], acc[fr], 0, 0, 0);
+              else if (term == 1) acc[fr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kt & 1][kf], bl[cur], acc[fr], 0, 0, 0);
+              else acc[fr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kt & 1][kf], bh[cur], acc[fr], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // conv3x3_bf16x3_dma2: the software-pipelined form of the kernel above (stride-1 and transposed layers).
-//   * ONE persistent workgroup per CU (127 KB of LDS: two input-image buffers, one weight buffer) of 8 waves:
-//     waves 0-3 = CONSUMERS (one per SIMD; MFMAs and the tile epilogue), waves 4-7 = PRODUCERS (one per SIMD; nothing
-//     but LDS-DMA).  A DMA instruction holds its wave until the memory pipeline accepts it (measured: ~130 cycles each
-//     in a burst, ~70 when spread between MFMAs), so it must not come from a wave that feeds the matrix pipe.
-//     Workgroup b belongs to XCD b & 7 and walks that XCD's tile list (conv_tile order) with stride = workgroups per XCD.
-//   * Per K-chunk g: [producers: their DMA of chunk g has landed] -> barrier 1 -> consumers pull the 18 weight fragments
-//     of the chunk into registers -> barrier 2 (weight buffer free; input buffer (g+1)&1 free since barrier 1) ->
-//     producers put chunk g+1 in flight while consumers run the MFMAs of chunk g.
-//   * The last chunk of a tile stages chunk 0 of the NEXT tile, so tile set-up and the first load latency sit behind
-//     the last MFMAs and the epilogue.
+//   * ONE persistent workgroup per CU, 8 waves, 148 KB of LDS = two complete stages (input images + weight images of one
+//     K-chunk each) + two sets of epilogue tables.  Workgroup b belongs to XCD b & 7 and walks that XCD's tile list
+//     (conv_tile order) with stride = workgroups per XCD.
+//   * waves 0-3 = CONSUMERS (one per SIMD): MFMAs and the tile epilogue, nothing else.
+//     waves 4-7 = PRODUCERS (one per SIMD): LDS-DMA of the next chunk, the epilogue tables of the next tile, the float64
+//     statistics atomics of the previous tile.  A DMA instruction holds its wave until the memory pipeline accepts it
+//     (measured ~130 cycles each in a burst), so it must not come from a wave that feeds the matrix pipe.
+//   * ONE workgroup barrier per K-chunk g: producers arrive when the DMA of chunk g has landed, consumers when the MFMAs
+//     of chunk g - 1 are done (stage (g+1)&1 free).  Behind it producers put chunk g + 1 in flight while consumers run
+//     the MFMAs of chunk g.  Chunks are numbered across tiles: the last chunk of a tile stages chunk 0 of the next one,
+//     so tile set-up and the first load latency hide behind the last MFMAs and the epilogue.
 template <int MODE>
 __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, int nslots) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -296,17 +347,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
   constexpr int NPAIR = 2 * NR;
   constexpr int XN = NPAIR * TW;                     // 16-byte units per input image (hi or lo)
   constexpr int WN = 9 * 2 * COP;                    // 16-byte units per weight image (hi or lo)
+  constexpr int SN = 2 * XN + 2 * WN;                // units per stage: [x hi | x lo | w hi | w lo]
   constexpr int NXI = (XN + 255) / 256;
   constexpr int NWI = (2 * WN + 255) / 256;
   extern __shared__ __align__(16) unsigned char smem_b[];
-  bf16x8* s_x = reinterpret_cast<bf16x8*>(smem_b);             // [2 buffers][hi | lo][XN]
-  bf16x8* s_whi = s_x + 4 * XN;
-  bf16x8* s_wlo = s_whi + WN;
-  float* s_bs = reinterpret_cast<float*>(s_wlo + WN);          // [FT][2][16]: bias + shift, accumulator order
-  float* s_bl = s_bs + FT * COP;
-  float* s_br = s_bl + FT * COP;
-  float* s_bt = s_br + FT * COP;                               // [COP][9]
-  float* s_red = s_bt + COP * 9;                               // [4 waves][COP][2]
+  bf16x8* s_stage = reinterpret_cast<bf16x8*>(smem_b);         // [2][SN]
+  float* s_tab = reinterpret_cast<float*>(s_stage + 2 * SN);   // [2 sets][bs | bl | br][FT][2][16]
+  float* s_red = s_tab + 2 * 3 * FT * COP;                     // [2 sets][4 waves][COP][2]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -316,11 +363,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
   const int half = lane >> 5, l31 = lane & 31;
   const int T = a.T, Tp = a.Tp, Fin = a.Fin, Cin = a.Cin;
   const int nchunk = (Cin + CKB - 1) / CKB;
-  const unsigned P16 = (unsigned)Fin * (unsigned)Tp * 16u;
-  const unsigned in_rec = (unsigned)((a.in_c0 + Cin) >> 3) * P16;
-  const unsigned wbytes = (unsigned)nchunk * (unsigned)(2 * WN) * 16u;
-  const unsigned xstep = 2u * P16;
-  const unsigned wo = (unsigned)(tid & 255) * 16u;
 
   const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
   const unsigned per = (unsigned)(a.ntx * a.nty * a.ncg);                    // tiles per sample
@@ -328,11 +370,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
   unsigned k = slot;
   if (k >= nk) return;
 
-  int t0, f0, n, cg, fin0;
-  __amdgpu_buffer_rsrc_t rs_hi, rs_lo, rs_w;
-  unsigned xo[NXI];
-
-#define TILE_SETUP(K)                                                                                           \
+  int t0, f0, n, cg;
+#define TILE_COORDS(K)                                                                                          \
   {                                                                                                             \
     const unsigned grp_ = (K) / per;                                                                            \
     unsigned tile_ = (K) - grp_ * per;                                                                          \
@@ -341,36 +380,48 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
     tile_ /= (unsigned)a.ntx;                                                                                   \
     cg = (int)(tile_ % (unsigned)a.ncg);                                                                        \
     f0 = (int)(tile_ / (unsigned)a.ncg) * FT;                                                                   \
-    fin0 = TR2 ? (f0 >> 1) - 1 : SF * f0 - a.padf;                                                              \
-    if (producer) {                                                                                             \
-      const unsigned long long in_b_ =                                                                          \
-          reinterpret_cast<unsigned long long>(a.in) + (unsigned long long)n * a.in_bstride * 4ull;             \
-      rs_hi = make_rsrc_u(in_b_, in_rec);                                                                       \
-      rs_lo = make_rsrc_u(in_b_ + (unsigned long long)(a.in_sstride >> 3) * P16, in_rec);                       \
-      rs_w = make_rsrc_u(reinterpret_cast<unsigned long long>(a.wps) + (unsigned long long)n * a.wps_nstride +  \
-                             (unsigned long long)cg * wbytes, wbytes);                                          \
-      _Pragma("unroll") for (int i = 0; i < NXI; ++i) {                                                         \
-        const int u = (i * 4 + rw) * 64 + lane;                                                                 \
-        const int p = u / TW, j = u - p * TW;                                                                   \
-        const int fin = fin0 + (p >> 1);                                                                        \
-        const int t = t0 - 4 + j;                                                                               \
-        const bool ok = u < XN && fin >= 0 && fin < Fin && t >= 0 && t < T && j >= 3 && j <= TT + 4;            \
-        xo[i] = ok ? ((unsigned)(((a.in_c0 >> 3) + (p & 1)) * Fin + fin) * (unsigned)Tp + (unsigned)t) * 16u    \
-                   : 0x80000000u;                                                                               \
-      }                                                                                                         \
+  }
+
+  if (producer) {
+    // =============================================== producers ===============================================
+    const unsigned P16 = (unsigned)Fin * (unsigned)Tp * 16u;
+    const unsigned in_rec = (unsigned)((a.in_c0 + Cin) >> 3) * P16;
+    const unsigned wbytes = (unsigned)nchunk * (unsigned)(2 * WN) * 16u;
+    const unsigned xstep = 2u * P16;
+    const unsigned wo = (unsigned)(tid & 255) * 16u;
+    __amdgpu_buffer_rsrc_t rs_hi, rs_lo, rs_w;
+    unsigned xo[NXI];
+
+#define TILE_SETUP()                                                                                            \
+  {                                                                                                             \
+    const int fin0_ = TR2 ? (f0 >> 1) - 1 : SF * f0 - a.padf;                                                   \
+    const unsigned long long in_b_ =                                                                            \
+        reinterpret_cast<unsigned long long>(a.in) + (unsigned long long)n * a.in_bstride * 4ull;               \
+    rs_hi = make_rsrc_u(in_b_, in_rec);                                                                         \
+    rs_lo = make_rsrc_u(in_b_ + (unsigned long long)(a.in_sstride >> 3) * P16, in_rec);                         \
+    rs_w = make_rsrc_u(reinterpret_cast<unsigned long long>(a.wps) + (unsigned long long)n * a.wps_nstride +    \
+                           (unsigned long long)cg * wbytes, wbytes);                                            \
+    _Pragma("unroll") for (int i = 0; i < NXI; ++i) {                                                           \
+      const int u = (i * 4 + rw) * 64 + lane;                                                                   \
+      const int p = u / TW, j = u - p * TW;                                                                     \
+      const int fin = fin0_ + (p >> 1);                                                                         \
+      const int t = t0 - 4 + j;                                                                                 \
+      const bool ok = u < XN && fin >= 0 && fin < Fin && t >= 0 && t < T && j >= 3 && j <= TT + 4;              \
+      xo[i] = ok ? ((unsigned)(((a.in_c0 >> 3) + (p & 1)) * Fin + fin) * (unsigned)Tp + (unsigned)t) * 16u      \
+                 : 0x80000000u;                                                                                 \
     }                                                                                                           \
   }
 
-  // producers: chunk KC of the current tile -> input buffer XB (0 / 1) and the weight buffer
-#define DMA_STAGE(KC, XB)                                                                                       \
+    // chunk KC of the current tile -> stage SB
+#define DMA_STAGE(KC, SB)                                                                                       \
   {                                                                                                             \
-    bf16x8* sxh_ = s_x + (XB) * 2 * XN;                                                                         \
+    bf16x8* st_ = s_stage + (SB) * SN;                                                                          \
     _Pragma("unroll") for (int i = 0; i < NXI; ++i) {                                                           \
       const int ub = (i * 4 + rw) * 64;                                                                         \
       if (ub < XN) {                                                                                            \
         if (ub + 64 <= XN || ub + lane < XN) {                                                                  \
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_hi, MN_LDS(sxh_ + ub), 16, xo[i], 0, 0, 0);               \
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_lo, MN_LDS(sxh_ + XN + ub), 16, xo[i], 0, 0, 0);          \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_hi, MN_LDS(st_ + ub), 16, xo[i], 0, 0, 0);                \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_lo, MN_LDS(st_ + XN + ub), 16, xo[i], 0, 0, 0);           \
         }                                                                                                       \
       }                                                                                                         \
       xo[i] += xstep;                                                                                           \
@@ -379,22 +430,19 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
     _Pragma("unroll") for (int i = 0; i < NWI; ++i) {                                                           \
       const int ub = (i * 4 + rw) * 64;                                                                         \
       if (ub < 2 * WN)                                                                                          \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, MN_LDS(s_whi + ub), 16, wo + (unsigned)i * 4096u, wsoff_, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, MN_LDS(st_ + 2 * XN + ub), 16, wo + (unsigned)i * 4096u, \
+                                                 wsoff_, 0, 0);                                                 \
     }                                                                                                           \
   }
 
-  // all waves (two barriers inside)
-#define TILE_TABLES()                                                                                           \
+    // epilogue tables of the current tile, set TS: producer wave rw builds output row f0 + rw, lane = output channel
+#define TILE_TABLES(TS)                                                                                         \
   {                                                                                                             \
-    if (a.btab) {                                                                                               \
-      const float* bt_ = a.btab + (long long)n * a.btab_nstride + (long long)cg * COP * 9;                      \
-      for (int i = tid; i < COP * 9; i += 512) s_bt[i] = bt_[i];                                                \
-    }                                                                                                           \
-    __syncthreads();                                                                                            \
-    if (!producer && lane < COP) {                                                                              \
-      const int f_ = f0 + wave;                                                                                 \
+    if (lane < COP) {                                                                                           \
+      const int f_ = f0 + rw;                                                                                   \
       float b3[3] = {0.f, 0.f, 0.f};                                                                            \
       if (a.btab) {                                                                                             \
+        const float* bt_ = a.btab + (long long)n * a.btab_nstride + (long long)(cg * COP + lane) * 9;           \
         _Pragma("unroll") for (int kf = 0; kf < 3; ++kf) {                                                      \
           bool ok_;                                                                                             \
           if (TR2) {                                                                                            \
@@ -404,100 +452,111 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
             const int fi_ = SF * f_ + kf - a.padf;                                                              \
             ok_ = fi_ >= 0 && fi_ < Fin;                                                                        \
           }                                                                                                     \
-          if (ok_) {                                                                                            \
-            _Pragma("unroll") for (int kt = 0; kt < 3; ++kt) b3[kt] += s_bt[lane * 9 + kt * 3 + kf];            \
+          _Pragma("unroll") for (int kt = 0; kt < 3; ++kt) {                                                    \
+            const float v_ = bt_[kt * 3 + kf];                                                                  \
+            b3[kt] += ok_ ? v_ : 0.f;                                                                           \
           }                                                                                                     \
         }                                                                                                       \
       }                                                                                                         \
       b3[1] += a.bias[cg * COP + lane];                                                                         \
-      const int slot_ = (wave * 2 + ((lane >> 2) & 1)) * 16 + (lane & 3) + 4 * (lane >> 3);                     \
-      s_bs[slot_] = b3[0] + b3[1] + b3[2];                                                                      \
-      s_bl[slot_] = b3[0];                                                                                      \
-      s_br[slot_] = b3[2];                                                                                      \
+      /* accumulator order: channel co = (i&3) + 8*(i>>2) + 4*h  ->  h = (co>>2)&1, i = (co&3) + 4*(co>>3) */    \
+      const int slot_ = (rw * 2 + ((lane >> 2) & 1)) * 16 + (lane & 3) + 4 * (lane >> 3);                       \
+      float* tb_ = s_tab + (TS) * (3 * FT * COP);                                                               \
+      tb_[slot_] = b3[0] + b3[1] + b3[2];                                                                       \
+      tb_[FT * COP + slot_] = b3[0];                                                                            \
+      tb_[2 * FT * COP + slot_] = b3[2];                                                                        \
     }                                                                                                           \
   }
 
-  const unsigned long long ts0 = clock64();
-  int si = 0;
-  bool stamp = false;
-#define STAMP() do { if (stamp && si < 60) a.dbg_buf[si++] = clock64() - ts0; } while (0)
-
-  unsigned g = 0;                                      // running chunk counter: chunk g lives in input buffer g & 1
-  int tcount = 0;
-  TILE_SETUP(k)
-  if (producer) DMA_STAGE(0, 0)
-  TILE_TABLES()
-
-  for (;;) {
-    stamp = a.dbg_buf && tid == 0 && t0 == 3 * TT && f0 == 5 * FT && n == 7 && cg == 0;
-    if (stamp) { si = 0; a.dbg_buf[62] = clock64() - ts0; }
-    if (a.dbg_buf && tid == 0 && blockIdx.x == 8 && tcount < 10) { a.dbg_buf[40 + tcount] = wall_clock64(); a.dbg_buf[50 + tcount] = clock64(); ++tcount; }
-    f32x16 acc[4];
-#pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r4][r] = 0.f;
-    const bool wave_live = !producer && (t0 + 32 * wave < T);   // this consumer's frames exist (ragged last tile)
-    const int e_n = n, e_cg = cg, e_f0 = f0, e_t0 = t0;
-    bool more = false;
-
-    for (int kc = 0; kc < nchunk; ++kc, ++g) {
-      // producers: the images of chunk g have landed (hipcc does not count LDS-DMA loads: wait explicitly).  Behind
-      // barrier 1 every consumer has also finished the MFMAs of chunk g - 1, i.e. input buffer (g + 1) & 1 is free.
-      if (producer) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      STAMP();
-      __syncthreads();                                 // barrier 1
-      STAMP();
-      bf16x8 ah[9], al[9];
-      if (!producer) {
-        chunk_load_a(ah, al, s_whi, s_wlo, half, l31);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
-      __syncthreads();                                 // barrier 2: weight buffer free
-      STAMP();
-      int next_kc = kc + 1;
-      bool do_dma = true;
-      if (kc + 1 == nchunk) {                          // stage chunk 0 of the next tile
-        k += (unsigned)nslots;
-        more = k < nk;
-        do_dma = more;
-        next_kc = 0;
-        if (more) TILE_SETUP(k)
-      }
-      if (producer) {
-        if (do_dma) DMA_STAGE(next_kc, (g + 1) & 1)
-      } else if (wave_live && !(a.dbg & 1)) {
-        const bf16x8* sx = s_x + (g & 1) * 2 * XN;
-        __builtin_amdgcn_s_setprio(1);
-        chunk_mfma_rows_a<NR, SF, TR2>(acc, ah, al, sx, sx + XN, wave, half, l31);
-        __builtin_amdgcn_s_setprio(0);
-      }
-      STAMP();
-    }
-
-    // ---- epilogue of the finished tile (conv_epilogue.hpp); chunk 0 of the next tile is already in flight ----
-    if (!producer && !(a.dbg & 4))
-      conv_epilogue_rows(a, acc, e_n, e_cg, e_f0, e_t0 + 32 * wave, lane, s_red + wave * (COP * 2), s_bs, s_bl, s_br);
-    STAMP();
-    __syncthreads();                                   // s_red complete; the tables of the finished tile are free
-    if (a.act && tid < COP * 2) {
-      const int co_l = tid >> 1, which = tid & 1;
-      const int co = e_cg * COP + co_l;
-      if (co < a.Cout) {
-        float tot = 0.f;
-        for (int w = 0; w < 4; ++w) tot += s_red[(w * COP + co_l) * 2 + which];
-        unsafeAtomicAdd(a.out_stats + ((long long)e_n * a.out_sstride + a.out_c0 + co) * 2 + which, (double)tot);
-      }
-    }
-    STAMP();
-    if (stamp) a.dbg_buf[63] = si;
-    if (!more) break;
-    TILE_TABLES()
+    // float64 statistics of a finished tile (producer wave 0): sum of the four consumer partials per channel
+#define TILE_STATS(PN, PCG, RS)                                                                                 \
+  {                                                                                                             \
+    if (a.act && rw == 0) {                                                                                     \
+      const float* sr_ = s_red + (RS) * (4 * COP * 2);                                                          \
+      const int co_l = lane >> 1, which = lane & 1;                                                             \
+      const int co = (PCG) * COP + co_l;                                                                        \
+      if (co < a.Cout) {                                                                                        \
+        float tot = 0.f;                                                                                        \
+        for (int w = 0; w < 4; ++w) tot += sr_[(w * COP + co_l) * 2 + which];                                   \
+        unsafeAtomicAdd(a.out_stats + ((long long)(PN) * a.out_sstride + a.out_c0 + co) * 2 + which, (double)tot); \
+      }                                                                                                         \
+    }                                                                                                           \
   }
-#undef STAMP
+
+    TILE_COORDS(k)
+    TILE_SETUP()
+    DMA_STAGE(0, 0)
+    TILE_TABLES(0)
+    unsigned g = 0, ti = 0;
+    int p_n = 0, p_cg = 0;
+    bool have_prev = false;
+    for (;;) {
+      bool more = false;
+      const int c_n = n, c_cg = cg;
+      for (int kc = 0; kc < nchunk; ++kc, ++g) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // chunk g has landed (hipcc does not count LDS-DMA loads)
+        __syncthreads();                                       // barrier g
+        if (kc == 0 && have_prev) TILE_STATS(p_n, p_cg, (ti + 1) & 1)
+        if (kc + 1 < nchunk) {
+          DMA_STAGE(kc + 1, (g + 1) & 1)
+        } else {
+          k += (unsigned)nslots;
+          more = k < nk;
+          if (more) {
+            TILE_COORDS(k)
+            TILE_SETUP()
+            DMA_STAGE(0, (g + 1) & 1)
+            TILE_TABLES((ti + 1) & 1)
+          }
+        }
+      }
+      p_n = c_n; p_cg = c_cg; have_prev = true;
+      ++ti;
+      if (!more) break;
+    }
+    __syncthreads();                                           // final barrier: the last epilogue is done
+    TILE_STATS(p_n, p_cg, (ti + 1) & 1)
 #undef TILE_SETUP
-#undef TILE_TABLES
 #undef DMA_STAGE
+#undef TILE_TABLES
+#undef TILE_STATS
+  } else {
+    // =============================================== consumers ===============================================
+    TILE_COORDS(k)
+    unsigned g = 0, ti = 0;
+    int tcount = 0;
+    for (;;) {
+      if (a.dbg_buf && tid == 0 && blockIdx.x == 8 && tcount < 10) {
+        a.dbg_buf[40 + tcount] = wall_clock64(); a.dbg_buf[50 + tcount] = clock64(); ++tcount;
+      }
+      f32x16 acc[4];
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r4][r] = 0.f;
+      const bool wave_live = (t0 + 32 * wave < T);             // this consumer's frames exist (ragged last tile)
+      for (int kc = 0; kc < nchunk; ++kc, ++g) {
+        __syncthreads();                                       // barrier g: stage g & 1 holds chunk g
+        if (wave_live && !(a.dbg & 1)) {
+          const bf16x8* st = s_stage + (g & 1) * SN;
+          __builtin_amdgcn_s_setprio(1);
+          chunk_mfma_rows_w<NR, SF, TR2>(acc, st, st + XN, st + 2 * XN, st + 2 * XN + WN, wave, half, l31);
+          __builtin_amdgcn_s_setprio(0);
+        }
+      }
+      if (!(a.dbg & 4)) {
+        const float* tb = s_tab + (ti & 1) * (3 * FT * COP);
+        conv_epilogue_rows(a, acc, n, cg, f0, t0 + 32 * wave, lane, s_red + (ti & 1) * (4 * COP * 2) + wave * (COP * 2),
+                           tb, tb + FT * COP, tb + 2 * FT * COP);
+      }
+      ++ti;
+      k += (unsigned)nslots;
+      if (k >= nk) break;
+      TILE_COORDS(k)
+    }
+    __syncthreads();                                           // final barrier
+  }
+#undef TILE_COORDS
 #endif
 }
 
@@ -566,7 +625,7 @@ __global__ __launch_bounds__(288) void conv_wprep_k(const float* wf, const doubl
 }
 
 static size_t dma2_lds_bytes(int NR) {
-  return (size_t)(2 * 2 * NR * 2 * TW + 2 * 9 * 2 * 32) * 16 + (size_t)(3 * FT * 32 + 32 * 9 + 4 * 32 * 2) * sizeof(float);
+  return (size_t)(2 * (2 * NR * 2 * TW + 2 * 9 * 2 * 32)) * 16 + (size_t)(2 * 3 * FT * 32 + 2 * 4 * 32 * 2) * sizeof(float);
 }
 
 static size_t dma_lds_bytes(int NR) {

@@ -77,11 +77,13 @@ class _Trunk:
         self.training = False
         return self
 
-    PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x3d": 2}
+    PRECISIONS = {"f32": 0, "bf16x3p": 1, "bf16x3": 2}
 
     def set_precision(self, mode: str):
-        """Arithmetic of the 3x3 convolutions: "f32" (exact float32 matrix cores, default) or "bf16x3" (three-term
-        bf16 split on the bf16 matrix cores, f32 accumulation; ~1e-5 relative per layer, several times faster)."""
+        """Arithmetic of the 3x3 convolutions: "f32" (exact float32 matrix cores, default), "bf16x3" (three-term bf16
+        split on the bf16 matrix cores, f32 accumulation, ~1e-5 relative per layer; activations travel pre-split in the
+        oct layout and are staged by LDS-DMA, conv_bf16_dma.hip) or "bf16x3p" (same arithmetic on planar float32
+        activations with normalise-on-load staging, conv_bf16.hip)."""
         if mode not in self.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}")
         _lib.check(_lib.lib().misonet_net_set_precision(self._net, self.PRECISIONS[mode]))

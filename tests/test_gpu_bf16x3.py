@@ -10,9 +10,9 @@ from test_gpu_parity import _assert_parity, _utt_inputs, _need_gpu
 pytestmark = pytest.mark.gpu
 
 
-# "bf16x3": planar float32 activations, normalise-on-load staging (conv_bf16.hip);
-# "bf16x3d": oct-layout activations, instance norm folded into per-sample weights, LDS-DMA staging (conv_bf16_dma.hip)
-@pytest.fixture(scope="module", params=["bf16x3", "bf16x3d"])
+# "bf16x3": oct-layout activations, instance norm folded into per-sample weights, LDS-DMA staging (conv_bf16_dma.hip);
+# "bf16x3p": planar float32 activations, normalise-on-load staging (conv_bf16.hip)
+@pytest.fixture(scope="module", params=["bf16x3", "bf16x3p"])
 def nets_bf(request, sd1, sd3):
     _need_gpu()
     PREC = request.param

@@ -3,7 +3,7 @@ sys.path.insert(0, '.')
 import misonet_amd as mz
 from misonet_amd import weights as W
 B, T = int(sys.argv[1]), int(sys.argv[2])
-prec = sys.argv[3] if len(sys.argv) > 3 else "bf16x3d"
+prec = sys.argv[3] if len(sys.argv) > 3 else "bf16x3"
 sd1 = W.make_state_dict(W.miso1_spec(), 1)
 m1 = mz.MISO_1(2, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN").cuda(0)
 m1.load_state_dict(sd1); m1.eval().set_precision(prec)
