@@ -530,13 +530,19 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
         a.dbg_buf[40 + tcount] = wall_clock64(); a.dbg_buf[50 + tcount] = clock64(); ++tcount;
       }
       f32x16 acc[4];
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r4][r] = 0.f;
       const bool wave_live = (t0 + 32 * wave < T);             // this consumer's frames exist (ragged last tile)
+      const bool stamp = a.dbg_buf && tid == 0 && t0 == 3 * TT && f0 == 5 * FT && n == 7 && cg == 0;
+      const unsigned long long ts0 = clock64();
+      int si = 0;
+#define STAMP() do { if (stamp && si < 36) a.dbg_buf[si++] = clock64() - ts0; } while (0)
       for (int kc = 0; kc < nchunk; ++kc, ++g) {
+        STAMP();
         __syncthreads();                                       // barrier g: stage g & 1 holds chunk g
+        STAMP();
+        if (kc == 0) {                                         // accumulators start at bias + folded shift (tables of this
+          const float* tb = s_tab + (ti & 1) * (3 * FT * COP); // tile: written by the producers before barrier g)
+          conv_acc_init_rows(acc, t0 + 32 * wave, T, lane, tb, tb + FT * COP, tb + 2 * FT * COP);
+        }
         if (wave_live && !(a.dbg & 1)) {
           const bf16x8* st = s_stage + (g & 1) * SN;
           __builtin_amdgcn_s_setprio(1);
@@ -544,11 +550,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
           __builtin_amdgcn_s_setprio(0);
         }
       }
-      if (!(a.dbg & 4)) {
-        const float* tb = s_tab + (ti & 1) * (3 * FT * COP);
-        conv_epilogue_rows(a, acc, n, cg, f0, t0 + 32 * wave, lane, s_red + (ti & 1) * (4 * COP * 2) + wave * (COP * 2),
-                           tb, tb + FT * COP, tb + 2 * FT * COP);
-      }
+      STAMP();
+      if (!(a.dbg & 4))
+        conv_epilogue_rows_nb(a, acc, n, cg, f0, t0 + 32 * wave, lane, s_red + (ti & 1) * (4 * COP * 2) + wave * (COP * 2));
+      STAMP();
+      if (stamp) a.dbg_buf[63] = si;
+#undef STAMP
       ++ti;
       k += (unsigned)nslots;
       if (k >= nk) break;

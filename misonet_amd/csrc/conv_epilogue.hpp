@@ -109,10 +109,10 @@ __device__ __forceinline__ void split_pair_t(float x0, float x1, unsigned& hi, u
 //         instance-norm shift of the DMA dataflow, split by time tap so that the first / last frame of the utterance
 //         (whose left / right taps fall into the zero padding) can drop their share.
 // OCT:    compile the oct-layout output path (a.out_oct selects it at run time).
-template <int NCO, int NSEG = 4, bool OCT = false>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16_t (&acc)[NCO][NSEG], int n, int cg, int f,
-                                              int t0, bool row_ok, int lane, float* s_red,
-                                              const float* s_bias = nullptr, const float* s_b4 = nullptr) {
+template <int NCO, int NSEG, bool OCT, bool ACT>
+__device__ __forceinline__ void conv_epilogue_impl(const ConvArgs& a, f32x16_t (&acc)[NCO][NSEG], int n, int cg, int f,
+                                                   int t0, bool row_ok, int lane, float* s_red,
+                                                   const float* s_bias, const float* s_b4) {
   constexpr int COP = NCO * 32;
   const int half = lane >> 5, l31 = lane & 31;
   const int T = a.T, Tp = a.Tp;
@@ -171,7 +171,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16_t (&acc)
         for (int r = 0; r < 16; ++r) {
           float x = acc[j][s][r] + bs[r];
           if (t_edge) x -= (t == 0 ? bl[r] : 0.f) + (t == T - 1 ? br[r] : 0.f);
-          if (a.act) x = elu_fast(x);
+          if (ACT) x = elu_fast(x);
           v[r] = x;
           const int kr = j * 32 + (r & 3) + 8 * (r >> 2);
           const float vm = (unmasked || (tm[s] && (full_c || kr < cmax))) ? x : 0.f;
@@ -204,7 +204,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16_t (&acc)
           }
         }
       }
-      if (a.act && !(a.dbg & 16)) {
+      if (ACT && !(a.dbg & 16)) {
         const float x1 = reduce16_halfwave(s1, lane);
         const float x2 = reduce16_halfwave(s2, lane);
         if ((lane & 16) == 0) {
@@ -260,7 +260,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16_t (&acc)
 #pragma unroll
         for (int s = 0; s < NSEG; ++s) {
           float v = acc[j][s][r] + bs[r];
-          if (a.act) v = elu_fast(v);
+          if (ACT) v = elu_fast(v);
           if (!(a.dbg & 8)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff[s] + coff, 0, 0);
           a1 += v;
           a2 = fmaf(v, v, a2);
@@ -272,7 +272,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16_t (&acc)
           const int t = t0 + s * 32 + l31;
           float v = acc[j][s][r] + bs[r];
           if (t_edge) v -= (t == 0 ? bl[r] : 0.f) + (t == T - 1 ? br[r] : 0.f);
-          if (a.act) v = elu_fast(v);
+          if (ACT) v = elu_fast(v);
           if (!(a.dbg & 8)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff[s] + coff, 0, 0);
           const float vm = (tm[s] && cok) ? v : 0.f;
           a1 += vm;
@@ -282,7 +282,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16_t (&acc)
       s1[r] = a1;
       s2[r] = a2;
     }
-    if (a.act && !(a.dbg & 16)) {
+    if (ACT && !(a.dbg & 16)) {
       const float x1 = reduce16_halfwave(s1, lane);
       const float x2 = reduce16_halfwave(s2, lane);
       if ((lane & 16) == 0) {
@@ -295,6 +295,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16_t (&acc)
   }
 }
 
+// ACT (ELU + statistics) is a compile-time parameter of the implementation: a run-time test inside the unrolled element
+// loops turns into a branch per element and serialises the exp latency.
+template <int NCO, int NSEG = 4, bool OCT = false>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16_t (&acc)[NCO][NSEG], int n, int cg, int f,
+                                              int t0, bool row_ok, int lane, float* s_red,
+                                              const float* s_bias = nullptr, const float* s_b4 = nullptr) {
+  if (a.act) conv_epilogue_impl<NCO, NSEG, OCT, true>(a, acc, n, cg, f, t0, row_ok, lane, s_red, s_bias, s_b4);
+  else conv_epilogue_impl<NCO, NSEG, OCT, false>(a, acc, n, cg, f, t0, row_ok, lane, s_red, s_bias, s_b4);
+}
+
 // Tile epilogue of the row-reuse mapping (conv_bf16_dma.hip): one wave owns 32 frames [tw, tw + 32) of FOUR output rows
 // f0 .. f0 + 3 (acc[r] = 32 channels x 32 frames of row f0 + r).
 //   s_bs / s_bl / s_br: LDS tables [4 rows][2 half-waves][16] in ACCUMULATOR order (entry i of half h = channel
@@ -305,7 +315,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16_t (&acc)
 // Channels >= Cout need no masking in the statistics: their weights and bias are zero-padded, so the value is
 // ELU(0) = 0 exactly.  Everything that depends only on the wave (tile edges) selects between a branch-free fast path
 // and a masked path; nothing is decided per element.
-template <bool MASKED>
+template <bool MASKED, bool ACT>
 __device__ __forceinline__ void conv_epilogue_rows_impl(const ConvArgs& a, f32x16_t (&acc)[4], int cg, int f0, int tw,
                                                         int lane, const float* s_bs, const float* s_bl,
                                                         const float* s_br, const __amdgpu_buffer_rsrc_t rs_h,
@@ -350,7 +360,7 @@ __device__ __forceinline__ void conv_epilogue_rows_impl(const ConvArgs& a, f32x1
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       float x = acc[r][i] + bs[i];
-      if (a.act) x = elu_fast(x);
+      if (ACT) x = elu_fast(x);
       v[i] = x;
       const float vm = MASKED ? x * m : x;
       s1[i] += vm;
@@ -429,8 +439,12 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvArgs& a, f32x16_t (
   const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc(
       reinterpret_cast<void*>(((unsigned long long)pb_hi << 32) | pb_lo), 0, nrec_s, 0x00020000);
 
-  if (fast) conv_epilogue_rows_impl<false>(a, acc, cg, f0, tw, lane, s_bs, s_bl, s_br, rs_h, rs_l, s1, s2);
-  else conv_epilogue_rows_impl<true>(a, acc, cg, f0, tw, lane, s_bs, s_bl, s_br, rs_h, rs_l, s1, s2);
+  if (a.act) {
+    if (fast) conv_epilogue_rows_impl<false, true>(a, acc, cg, f0, tw, lane, s_bs, s_bl, s_br, rs_h, rs_l, s1, s2);
+    else conv_epilogue_rows_impl<true, true>(a, acc, cg, f0, tw, lane, s_bs, s_bl, s_br, rs_h, rs_l, s1, s2);
+  } else {
+    conv_epilogue_rows_impl<true, false>(a, acc, cg, f0, tw, lane, s_bs, s_bl, s_br, rs_h, rs_l, s1, s2);
+  }
 
   if (a.act && !(a.dbg & 16)) {
     const float x1 = reduce16_halfwave(s1, lane);
@@ -443,5 +457,170 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvArgs& a, f32x16_t (
     }
   }
 }
+
+// ---- epilogue of the persistent DMA kernel: the accumulators were INITIALISED with the bias (conv_acc_init_rows), so
+// the element work is ELU + statistics only, written with 2-wide vector types so that the multiplies, adds and FMAs
+// become v_pk_*_f32 (two elements per instruction).
+typedef float f32x2_e __attribute__((ext_vector_type(2)));
+
+// acc[r][i] = bias + folded shift of (row f0 + r, channel of accumulator slot i); tables as in conv_epilogue_rows.
+__device__ __forceinline__ void conv_acc_init_rows(f32x16_t (&acc)[4], int tw, int T, int lane, const float* s_bs,
+                                                   const float* s_bl, const float* s_br) {
+  const int half = lane >> 5, l31 = lane & 31;
+  const int t = tw + l31;
+  const bool t_edge = (tw == 0 || tw + 32 >= T);                            // uniform
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float4* pb = reinterpret_cast<const float4*>(s_bs + (r * 2 + half) * 16);
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const float4 q = pb[q4];
+      acc[r][4 * q4 + 0] = q.x; acc[r][4 * q4 + 1] = q.y; acc[r][4 * q4 + 2] = q.z; acc[r][4 * q4 + 3] = q.w;
+    }
+  }
+  if (t_edge) {
+    const float e0 = (t == 0) ? 1.f : 0.f, e1 = (t == T - 1) ? 1.f : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float4* pl = reinterpret_cast<const float4*>(s_bl + (r * 2 + half) * 16);
+      const float4* pr = reinterpret_cast<const float4*>(s_br + (r * 2 + half) * 16);
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const float4 ql = pl[q4], qr = pr[q4];
+        acc[r][4 * q4 + 0] -= e0 * ql.x + e1 * qr.x; acc[r][4 * q4 + 1] -= e0 * ql.y + e1 * qr.y;
+        acc[r][4 * q4 + 2] -= e0 * ql.z + e1 * qr.z; acc[r][4 * q4 + 3] -= e0 * ql.w + e1 * qr.w;
+      }
+    }
+  }
+}
+
+template <bool MASKED, bool ACT>
+__device__ __forceinline__ void conv_epilogue_rows_nb_impl(const ConvArgs& a, f32x16_t (&acc)[4], int cg, int f0, int tw,
+                                                           int lane, const __amdgpu_buffer_rsrc_t rs_h,
+                                                           const __amdgpu_buffer_rsrc_t rs_l, f32x2_e (&s1)[8],
+                                                           f32x2_e (&s2)[8]) {
+  constexpr int COP = 32;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int T = a.T, Tp = a.Tp;
+  const int cbase = cg * COP;
+  const int t = tw + l31;
+  const unsigned P16 = (unsigned)a.Fout * (unsigned)Tp * 16u;
+  const unsigned P4 = (unsigned)a.Fout * (unsigned)Tp * 4u;
+  const bool oct_ok0 = cbase + (0 + half) * 8 < a.Cout;
+  const bool oct_ok1 = cbase + (2 + half) * 8 < a.Cout;
+  const f32x2_e kl2e = {1.4426950408889634f, 1.4426950408889634f};
+  const f32x2_e kone = {1.f, 1.f};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int f = f0 + r;
+    const bool ok = !MASKED || ((f < a.Fout) && (t < T));
+    const float mf = ok ? 1.f : 0.f;
+    const f32x2_e m2 = {mf, mf};
+    float v[16];
+#pragma unroll
+    for (int i2 = 0; i2 < 8; ++i2) {
+      f32x2_e x = {acc[r][2 * i2], acc[r][2 * i2 + 1]};
+      if (ACT) {                                   // compile-time: a run-time test here becomes a branch per pair and
+                                                   // serialises the exp latency of the eight pairs
+        f32x2_e e = x * kl2e;
+        e.x = __builtin_amdgcn_exp2f(e.x);
+        e.y = __builtin_amdgcn_exp2f(e.y);
+        e = e - kone;
+        x.x = x.x > 0.f ? x.x : e.x;
+        x.y = x.y > 0.f ? x.y : e.y;
+      }
+      v[2 * i2] = x.x; v[2 * i2 + 1] = x.y;
+      const f32x2_e vm = MASKED ? x * m2 : x;
+      s1[i2] = s1[i2] + vm;
+      s2[i2] = vm * vm + s2[i2];
+    }
+    if (a.dbg & 8) continue;
+    if (a.out_oct) {
+      unsigned H[4][2], L[4][2];
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        split_pair_t(v[4 * o + 0], v[4 * o + 1], H[o][0], L[o][0]);
+        split_pair_t(v[4 * o + 2], v[4 * o + 3], H[o][1], L[o][1]);
+      }
+      const unsigned vo = (unsigned)(f * Tp + t) * 16u + (unsigned)half * P16 + (unsigned)(cbase >> 3) * P16;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          auto rh = __builtin_amdgcn_permlane32_swap(H[2 * k][d], H[2 * k + 1][d], false, false);
+          H[2 * k][d] = rh[0]; H[2 * k + 1][d] = rh[1];
+          auto rl = __builtin_amdgcn_permlane32_swap(L[2 * k][d], L[2 * k + 1][d], false, false);
+          L[2 * k][d] = rl[0]; L[2 * k + 1][d] = rl[1];
+        }
+        const u32x4_t uh = {H[2 * k][0], H[2 * k][1], H[2 * k + 1][0], H[2 * k + 1][1]};
+        const u32x4_t ul = {L[2 * k][0], L[2 * k][1], L[2 * k + 1][0], L[2 * k + 1][1]};
+        if (ok && (k == 0 ? oct_ok0 : oct_ok1)) {
+          __builtin_amdgcn_raw_buffer_store_b128(uh, rs_h, vo + (unsigned)(2 * k) * P16, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(ul, rs_l, vo + (unsigned)(2 * k) * P16, 0, 0);
+        }
+      }
+    } else {
+      const unsigned vo = ok ? ((unsigned)(f * Tp + t) * 4u + (unsigned)(4 * half) * P4) : 0x80000000u;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int kr = (i & 3) + 8 * (i >> 2);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[i]), rs_h, vo + (unsigned)(cbase + kr) * P4, 0, 0);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void conv_epilogue_rows_nb(const ConvArgs& a, f32x16_t (&acc)[4], int n, int cg, int f0, int tw,
+                                                      int lane, float* s_red) {
+  const int half = lane >> 5;
+  const int T = a.T, Tp = a.Tp;
+  const bool fast = (tw + 32 <= T) && (f0 + 4 <= a.Fout);                   // uniform: all 32 frames and 4 rows exist
+  f32x2_e s1[8], s2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { s1[i] = f32x2_e{0.f, 0.f}; s2[i] = f32x2_e{0.f, 0.f}; }
+  const unsigned P16 = (unsigned)a.Fout * (unsigned)Tp * 16u;
+  const unsigned P4 = (unsigned)a.Fout * (unsigned)Tp * 4u;
+  unsigned long long pa, pb;
+  unsigned nrec;
+  if (a.out_oct) {
+    pa = reinterpret_cast<unsigned long long>(a.out) + (unsigned long long)n * a.out_bstride * 4ull +
+         (unsigned long long)(a.out_c0 >> 3) * P16;
+    pb = pa + (unsigned long long)(a.out_sstride >> 3) * P16;
+    nrec = (unsigned)(a.Cout >> 3) * P16;
+  } else {
+    pa = reinterpret_cast<unsigned long long>(a.out + (long long)n * a.out_bstride + (long long)a.out_c0 * a.Fout * Tp);
+    pb = pa;
+    nrec = (unsigned)a.Cout * P4;
+  }
+  const unsigned pa_lo = __builtin_amdgcn_readfirstlane((unsigned)pa), pa_hi = __builtin_amdgcn_readfirstlane((unsigned)(pa >> 32));
+  const unsigned pb_lo = __builtin_amdgcn_readfirstlane((unsigned)pb), pb_hi = __builtin_amdgcn_readfirstlane((unsigned)(pb >> 32));
+  const int nrec_s = __builtin_amdgcn_readfirstlane((int)nrec);
+  const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<void*>(((unsigned long long)pa_hi << 32) | pa_lo), 0, nrec_s, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<void*>(((unsigned long long)pb_hi << 32) | pb_lo), 0, nrec_s, 0x00020000);
+
+  if (a.act) {
+    if (fast) conv_epilogue_rows_nb_impl<false, true>(a, acc, cg, f0, tw, lane, rs_h, rs_l, s1, s2);
+    else conv_epilogue_rows_nb_impl<true, true>(a, acc, cg, f0, tw, lane, rs_h, rs_l, s1, s2);
+  } else {
+    conv_epilogue_rows_nb_impl<true, false>(a, acc, cg, f0, tw, lane, rs_h, rs_l, s1, s2);
+  }
+
+  if (a.act && !(a.dbg & 16)) {
+    float f1[16], f2[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { f1[2 * i] = s1[i].x; f1[2 * i + 1] = s1[i].y; f2[2 * i] = s2[i].x; f2[2 * i + 1] = s2[i].y; }
+    const float x1 = reduce16_halfwave(f1, lane);
+    const float x2 = reduce16_halfwave(f2, lane);
+    if ((lane & 16) == 0) {
+      const int q = lane & 15;
+      const int co_l = (q & 3) + 8 * (q >> 2) + 4 * half;
+      s_red[co_l * 2 + 0] = x1;
+      s_red[co_l * 2 + 1] = x2;
+    }
+  }
+}
+
 
 }  // namespace mn
