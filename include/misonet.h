@@ -60,8 +60,12 @@ int misonet_net_set_tensor(misonet_net* net, const char* key, const float* host_
 int misonet_net_commit(misonet_net* net);
 
 /* arithmetic of the 3x3 convolutions (99.4 % of the FLOPs): 0 = exact float32 matrix cores
- * (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain; default), 1 = "bf16x3": every product is evaluated as
- * w_hi*x_hi + w_hi*x_lo + w_lo*x_hi on the bf16 matrix cores with f32 accumulation (~1e-5 relative per layer). */
+ * (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain; default), 1 = "bf16x3p": every product is evaluated as
+ * w_hi*x_hi + w_hi*x_lo + w_lo*x_hi on the bf16 matrix cores with f32 accumulation (~1e-5 relative per layer) on
+ * planar float32 activations, 2 = "bf16x3": the same arithmetic with the activations kept pre-split (bf16 hi/lo,
+ * 8 channels per 16-byte unit) between the convolutions, the instance norm folded into per-sample weights and
+ * LDS-DMA staging -- the fastest mode.  The choice is internal to the workspace: inputs, outputs and taps are the
+ * same float32 / complex64 tensors in every mode. */
 int misonet_net_set_precision(misonet_net* net, int mode);
 int misonet_net_get_precision(const misonet_net* net);
 
