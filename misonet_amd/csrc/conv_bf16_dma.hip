@@ -274,35 +274,59 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_dma(const ConvArgs a) {
 #endif
 }
 
-// MFMA loop of one K-chunk with row reuse, weight fragments read from LDS one time tap ahead (the weight image stays
-// valid for the whole chunk in the fully double-buffered kernel, so only 2 x 6 fragments are live instead of 18).
+// MFMA loop of one K-chunk with row reuse; the weight image stays valid for the whole chunk (fully double-buffered
+// kernel), so the weight fragments are read from LDS on the fly, single-buffered: fragment (kt, kf) is reloaded with the
+// next time tap's weights in the first step after its last use, which is at least one full step before its next use.
+//   use(fr, kf, R): output row fr takes tap kf from staged input row R.
+template <int SF, bool TR2>
+__device__ __forceinline__ constexpr bool mfma_use(int fr, int kf, int R) {
+  return TR2 ? ((((fr + kf) & 1) == 0) && (((fr + kf) >> 1) == R)) : (SF * fr + kf == R);
+}
 template <int NR, int SF, bool TR2>
+__device__ __forceinline__ constexpr int mfma_last_r(int kf) {        // last staged row that uses tap kf
+  int last = 0;
+  for (int R = 0; R < NR; ++R)
+    for (int fr = 0; fr < 4; ++fr)
+      if (mfma_use<SF, TR2>(fr, kf, R)) last = R;
+  return last;
+}
+
+// `issue(st)` runs once per step behind the first MFMAs of the step: the deferred epilogue of the PREVIOUS tile is
+// spread over these slots, so its VALU work and stores execute in the shadow of the matrix pipe.
+template <int NR, int SF, bool TR2, class Issue = NoIssue>
 __device__ __forceinline__ void chunk_mfma_rows_w(f32x16 (&acc)[4], const bf16x8* s_xhi, const bf16x8* s_xlo,
                                                   const bf16x8* s_whi, const bf16x8* s_wlo, int wave, int half,
-                                                  int l31) {
+                                                  int l31, const Issue& issue = Issue()) {
   const int wb = half * 32 + l31;                        // + tap * 64
   const int xb = half * TW + 3 + 32 * wave + l31;        // + R * 2 * TW + kt
   constexpr int NSTEP = 3 * NR;
-  bf16x8 ah[2][3], al[2][3], bh[2], bl[2];
+  bf16x8 ah[3], al[3], bh[2], bl[2];
 #pragma unroll
-  for (int kf = 0; kf < 3; ++kf) { ah[0][kf] = s_whi[wb + kf * 64]; al[0][kf] = s_wlo[wb + kf * 64]; }
+  for (int kf = 0; kf < 3; ++kf) { ah[kf] = s_whi[wb + kf * 64]; al[kf] = s_wlo[wb + kf * 64]; }
 #pragma unroll
   for (int st = -1; st < NSTEP; ++st) {
     if (st + 1 < NSTEP) {
       const int kt_ = (st + 1) / NR, R_ = (st + 1) % NR;
       bh[(st + 1) & 1] = s_xhi[xb + R_ * 2 * TW + kt_];
       bl[(st + 1) & 1] = s_xlo[xb + R_ * 2 * TW + kt_];
-      if (R_ == 1 && kt_ < 2) {                          // next time tap's weights, one tap group ahead
+    }
+    if (st >= 0) {
+      // weights of the next time tap into the fragments whose last use was the PREVIOUS step
+      const int kt = st / NR, R = st % NR;
 #pragma unroll
-        for (int kf = 0; kf < 3; ++kf) {
-          ah[(kt_ + 1) & 1][kf] = s_whi[wb + ((kt_ + 1) * 3 + kf) * 64];
-          al[(kt_ + 1) & 1][kf] = s_wlo[wb + ((kt_ + 1) * 3 + kf) * 64];
+      for (int kf = 0; kf < 3; ++kf) {
+        const int lr = mfma_last_r<NR, SF, TR2>(kf);
+        const bool now = (lr + 1 < NR) ? (R == lr + 1 && kt < 2) : (R == 0 && kt > 0);
+        const int ktn = (lr + 1 < NR) ? kt + 1 : kt;
+        if (now) {
+          ah[kf] = s_whi[wb + (ktn * 3 + kf) * 64];
+          al[kf] = s_wlo[wb + (ktn * 3 + kf) * 64];
         }
       }
     }
     __builtin_amdgcn_sched_barrier(0);     // keep the next step's ds_reads AHEAD of this step's MFMAs
     if (st >= 0) {
-      const int kt = st / NR, R = st % NR;
+      const int R = st % NR;
       const int cur = st & 1;
 #pragma unroll
       for (int term = 0; term < 3; ++term) {
@@ -310,14 +334,14 @@ __device__ __forceinline__ void chunk_mfma_rows_w(f32x16 (&acc)[4], const bf16x8
         for (int fr = 0; fr < 4; ++fr) {
 #pragma unroll
           for (int kf = 0; kf < 3; ++kf) {
-            const bool use = TR2 ? ((((fr + kf) & 1) == 0) && (((fr + kf) >> 1) == R)) : (SF * fr + kf == R);
-            if (use) {
-              if (term == 0) acc[fr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[kt & 1][kf], bh[cur], acc[fr], 0, 0, 0);
-              else if (term == 1) acc[fr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kt & 1][kf], bl[cur], acc[fr], 0, 0, 0);
-              else acc[fr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kt & 1][kf], bh[cur], acc[fr], 0, 0, 0);
+            if (mfma_use<SF, TR2>(fr, kf, R)) {
+              if (term == 0) acc[fr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[kf], bh[cur], acc[fr], 0, 0, 0);
+              else if (term == 1) acc[fr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kf], bl[cur], acc[fr], 0, 0, 0);
+              else acc[fr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kf], bh[cur], acc[fr], 0, 0, 0);
             }
           }
         }
+        if (term == 0) issue(st);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -363,6 +387,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
   const int half = lane >> 5, l31 = lane & 31;
   const int T = a.T, Tp = a.Tp, Fin = a.Fin, Cin = a.Cin;
   const int nchunk = (Cin + CKB - 1) / CKB;
+  // deferred epilogue: rows 0-3 of a finished tile are post-processed during K-chunks 0-3 of the next tile
+  const bool deferred = nchunk >= 4 && a.act && a.out_oct && !(a.dbg & 32);
 
   const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
   const unsigned per = (unsigned)(a.ntx * a.nty * a.ncg);                    // tiles per sample
@@ -488,15 +514,19 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
     DMA_STAGE(0, 0)
     TILE_TABLES(0)
     unsigned g = 0, ti = 0;
-    int p_n = 0, p_cg = 0;
-    bool have_prev = false;
+    // finished tiles whose statistics are still to be flushed: p1 = previous tile, p2 = the one before.  With the
+    // deferred epilogue the partials of tile j are complete only after chunk 3 of tile j + 1.
+    int p1_n = 0, p1_cg = 0, p2_n = 0, p2_cg = 0;
     for (;;) {
       bool more = false;
       const int c_n = n, c_cg = cg;
       for (int kc = 0; kc < nchunk; ++kc, ++g) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // chunk g has landed (hipcc does not count LDS-DMA loads)
         __syncthreads();                                       // barrier g
-        if (kc == 0 && have_prev) TILE_STATS(p_n, p_cg, (ti + 1) & 1)
+        if (kc == 0) {
+          if (!deferred && ti >= 1) TILE_STATS(p1_n, p1_cg, (ti + 1) & 1)
+          if (deferred && ti >= 2) TILE_STATS(p2_n, p2_cg, ti & 1)
+        }
         if (kc + 1 < nchunk) {
           DMA_STAGE(kc + 1, (g + 1) & 1)
         } else {
@@ -510,12 +540,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
           }
         }
       }
-      p_n = c_n; p_cg = c_cg; have_prev = true;
+      p2_n = p1_n; p2_cg = p1_cg;
+      p1_n = c_n; p1_cg = c_cg;
       ++ti;
       if (!more) break;
     }
     __syncthreads();                                           // final barrier: the last epilogue is done
-    TILE_STATS(p_n, p_cg, (ti + 1) & 1)
+    if (deferred && ti >= 2) TILE_STATS(p2_n, p2_cg, ti & 1)
+    TILE_STATS(p1_n, p1_cg, (ti + 1) & 1)
 #undef TILE_SETUP
 #undef DMA_STAGE
 #undef TILE_TABLES
@@ -523,43 +555,154 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
   } else {
     // =============================================== consumers ===============================================
     TILE_COORDS(k)
+    if (deferred) {
+      const unsigned OP16 = (unsigned)a.Fout * (unsigned)Tp * 16u;           // bytes per output octet plane
+      // rows 0 .. NDEF-1 of a tile are post-processed during the next tile, the others right after its last MFMA.
+      // Register budget: 16 VGPRs per deferred row on top of acc 64 + statistics 32 + operands 40; 3 rows already
+      // spill inside the MFMA loops and are no faster than 2.
+      constexpr int NDEF = 2;
+      f32x16 prev[4];
+      EpiState es;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) prev[r4][r] = 0.f;
+      es.pmt = 0.f; es.pvo0 = 0u; es.prows = 0; es.prow_b = (unsigned)Tp * 16u;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { es.s1[i] = f32x2{0.f, 0.f}; es.s2[i] = f32x2{0.f, 0.f}; }
+      es.okk0 = es.okk1 = false;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { es.PH[i][0] = es.PH[i][1] = es.PL[i][0] = es.PL[i][1] = 0u; }
+      __amdgpu_buffer_rsrc_t prs_h = make_rsrc_u(reinterpret_cast<unsigned long long>(a.out), 0u);
+      __amdgpu_buffer_rsrc_t prs_l = prs_h;
+      unsigned g = 0, ti = 0;
+      int tcount = 0;
+      for (;;) {
+        if (a.dbg_buf && tid == 0 && blockIdx.x == 8 && tcount < 10) {
+          a.dbg_buf[40 + tcount] = wall_clock64(); a.dbg_buf[50 + tcount] = clock64(); ++tcount;
+        }
+        f32x16 acc[4];
+        const bool wave_live = (t0 + 32 * wave < T);
+        float* sred_prev = s_red + ((ti + 1) & 1) * (4 * COP * 2) + wave * (COP * 2);   // partials of tile ti - 1
+        // one K-chunk; ROW = row of the previous tile post-processed in the shadow of its MFMAs (-1: none)
+#define RUN_CHUNK(ROW)                                                                                          \
+        {                                                                                                       \
+          __syncthreads();                                     /* barrier g: stage g & 1 holds chunk g */         \
+          if ((ROW) == 0) {                                                                                     \
+            const float* tb = s_tab + (ti & 1) * (3 * FT * COP);                                                \
+            conv_acc_init_rows(acc, t0 + 32 * wave, T, lane, tb, tb + FT * COP, tb + 2 * FT * COP);             \
+          }                                                                                                     \
+          const bf16x8* st_ = s_stage + (g & 1) * SN;                                                           \
+          auto hook = [&](int stp) {                                                                            \
+            if ((ROW) >= 0)                                                                                     \
+              conv_epi_step<((ROW) >= 0 ? (ROW) : 0), 3 * NR>(stp, prev, es, prs_h, prs_l, OP16, sred_prev, lane); \
+          };                                                                                                    \
+          if (wave_live && !(a.dbg & 1)) {                                                                      \
+            __builtin_amdgcn_s_setprio(1);                                                                      \
+            chunk_mfma_rows_w<NR, SF, TR2>(acc, st_, st_ + XN, st_ + 2 * XN, st_ + 2 * XN + WN, wave, half, l31, hook); \
+            __builtin_amdgcn_s_setprio(0);                                                                      \
+          } else {                                                                                              \
+            _Pragma("unroll") for (int stp = 0; stp < 3 * NR; ++stp) hook(stp);                                 \
+          }                                                                                                     \
+          ++g;                                                                                                  \
+        }
+        RUN_CHUNK(0)
+        RUN_CHUNK(NDEF > 1 ? 1 : -1)
+        if (NDEF == 2) conv_epi_reduce(es, sred_prev, lane);
+        RUN_CHUNK(NDEF > 2 ? 2 : -1)
+        if (NDEF == 3) conv_epi_reduce(es, sred_prev, lane);
+        RUN_CHUNK(NDEF > 3 ? 3 : -1)
+        if (NDEF == 4) conv_epi_reduce(es, sred_prev, lane);
+        for (int kc = 4; kc < nchunk; ++kc) RUN_CHUNK(-1)
+        // ---- the finished tile: rows NDEF..3 now, rows 0..NDEF-1 become the "previous tile" ----
+        {
+          const int tw = t0 + 32 * wave;
+          const int t = tw + l31;
+          const int cbase = cg * COP;
+          es.pmt = (t < T) ? 1.f : 0.f;
+          es.prows = (a.Fout - f0) < 4 ? (a.Fout - f0) : 4;
+          es.pvo0 = (unsigned)(f0 * Tp + t) * 16u + (unsigned)(half + (cbase >> 3)) * OP16;
+          es.okk0 = cbase + (0 + half) * 8 < a.Cout;
+          es.okk1 = cbase + (2 + half) * 8 < a.Cout;
+          const unsigned long long pa = reinterpret_cast<unsigned long long>(a.out) +
+                                        (unsigned long long)n * a.out_bstride * 4ull + (unsigned long long)(a.out_c0 >> 3) * OP16;
+          const unsigned nrec = (unsigned)(a.Cout >> 3) * OP16;
+          prs_h = make_rsrc_u(pa, nrec);
+          prs_l = make_rsrc_u(pa + (unsigned long long)(a.out_sstride >> 3) * OP16, nrec);
+          float* sred_cur = s_red + (ti & 1) * (4 * COP * 2) + wave * (COP * 2);
+          if (NDEF <= 2) {
+#pragma unroll
+            for (int stp = 0; stp < 3 * NR; ++stp) conv_epi_step<2, 3 * NR>(stp, acc, es, prs_h, prs_l, OP16, sred_cur, lane);
+          }
+          if (NDEF <= 3) {
+#pragma unroll
+            for (int stp = 0; stp < 3 * NR; ++stp) conv_epi_step<3, 3 * NR>(stp, acc, es, prs_h, prs_l, OP16, sred_cur, lane);
+          }
+#pragma unroll
+          for (int r4 = 0; r4 < NDEF; ++r4) prev[r4] = acc[r4];
+        }
+        ++ti;
+        k += (unsigned)nslots;
+        if (k >= nk) break;
+        TILE_COORDS(k)
+      }
+      // ---- flush: the deferred rows of the last tile, not overlapped ----
+      {
+        float* sred_prev = s_red + ((ti + 1) & 1) * (4 * COP * 2) + wave * (COP * 2);
+#pragma unroll
+        for (int stp = 0; stp < 3 * NR; ++stp) conv_epi_step<0, 3 * NR>(stp, prev, es, prs_h, prs_l, OP16, sred_prev, lane);
+#pragma unroll
+        for (int stp = 0; stp < 3 * NR; ++stp) conv_epi_step<1, 3 * NR>(stp, prev, es, prs_h, prs_l, OP16, sred_prev, lane);
+        if (NDEF > 2) {
+#pragma unroll
+          for (int stp = 0; stp < 3 * NR; ++stp) conv_epi_step<2, 3 * NR>(stp, prev, es, prs_h, prs_l, OP16, sred_prev, lane);
+        }
+        if (NDEF > 3) {
+#pragma unroll
+          for (int stp = 0; stp < 3 * NR; ++stp) conv_epi_step<3, 3 * NR>(stp, prev, es, prs_h, prs_l, OP16, sred_prev, lane);
+        }
+        conv_epi_reduce(es, sred_prev, lane);
+      }
+#undef RUN_CHUNK
+    } else {
     unsigned g = 0, ti = 0;
-    int tcount = 0;
-    for (;;) {
-      if (a.dbg_buf && tid == 0 && blockIdx.x == 8 && tcount < 10) {
-        a.dbg_buf[40 + tcount] = wall_clock64(); a.dbg_buf[50 + tcount] = clock64(); ++tcount;
-      }
-      f32x16 acc[4];
-      const bool wave_live = (t0 + 32 * wave < T);             // this consumer's frames exist (ragged last tile)
-      const bool stamp = a.dbg_buf && tid == 0 && t0 == 3 * TT && f0 == 5 * FT && n == 7 && cg == 0;
-      const unsigned long long ts0 = clock64();
-      int si = 0;
+      int tcount = 0;
+      for (;;) {
+        if (a.dbg_buf && tid == 0 && blockIdx.x == 8 && tcount < 10) {
+          a.dbg_buf[40 + tcount] = wall_clock64(); a.dbg_buf[50 + tcount] = clock64(); ++tcount;
+        }
+        f32x16 acc[4];
+        const bool wave_live = (t0 + 32 * wave < T);             // this consumer's frames exist (ragged last tile)
+        const bool stamp = a.dbg_buf && tid == 0 && t0 == 3 * TT && f0 == 5 * FT && n == 7 && cg == 0;
+        const unsigned long long ts0 = clock64();
+        int si = 0;
 #define STAMP() do { if (stamp && si < 36) a.dbg_buf[si++] = clock64() - ts0; } while (0)
-      for (int kc = 0; kc < nchunk; ++kc, ++g) {
-        STAMP();
-        __syncthreads();                                       // barrier g: stage g & 1 holds chunk g
-        STAMP();
-        if (kc == 0) {                                         // accumulators start at bias + folded shift (tables of this
-          const float* tb = s_tab + (ti & 1) * (3 * FT * COP); // tile: written by the producers before barrier g)
-          conv_acc_init_rows(acc, t0 + 32 * wave, T, lane, tb, tb + FT * COP, tb + 2 * FT * COP);
+        for (int kc = 0; kc < nchunk; ++kc, ++g) {
+          STAMP();
+          __syncthreads();                                       // barrier g: stage g & 1 holds chunk g
+          STAMP();
+          if (kc == 0) {                                         // accumulators start at bias + folded shift (tables of this
+            const float* tb = s_tab + (ti & 1) * (3 * FT * COP); // tile: written by the producers before barrier g)
+            conv_acc_init_rows(acc, t0 + 32 * wave, T, lane, tb, tb + FT * COP, tb + 2 * FT * COP);
+          }
+          if (wave_live && !(a.dbg & 1)) {
+            const bf16x8* st = s_stage + (g & 1) * SN;
+            __builtin_amdgcn_s_setprio(1);
+            chunk_mfma_rows_w<NR, SF, TR2>(acc, st, st + XN, st + 2 * XN, st + 2 * XN + WN, wave, half, l31);
+            __builtin_amdgcn_s_setprio(0);
+          }
         }
-        if (wave_live && !(a.dbg & 1)) {
-          const bf16x8* st = s_stage + (g & 1) * SN;
-          __builtin_amdgcn_s_setprio(1);
-          chunk_mfma_rows_w<NR, SF, TR2>(acc, st, st + XN, st + 2 * XN, st + 2 * XN + WN, wave, half, l31);
-          __builtin_amdgcn_s_setprio(0);
-        }
-      }
-      STAMP();
-      if (!(a.dbg & 4))
-        conv_epilogue_rows_nb(a, acc, n, cg, f0, t0 + 32 * wave, lane, s_red + (ti & 1) * (4 * COP * 2) + wave * (COP * 2));
-      STAMP();
-      if (stamp) a.dbg_buf[63] = si;
+        STAMP();
+        if (!(a.dbg & 4))
+          conv_epilogue_rows_nb(a, acc, n, cg, f0, t0 + 32 * wave, lane, s_red + (ti & 1) * (4 * COP * 2) + wave * (COP * 2));
+        STAMP();
+        if (stamp) a.dbg_buf[63] = si;
 #undef STAMP
-      ++ti;
-      k += (unsigned)nslots;
-      if (k >= nk) break;
-      TILE_COORDS(k)
+        ++ti;
+        k += (unsigned)nslots;
+        if (k >= nk) break;
+        TILE_COORDS(k)
+      }
     }
     __syncthreads();                                           // final barrier
   }

@@ -623,4 +623,95 @@ __device__ __forceinline__ void conv_epilogue_rows_nb(const ConvArgs& a, f32x16_
 }
 
 
+// ---- deferred tile epilogue of the persistent kernel: ELU + statistics + bf16 split + stores of the PREVIOUS tile, cut
+// into pieces that run between the MFMAs of the current tile (one call per MFMA step, st compile-time after unrolling).
+// Row ROW of the previous tile is handled during K-chunk ROW of the current one:
+//   pieces 0-7  : element pair q: ELU in place, statistics
+//   piece  8/10 : bf16 hi/lo split of elements 0-7 / 8-15      piece 9/11: half-wave swaps + the two 16-byte stores
+//   pieces 12-14 (row 3 only): the two reduce-scatters of the tile's statistics, partials to LDS
+// State lives in the caller: prev (accumulators of the previous tile, bias included), s1/s2, per-row mask pm and store
+// offset pvo, and the pack registers PH/PL.  Everything is branch-free except the store predicates.
+struct EpiState {
+  f32x2_e s1[8], s2[8];
+  float pmt;                // 1 if this lane's frame of the previous tile exists (t < T), else 0
+  unsigned pvo0;            // byte offset of (row 0, this lane's frame) in the octet plane of the lane's half-wave
+  int prows;                // rows of the previous tile that exist (uniform: min(4, Fout - f0), 0 = no previous tile)
+  unsigned prow_b;          // bytes per output row (Tp * 16)
+  unsigned PH[2][2], PL[2][2];
+  bool okk0, okk1;          // this lane's octet of pair 0 / 1 exists (Cout)
+};
+
+template <int ROW, int NSTEP>
+__device__ __forceinline__ void conv_epi_step(int st, f32x16_t (&prev)[4], EpiState& e, const __amdgpu_buffer_rsrc_t rs_h,
+                                              const __amdgpu_buffer_rsrc_t rs_l, unsigned P16, float* s_red_w,
+                                              int lane) {
+  constexpr int NPIECE = 12;
+  constexpr int PP = (NPIECE + NSTEP - 1) / NSTEP;
+  const f32x2_e kl2e = {1.4426950408889634f, 1.4426950408889634f};
+  const f32x2_e kone = {1.f, 1.f};
+#pragma unroll
+  for (int pi = 0; pi < PP; ++pi) {
+    const int q = st * PP + pi;
+    if (q < 8) {
+      f32x2_e x = {prev[ROW][2 * q], prev[ROW][2 * q + 1]};
+      f32x2_e ex = x * kl2e;
+      ex.x = __builtin_amdgcn_exp2f(ex.x);
+      ex.y = __builtin_amdgcn_exp2f(ex.y);
+      ex = ex - kone;
+      x.x = x.x > 0.f ? x.x : ex.x;
+      x.y = x.y > 0.f ? x.y : ex.y;
+      prev[ROW][2 * q] = x.x; prev[ROW][2 * q + 1] = x.y;
+      const float mr = (ROW < e.prows) ? e.pmt : 0.f;
+      const f32x2_e m2 = {mr, mr};
+      const f32x2_e vm = x * m2;
+      e.s1[q] = e.s1[q] + vm;
+      e.s2[q] = vm * vm + e.s2[q];
+    } else if (q == 8 || q == 10) {
+      const int b = (q == 8) ? 0 : 8;
+      split_pair_t(prev[ROW][b + 0], prev[ROW][b + 1], e.PH[0][0], e.PL[0][0]);
+      split_pair_t(prev[ROW][b + 2], prev[ROW][b + 3], e.PH[0][1], e.PL[0][1]);
+      split_pair_t(prev[ROW][b + 4], prev[ROW][b + 5], e.PH[1][0], e.PL[1][0]);
+      split_pair_t(prev[ROW][b + 6], prev[ROW][b + 7], e.PH[1][1], e.PL[1][1]);
+    } else if (q == 9 || q == 11) {
+      const int k = (q == 9) ? 0 : 1;
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        auto rh = __builtin_amdgcn_permlane32_swap(e.PH[0][d], e.PH[1][d], false, false);
+        e.PH[0][d] = rh[0]; e.PH[1][d] = rh[1];
+        auto rl = __builtin_amdgcn_permlane32_swap(e.PL[0][d], e.PL[1][d], false, false);
+        e.PL[0][d] = rl[0]; e.PL[1][d] = rl[1];
+      }
+      const u32x4_t uh = {e.PH[0][0], e.PH[0][1], e.PH[1][0], e.PH[1][1]};
+      const u32x4_t ul = {e.PL[0][0], e.PL[0][1], e.PL[1][0], e.PL[1][1]};
+      if (ROW < e.prows && e.pmt != 0.f && (k == 0 ? e.okk0 : e.okk1)) {
+        const unsigned off = e.pvo0 + (unsigned)ROW * e.prow_b + (unsigned)(2 * k) * P16;
+        __builtin_amdgcn_raw_buffer_store_b128(uh, rs_h, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(ul, rs_l, off, 0, 0);
+      }
+    }
+  }
+}
+
+// statistics of the previous tile: reduce-scatter over the half-waves, partials to LDS, accumulators reset.  Called once
+// per tile right after the MFMA loop of K-chunk 3 (not interleaved: its temporaries would not fit the register budget).
+__device__ __forceinline__ void conv_epi_reduce(EpiState& e, float* s_red_w, int lane) {
+  float f1[16], f2[16];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    f1[2 * i] = e.s1[i].x; f1[2 * i + 1] = e.s1[i].y;
+    f2[2 * i] = e.s2[i].x; f2[2 * i + 1] = e.s2[i].y;
+  }
+  const float x1 = reduce16_halfwave(f1, lane);
+  const float x2 = reduce16_halfwave(f2, lane);
+  if ((lane & 16) == 0) {
+    const int qq = lane & 15;
+    const int co_l = (qq & 3) + 8 * (qq >> 2) + 4 * (lane >> 5);
+    s_red_w[co_l * 2 + 0] = x1;
+    s_red_w[co_l * 2 + 1] = x2;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { e.s1[i] = f32x2_e{0.f, 0.f}; e.s2[i] = f32x2_e{0.f, 0.f}; }
+}
+
+
 }  // namespace mn
