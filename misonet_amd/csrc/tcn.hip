@@ -122,17 +122,21 @@ __global__ __launch_bounds__(256) void tcn_dw_k(const float* x, const double* x_
 
 // y[co][t] = sum_ci W[co][ci] * (gamma[ci] * (d[ci][t] - mean_n) * rstd_n + beta[ci])  (+ residual[co][t])
 // C must be 128.  Workgroup: 128 output channels x 128 frames; wave w owns channels 32w..32w+31 and four 32-frame
-// tiles (fp32 MFMA 32x32x2, exact).  K is consumed in 4 chunks of 32 input channels; per chunk every thread stages
-// 4 float4 of gLN-normalised input and 4 float4 of the transposed weights (unrolled, all loads issued first).
+// tiles (fp32 MFMA 32x32x2, exact).  K is consumed in 8 chunks of 16 input channels through two LDS buffers: the global
+// loads of chunk k+1 are issued before the MFMAs of chunk k and committed (gLN applied) after them, one barrier per
+// chunk (32 KB of LDS, <= 170 VGPRs: three workgroups per CU).  Epilogue: the residual tile is loaded with 64 buffer
+// loads issued together, stores are buffer stores with an
+// out-of-range offset for frames >= T (dropped by the hardware), statistics go through the reduce-scatter of
+// conv_epilogue.hpp.
 constexpr int PW_TT = 128;
-constexpr int PW_KC = 32;
+constexpr int PW_KC = 16;
 __global__ __launch_bounds__(256) void tcn_pw_k(const float* d, const double* gln_stats, const float* gamma,
                                                 const float* beta, const float* wt /*[ci][co]*/,
                                                 const float* residual, float* y, long long y_bstride, int y_c0,
                                                 double* y_stats, int T, int Tp) {
   constexpr int C = 128;
-  __shared__ __align__(16) float s_g[PW_KC][PW_TT];
-  __shared__ __align__(16) float s_w[PW_KC][C];
+  __shared__ __align__(16) float s_g[2][PW_KC][PW_TT];
+  __shared__ __align__(16) float s_w[2][PW_KC][C];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int t0 = blockIdx.x * PW_TT, n = blockIdx.y;
@@ -150,76 +154,112 @@ __global__ __launch_bounds__(256) void tcn_pw_k(const float* d, const double* gl
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
 
-  // staging roles: thread (q = tid & 31 -> frames 4q..4q+3, g = tid >> 5 -> channels g, g+8, g+16, g+24 of the chunk)
+  // staging roles: thread (q = tid & 31 -> frames 4q..4q+3, g = tid >> 5 -> channels g, g+8 of the chunk)
   const int sq = tid & 31, sg = tid >> 5;
   const int tg = t0 + 4 * sq;
   const bool tok = tg < Tp;
-
-  for (int k0 = 0; k0 < C; k0 += PW_KC) {
-    float4 gi[4], wi[4];
-    float ga[4], be[4];
+  float4 gi[2], wi[2];
+  float ga[2], be[2];
+#define PW_ISSUE(K0)                                                                                             \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
+    const int ci = (K0) + sg + 8 * i;                                                                            \
+    gi[i] = tok ? *reinterpret_cast<const float4*>(dn + (long long)ci * Tp + tg) : make_float4(0.f, 0.f, 0.f, 0.f); \
+    wi[i] = *reinterpret_cast<const float4*>(wt + (long long)ci * C + 4 * sq);                                   \
+    ga[i] = gamma[ci] * rstd;                                                                                    \
+    be[i] = beta[ci] - gamma[ci] * rstd * mean;                                                                  \
+  }
+#define PW_COMMIT(BUF)                                                                                           \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
+    float4 v;                                                                                                    \
+    v.x = (tg + 0 < T) ? fmaf(gi[i].x, ga[i], be[i]) : 0.f;                                                      \
+    v.y = (tg + 1 < T) ? fmaf(gi[i].y, ga[i], be[i]) : 0.f;                                                      \
+    v.z = (tg + 2 < T) ? fmaf(gi[i].z, ga[i], be[i]) : 0.f;                                                      \
+    v.w = (tg + 3 < T) ? fmaf(gi[i].w, ga[i], be[i]) : 0.f;                                                      \
+    *reinterpret_cast<float4*>(&s_g[BUF][sg + 8 * i][4 * sq]) = v;                                               \
+    *reinterpret_cast<float4*>(&s_w[BUF][sg + 8 * i][4 * sq]) = wi[i];                                           \
+  }
+  PW_ISSUE(0)
+  PW_COMMIT(0)
+  __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int ci = k0 + sg + 8 * i;
-      gi[i] = tok ? *reinterpret_cast<const float4*>(dn + (long long)ci * Tp + tg) : make_float4(0.f, 0.f, 0.f, 0.f);
-      wi[i] = *reinterpret_cast<const float4*>(wt + (long long)(k0 + sg + 8 * i) * C + 4 * sq);
-      ga[i] = gamma[ci] * rstd;
-      be[i] = beta[ci] - gamma[ci] * rstd * mean;
-    }
-    __syncthreads();                       // previous chunk consumed
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float4 v;
-      v.x = (tg + 0 < T) ? fmaf(gi[i].x, ga[i], be[i]) : 0.f;
-      v.y = (tg + 1 < T) ? fmaf(gi[i].y, ga[i], be[i]) : 0.f;
-      v.z = (tg + 2 < T) ? fmaf(gi[i].z, ga[i], be[i]) : 0.f;
-      v.w = (tg + 3 < T) ? fmaf(gi[i].w, ga[i], be[i]) : 0.f;
-      *reinterpret_cast<float4*>(&s_g[sg + 8 * i][4 * sq]) = v;
-      *reinterpret_cast<float4*>(&s_w[sg + 8 * i][4 * sq]) = wi[i];
-    }
-    __syncthreads();
+  for (int kc = 0; kc < C / PW_KC; ++kc) {
+    const int buf = kc & 1;
+    if (kc + 1 < C / PW_KC) PW_ISSUE((kc + 1) * PW_KC)
 #pragma unroll
     for (int kk = 0; kk < PW_KC; kk += 2) {
-      const float av = s_w[kk + half][wave * 32 + l31];
+      const float av = s_w[buf][kk + half][wave * 32 + l31];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const float bv = s_g[kk + half][s * 32 + l31];
+        const float bv = s_g[buf][kk + half][s * 32 + l31];
         acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[s], 0, 0, 0);
+      }
+    }
+    if (kc + 1 < C / PW_KC) {
+      PW_COMMIT(buf ^ 1)
+      __syncthreads();
+    }
+  }
+#undef PW_ISSUE
+#undef PW_COMMIT
+
+  // ---- epilogue ----
+  // residual tile: this lane's (channel, frame) elements in accumulator order, all loads issued together
+  float rv[4][16];
+  const float* rn = residual ? residual + (long long)n * C * Tp : nullptr;
+  {
+    const unsigned long long pa = reinterpret_cast<unsigned long long>(rn ? rn : dn);
+    const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pa);
+    const unsigned phi = __builtin_amdgcn_readfirstlane((unsigned)(pa >> 32));
+    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void*>(((unsigned long long)phi << 32) | plo), 0,
+        __builtin_amdgcn_readfirstlane(rn ? (int)((unsigned)C * (unsigned)Tp * 4u) : 0), 0x00020000);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int t = t0 + s * 32 + l31;
+      const unsigned vo = (t < T) ? (unsigned)((wave * 32 + 4 * half) * Tp + t) * 4u : 0x80000000u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co_off = (r & 3) + 8 * (r >> 2);
+        rv[s][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, vo + (unsigned)(co_off * Tp) * 4u, 0, 0));
       }
     }
   }
 
   float* yn = y + (long long)n * y_bstride + (long long)y_c0 * Tp;
-  const float* rn = residual ? residual + (long long)n * C * Tp : nullptr;
+  const unsigned long long pa = reinterpret_cast<unsigned long long>(yn);
+  const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pa);
+  const unsigned phi = __builtin_amdgcn_readfirstlane((unsigned)(pa >> 32));
+  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<void*>(((unsigned long long)phi << 32) | plo), 0,
+      __builtin_amdgcn_readfirstlane((int)((unsigned)C * (unsigned)Tp * 4u)), 0x00020000);
   float s1[16], s2[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int t = t0 + s * 32 + l31;
+    const bool ok = t < T;
+    const float m = ok ? 1.f : 0.f;
+    const unsigned vo = ok ? (unsigned)((wave * 32 + 4 * half) * Tp + t) * 4u : 0x80000000u;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int co = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (t < T) {
-        float v = acc[s][r];
-        if (rn) v += rn[(long long)co * Tp + t];
-        yn[(long long)co * Tp + t] = v;
-        s1[r] += v;
-        s2[r] = fmaf(v, v, s2[r]);
-      }
+      const int co_off = (r & 3) + 8 * (r >> 2);
+      const float v = acc[s][r] + rv[s][r];
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, vo + (unsigned)(co_off * Tp) * 4u, 0, 0);
+      const float vm = v * m;
+      s1[r] += vm;
+      s2[r] = fmaf(vm, vm, s2[r]);
     }
   }
   if (y_stats) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float x1 = half_wave_sum(s1[r]);
-      const float x2 = half_wave_sum(s2[r]);
-      if (l31 == 31) {
-        const int co = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        double* o = y_stats + ((long long)n * C + co) * 2;
-        unsafeAtomicAdd(o + 0, (double)x1);
-        unsafeAtomicAdd(o + 1, (double)x2);
-      }
+    const float x1 = reduce16_halfwave(s1, lane);
+    const float x2 = reduce16_halfwave(s2, lane);
+    if ((lane & 16) == 0) {
+      const int q = lane & 15;
+      const int co = wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
+      double* o = y_stats + ((long long)n * C + co) * 2;
+      unsafeAtomicAdd(o + 0, (double)x1);
+      unsafeAtomicAdd(o + 1, (double)x2);
     }
   }
 }
