@@ -387,8 +387,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
   const int half = lane >> 5, l31 = lane & 31;
   const int T = a.T, Tp = a.Tp, Fin = a.Fin, Cin = a.Cin;
   const int nchunk = (Cin + CKB - 1) / CKB;
-  // deferred epilogue: rows 0-3 of a finished tile are post-processed during K-chunks 0-3 of the next tile
-  const bool deferred = nchunk >= 4 && a.act && a.out_oct && !(a.dbg & 32);
+  // deferred epilogue: rows 0-1 of a finished tile are post-processed during K-chunks 0-1 of the next tile
+  const bool deferred = nchunk >= 2 && a.act && a.out_oct && !(a.dbg & 32);
 
   const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
   const unsigned per = (unsigned)(a.ntx * a.nty * a.ncg);                    // tiles per sample
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
     TILE_TABLES(0)
     unsigned g = 0, ti = 0;
     // finished tiles whose statistics are still to be flushed: p1 = previous tile, p2 = the one before.  With the
-    // deferred epilogue the partials of tile j are complete only after chunk 3 of tile j + 1.
+    // deferred epilogue the partials of tile j are complete only after chunk 1 of tile j + 1.
     int p1_n = 0, p1_cg = 0, p2_n = 0, p2_cg = 0;
     for (;;) {
       bool more = false;
@@ -606,14 +606,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
           }                                                                                                     \
           ++g;                                                                                                  \
         }
+        static_assert(NDEF == 2, "chunk schedule below is written for two deferred rows");
         RUN_CHUNK(0)
-        RUN_CHUNK(NDEF > 1 ? 1 : -1)
-        if (NDEF == 2) conv_epi_reduce(es, sred_prev, lane);
-        RUN_CHUNK(NDEF > 2 ? 2 : -1)
-        if (NDEF == 3) conv_epi_reduce(es, sred_prev, lane);
-        RUN_CHUNK(NDEF > 3 ? 3 : -1)
-        if (NDEF == 4) conv_epi_reduce(es, sred_prev, lane);
-        for (int kc = 4; kc < nchunk; ++kc) RUN_CHUNK(-1)
+        RUN_CHUNK(1)
+        conv_epi_reduce(es, sred_prev, lane);
+        for (int kc = 2; kc < nchunk; ++kc) RUN_CHUNK(-1)
         // ---- the finished tile: rows NDEF..3 now, rows 0..NDEF-1 become the "previous tile" ----
         {
           const int tw = t0 + 32 * wave;
@@ -653,14 +650,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
         for (int stp = 0; stp < 3 * NR; ++stp) conv_epi_step<0, 3 * NR>(stp, prev, es, prs_h, prs_l, OP16, sred_prev, lane);
 #pragma unroll
         for (int stp = 0; stp < 3 * NR; ++stp) conv_epi_step<1, 3 * NR>(stp, prev, es, prs_h, prs_l, OP16, sred_prev, lane);
-        if (NDEF > 2) {
-#pragma unroll
-          for (int stp = 0; stp < 3 * NR; ++stp) conv_epi_step<2, 3 * NR>(stp, prev, es, prs_h, prs_l, OP16, sred_prev, lane);
-        }
-        if (NDEF > 3) {
-#pragma unroll
-          for (int stp = 0; stp < 3 * NR; ++stp) conv_epi_step<3, 3 * NR>(stp, prev, es, prs_h, prs_l, OP16, sred_prev, lane);
-        }
         conv_epi_reduce(es, sred_prev, lane);
       }
 #undef RUN_CHUNK
