@@ -732,32 +732,50 @@ __global__ __launch_bounds__(288) void conv_wprep_k(const float* wf, const doubl
   unsigned short* wdst = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(wps) + (long long)n * wps_nstride_b) +
                          (long long)cg * nchunk * (2 * 9 * 2 * 32 * 8);
   double bsum = 0.0;
-  for (int kc = 0; kc < nchunk; ++kc) {
+  constexpr int U = 4;                               // chunks per batch: all 16 loads of a batch are issued together
+  for (int kc0 = 0; kc0 < nchunk; kc0 += U) {
+    float4 wl[U][2][2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int unit = (tap * 2 + h) * 32 + co;
-      const float4* src = reinterpret_cast<const float4*>(wsrc + ((long long)kc * (9 * 2 * 32) + unit) * 8);
-      const float4 w0 = src[0], w1 = src[1];
-      const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-      float ws[8];
-      float bs = 0.f;
+    for (int u = 0; u < U; ++u) {
+      const int kc = (kc0 + u < nchunk) ? kc0 + u : nchunk - 1;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float2 m = s_nrm[kc * CKB + h * 8 + e];
-        ws[e] = wv[e] * m.x;
-        bs = fmaf(wv[e], m.y, bs);
+      for (int h = 0; h < 2; ++h) {
+        const int unit = (tap * 2 + h) * 32 + co;
+        const float4* src = reinterpret_cast<const float4*>(wsrc + ((long long)kc * (9 * 2 * 32) + unit) * 8);
+        wl[u][h][0] = src[0];
+        wl[u][h][1] = src[1];
       }
-      bsum += (double)bs;
-      u32x4_t hi, lo;
+    }
 #pragma unroll
-      for (int e2 = 0; e2 < 4; ++e2) {
-        unsigned a_, b_;
-        split_pair_t(ws[2 * e2], ws[2 * e2 + 1], a_, b_);
-        hi[e2] = a_; lo[e2] = b_;
+    for (int u = 0; u < U; ++u) {
+      const int kc = kc0 + u;
+      if (kc < nchunk) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int unit = (tap * 2 + h) * 32 + co;
+          const float4 w0 = wl[u][h][0], w1 = wl[u][h][1];
+          const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+          float ws[8];
+          float bs = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float2 m = s_nrm[kc * CKB + h * 8 + e];
+            ws[e] = wv[e] * m.x;
+            bs = fmaf(wv[e], m.y, bs);
+          }
+          bsum += (double)bs;
+          u32x4_t hi, lo;
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) {
+            unsigned a_, b_;
+            split_pair_t(ws[2 * e2], ws[2 * e2 + 1], a_, b_);
+            hi[e2] = a_; lo[e2] = b_;
+          }
+          u32x4_t* d = reinterpret_cast<u32x4_t*>(wdst + (long long)kc * (2 * 9 * 2 * 32 * 8));
+          d[unit] = hi;
+          d[9 * 2 * 32 + unit] = lo;
+        }
       }
-      u32x4_t* d = reinterpret_cast<u32x4_t*>(wdst + (long long)kc * (2 * 9 * 2 * 32 * 8));
-      d[unit] = hi;
-      d[9 * 2 * 32 + unit] = lo;
     }
   }
   btab[(long long)n * btab_nstride + (long long)(cg * 32 + co) * 9 + tap] = (float)bsum;
