@@ -278,9 +278,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_dma(const ConvArgs a) {
 // kernel), so the weight fragments are read from LDS on the fly, single-buffered: fragment (kt, kf) is reloaded with the
 // next time tap's weights in the first step after its last use, which is at least one full step before its next use.
 //   use(fr, kf, R): output row fr takes tap kf from staged input row R.
+// The tile has FTR output rows (4; 2 for the stride-2 layers, whose 4-row tile would need 9 staged input rows).
 template <int SF, bool TR2>
 __device__ __forceinline__ constexpr bool mfma_use(int fr, int kf, int R) {
-  return TR2 ? ((((fr + kf) & 1) == 0) && (((fr + kf) >> 1) == R)) : (SF * fr + kf == R);
+  constexpr int FTR = (SF == 2) ? 2 : 4;
+  return fr < FTR && (TR2 ? ((((fr + kf) & 1) == 0) && (((fr + kf) >> 1) == R)) : (SF * fr + kf == R));
 }
 template <int NR, int SF, bool TR2>
 __device__ __forceinline__ constexpr int mfma_last_r(int kf) {        // last staged row that uses tap kf
@@ -365,9 +367,10 @@ template <int MODE>
 __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, int nslots) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int COP = 32;
-  constexpr int NR = MODE == 0 ? 6 : 3;
-  constexpr int SF = 1;
+  constexpr int SF = MODE == 1 ? 2 : 1;
   constexpr bool TR2 = MODE == 2;
+  constexpr int FTR = MODE == 1 ? 2 : 4;             // output rows per tile
+  constexpr int NR = MODE == 0 ? 6 : (MODE == 1 ? 5 : 3);   // staged input rows: SF * (FTR - 1) + 3, or 3 (transposed)
   constexpr int NPAIR = 2 * NR;
   constexpr int XN = NPAIR * TW;                     // 16-byte units per input image (hi or lo)
   constexpr int WN = 9 * 2 * COP;                    // 16-byte units per weight image (hi or lo)
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
     t0 = (int)(tile_ % (unsigned)a.ntx) * TT;                                                                   \
     tile_ /= (unsigned)a.ntx;                                                                                   \
     cg = (int)(tile_ % (unsigned)a.ncg);                                                                        \
-    f0 = (int)(tile_ / (unsigned)a.ncg) * FT;                                                                   \
+    f0 = (int)(tile_ / (unsigned)a.ncg) * FTR;                                                                  \
   }
 
   if (producer) {
@@ -617,7 +620,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
           const int t = tw + l31;
           const int cbase = cg * COP;
           es.pmt = (t < T) ? 1.f : 0.f;
-          es.prows = (a.Fout - f0) < 4 ? (a.Fout - f0) : 4;
+          es.prows = (a.Fout - f0) < FTR ? (a.Fout - f0) : FTR;
           es.pvo0 = (unsigned)(f0 * Tp + t) * 16u + (unsigned)(half + (cbase >> 3)) * OP16;
           es.okk0 = cbase + (0 + half) * 8 < a.Cout;
           es.okk1 = cbase + (2 + half) * 8 < a.Cout;
@@ -627,11 +630,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
           prs_h = make_rsrc_u(pa, nrec);
           prs_l = make_rsrc_u(pa + (unsigned long long)(a.out_sstride >> 3) * OP16, nrec);
           float* sred_cur = s_red + (ti & 1) * (4 * COP * 2) + wave * (COP * 2);
-          if (NDEF <= 2) {
+          if (NDEF <= 2 && FTR > 2) {
 #pragma unroll
             for (int stp = 0; stp < 3 * NR; ++stp) conv_epi_step<2, 3 * NR>(stp, acc, es, prs_h, prs_l, OP16, sred_cur, lane);
           }
-          if (NDEF <= 3) {
+          if (NDEF <= 3 && FTR > 3) {
 #pragma unroll
             for (int stp = 0; stp < 3 * NR; ++stp) conv_epi_step<3, 3 * NR>(stp, acc, es, prs_h, prs_l, OP16, sred_cur, lane);
           }
@@ -683,7 +686,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
         }
         STAMP();
         if (!(a.dbg & 4))
-          conv_epilogue_rows_nb(a, acc, n, cg, f0, t0 + 32 * wave, lane, s_red + (ti & 1) * (4 * COP * 2) + wave * (COP * 2));
+          conv_epilogue_rows_nb(a, acc, n, cg, f0, t0 + 32 * wave, lane, s_red + (ti & 1) * (4 * COP * 2) + wave * (COP * 2), FTR);
         STAMP();
         if (stamp) a.dbg_buf[63] = si;
 #undef STAMP
@@ -802,6 +805,8 @@ hipError_t conv_bf16_dma_init() {
   if ((e = dma_set_attr<2>()) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x3_dma2<0>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x3_dma2<1>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x3_dma2<2>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
@@ -846,7 +851,11 @@ hipError_t launch_conv_bf16_dma(const ConvArgs& a_in, int n_samples, hipStream_t
   }
   static int dma2_env = -1;
   if (dma2_env < 0) { const char* e = getenv("MISONET_DMA2"); dma2_env = e ? atoi(e) : 1; }
-  if (dma2_env && mode != 1) {
+  const int nchunk_l = (a.Cin + CKB - 1) / CKB;
+  // stride-2 layers run the pipelined kernel on 2-row tiles (5 staged rows; 9 rows x two stages do not fit the LDS)
+  const bool dma2_ok = mode != 1 || (nchunk_l >= 2 && a.act && a.out_oct);
+  if (dma2_env && dma2_ok) {
+    if (mode == 1) (void)conv_grid(a, n_samples, TT, 2, 1);          // tile geometry with 2 output rows
     // persistent launch: one workgroup per CU, capped by the largest per-XCD tile list
     static int g_cus = 0;
     if (!g_cus) {
@@ -860,8 +869,9 @@ hipError_t launch_conv_bf16_dma(const ConvArgs& a_in, int n_samples, hipStream_t
     if (nslots < 1) nslots = 1;
     if (nslots > nk_max) nslots = (int)nk_max;
     const dim3 pgrid((unsigned)(8 * nslots), 1, 1);
-    const size_t lds2 = dma2_lds_bytes(a.NR);
+    const size_t lds2 = dma2_lds_bytes(mode == 1 ? 5 : a.NR);
     if (mode == 0) hipLaunchKernelGGL((conv3x3_bf16x3_dma2<0>), pgrid, dim3(512), lds2, s, a, nslots);
+    else if (mode == 1) hipLaunchKernelGGL((conv3x3_bf16x3_dma2<1>), pgrid, dim3(512), lds2, s, a, nslots);
     else hipLaunchKernelGGL((conv3x3_bf16x3_dma2<2>), pgrid, dim3(512), lds2, s, a, nslots);
   } else if (mode == 0) hipLaunchKernelGGL((conv3x3_bf16x3_dma<0>), grid, dim3(256), lds, s, a);
   else if (mode == 1) hipLaunchKernelGGL((conv3x3_bf16x3_dma<1>), grid, dim3(256), lds, s, a);

@@ -498,7 +498,7 @@ template <bool MASKED, bool ACT>
 __device__ __forceinline__ void conv_epilogue_rows_nb_impl(const ConvArgs& a, f32x16_t (&acc)[4], int cg, int f0, int tw,
                                                            int lane, const __amdgpu_buffer_rsrc_t rs_h,
                                                            const __amdgpu_buffer_rsrc_t rs_l, f32x2_e (&s1)[8],
-                                                           f32x2_e (&s2)[8]) {
+                                                           f32x2_e (&s2)[8], int rows) {
   constexpr int COP = 32;
   const int half = lane >> 5, l31 = lane & 31;
   const int T = a.T, Tp = a.Tp;
@@ -513,7 +513,7 @@ __device__ __forceinline__ void conv_epilogue_rows_nb_impl(const ConvArgs& a, f3
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int f = f0 + r;
-    const bool ok = !MASKED || ((f < a.Fout) && (t < T));
+    const bool ok = !MASKED || ((f < a.Fout) && (t < T) && (r < rows));
     const float mf = ok ? 1.f : 0.f;
     const f32x2_e m2 = {mf, mf};
     float v[16];
@@ -570,11 +570,12 @@ __device__ __forceinline__ void conv_epilogue_rows_nb_impl(const ConvArgs& a, f3
   }
 }
 
+// rows: output rows of the tile (4, or 2 for the stride-2 layers)
 __device__ __forceinline__ void conv_epilogue_rows_nb(const ConvArgs& a, f32x16_t (&acc)[4], int n, int cg, int f0, int tw,
-                                                      int lane, float* s_red) {
+                                                      int lane, float* s_red, int rows = 4) {
   const int half = lane >> 5;
   const int T = a.T, Tp = a.Tp;
-  const bool fast = (tw + 32 <= T) && (f0 + 4 <= a.Fout);                   // uniform: all 32 frames and 4 rows exist
+  const bool fast = (tw + 32 <= T) && (f0 + 4 <= a.Fout) && rows == 4;      // uniform: all 32 frames and 4 rows exist
   f32x2_e s1[8], s2[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { s1[i] = f32x2_e{0.f, 0.f}; s2[i] = f32x2_e{0.f, 0.f}; }
@@ -601,10 +602,10 @@ __device__ __forceinline__ void conv_epilogue_rows_nb(const ConvArgs& a, f32x16_
       reinterpret_cast<void*>(((unsigned long long)pb_hi << 32) | pb_lo), 0, nrec_s, 0x00020000);
 
   if (a.act) {
-    if (fast) conv_epilogue_rows_nb_impl<false, true>(a, acc, cg, f0, tw, lane, rs_h, rs_l, s1, s2);
-    else conv_epilogue_rows_nb_impl<true, true>(a, acc, cg, f0, tw, lane, rs_h, rs_l, s1, s2);
+    if (fast) conv_epilogue_rows_nb_impl<false, true>(a, acc, cg, f0, tw, lane, rs_h, rs_l, s1, s2, rows);
+    else conv_epilogue_rows_nb_impl<true, true>(a, acc, cg, f0, tw, lane, rs_h, rs_l, s1, s2, rows);
   } else {
-    conv_epilogue_rows_nb_impl<true, false>(a, acc, cg, f0, tw, lane, rs_h, rs_l, s1, s2);
+    conv_epilogue_rows_nb_impl<true, false>(a, acc, cg, f0, tw, lane, rs_h, rs_l, s1, s2, rows);
   }
 
   if (a.act && !(a.dbg & 16)) {
