@@ -81,7 +81,8 @@ __global__ __launch_bounds__(256) void mvdr_scm_eig(const MvdrArgs a, double* ws
   float ps[NT][2], pn[NT][2];
 #pragma unroll
   for (int i = 0; i < NT; ++i) { ps[i][0] = ps[i][1] = pn[i][0] = pn[i][1] = 0.f; }
-  for (int t = tid; t < a.T; t += 256) {
+  const int nthr = blockDim.x, nw = nthr >> 6;
+  for (int t = tid; t < a.T; t += nthr) {
     float xr[M], xi[M], nr[M], ni[M];
 #pragma unroll
     for (int m = 0; m < M; ++m) {
@@ -121,10 +122,12 @@ __global__ __launch_bounds__(256) void mvdr_scm_eig(const MvdrArgs a, double* ws
   __syncthreads();
   const double invT = 1.0 / (double)a.T;
   const long long idx = ((long long)(b * a.S + spk) * a.F + f);
-  if (tid < 2 * NT * 2) {
-    const double v = (s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid]) * invT;
-    const int which = tid / (2 * NT);          // 0: Phi_s, 1: Phi_n
-    const int kc = tid - which * 2 * NT;
+  for (int e = tid; e < 2 * NT * 2; e += nthr) {
+    double v = 0.0;
+    for (int w = 0; w < nw; ++w) v += s_part[w][e];
+    v *= invT;
+    const int which = e / (2 * NT);            // 0: Phi_s, 1: Phi_n
+    const int kc = e - which * 2 * NT;
     const int k = kc >> 1, c = kc & 1;
     // k -> (i, j), i >= j
     int i = 0, rem = k;
@@ -140,14 +143,17 @@ __global__ __launch_bounds__(256) void mvdr_scm_eig(const MvdrArgs a, double* ws
       if (i != j) pn_o[(j * M + i) * 2 + c] = c ? -v : v;
     }
   }
-  if (tid < M * M) {
-    const int i = tid / M, j = tid - i * M;
+  for (int e = tid; e < M * M; e += nthr) {
+    const int i = e / M, j = e - i * M;
     s_V[i][j][0] = (i == j) ? 1.0 : 0.0;
     s_V[i][j][1] = 0.0;
   }
   __syncthreads();
-  if (tid == 0) {
-    // cyclic complex Jacobi on the Hermitian s_A; eigenvectors accumulate in the columns of s_V
+  // cyclic complex Jacobi on the Hermitian s_A; eigenvectors accumulate in the columns of s_V.  The workgroup is one wave:
+  // lane k < M owns index k of the three M-long update loops of a rotation (columns of A, columns of V, rows of A), every
+  // lane recomputes the rotation itself from the same LDS values, so control flow stays uniform and each matrix element
+  // sees exactly the arithmetic of the sequential algorithm.
+  {
     double scale = 0.0;
     for (int i = 0; i < M; ++i) scale += fabs(s_A[i][i][0]);
     for (int sweep = 0; sweep < 16; ++sweep) {
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(256) void mvdr_scm_eig(const MvdrArgs a, double* ws
         for (int q = p + 1; q < M; ++q) {
           const cd apq = {s_A[p][q][0], s_A[p][q][1]};
           const double g = sqrt(cabs2(apq));
-          if (g <= 1e-300) continue;
+          if (g <= 1e-300) continue;                       // uniform: every lane reads the same element
           const double app = s_A[p][p][0], aqq = s_A[q][q][0];
           const double tau = (aqq - app) / (2.0 * g);
           const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
@@ -168,7 +174,9 @@ __global__ __launch_bounds__(256) void mvdr_scm_eig(const MvdrArgs a, double* ws
           // R restricted to (p,q): Rpp = c, Rpq = s, Rqp = -s e^{-i phi}, Rqq = c e^{-i phi}
           const cd Rpp = {cs, 0.0}, Rpq = {sn, 0.0};
           const cd Rqp = {-sn * ph.re, sn * ph.im}, Rqq = {cs * ph.re, -cs * ph.im};
-          for (int k = 0; k < M; ++k) {                  // A <- A R (columns p, q)
+          __syncthreads();                                 // every lane has read the pivot before anyone overwrites it
+          if (tid < M) {                                   // A <- A R (columns p, q), V <- V R: row k = tid
+            const int k = tid;
             const cd akp = {s_A[k][p][0], s_A[k][p][1]}, akq = {s_A[k][q][0], s_A[k][q][1]};
             const cd np_ = cadd(cmul(akp, Rpp), cmul(akq, Rqp));
             const cd nq_ = cadd(cmul(akp, Rpq), cmul(akq, Rqq));
@@ -180,19 +188,27 @@ __global__ __launch_bounds__(256) void mvdr_scm_eig(const MvdrArgs a, double* ws
             s_V[k][p][0] = vp_.re; s_V[k][p][1] = vp_.im;
             s_V[k][q][0] = vq_.re; s_V[k][q][1] = vq_.im;
           }
-          for (int k = 0; k < M; ++k) {                  // A <- R^H A (rows p, q)
+          __syncthreads();
+          if (tid < M) {                                   // A <- R^H A (rows p, q): column k = tid
+            const int k = tid;
             const cd apk = {s_A[p][k][0], s_A[p][k][1]}, aqk = {s_A[q][k][0], s_A[q][k][1]};
             const cd np_ = cadd(cmul(cconj(Rpp), apk), cmul(cconj(Rqp), aqk));
             const cd nq_ = cadd(cmul(cconj(Rpq), apk), cmul(cconj(Rqq), aqk));
             s_A[p][k][0] = np_.re; s_A[p][k][1] = np_.im;
             s_A[q][k][0] = nq_.re; s_A[q][k][1] = nq_.im;
           }
-          s_A[p][q][0] = s_A[p][q][1] = 0.0;
-          s_A[q][p][0] = s_A[q][p][1] = 0.0;
-          s_A[p][p][1] = 0.0;
-          s_A[q][q][1] = 0.0;
+          __syncthreads();
+          if (tid == 0) {
+            s_A[p][q][0] = s_A[p][q][1] = 0.0;
+            s_A[q][p][0] = s_A[q][p][1] = 0.0;
+            s_A[p][p][1] = 0.0;
+            s_A[q][q][1] = 0.0;
+          }
+          __syncthreads();
         }
     }
+  }
+  if (tid == 0) {
     int best = 0;                                         // argmax eigenvalue, first on ties (tester.py:1110)
     for (int i = 1; i < M; ++i)
       if (s_A[i][i][0] > s_A[best][best][0]) best = i;
@@ -337,7 +353,9 @@ __global__ __launch_bounds__(256) void mvdr_apply(const MvdrArgs a, const COut o
 template <int M>
 static hipError_t mvdr_run(const MvdrArgs& a, const COut& out, double* ws, hipStream_t s) {
   dim3 g(a.F, a.B, a.S);
-  hipLaunchKernelGGL(mvdr_scm_eig<M>, g, dim3(256), 0, s, a, ws);
+  // one wave per (b, f, spk): the 6x6 Jacobi runs on one lane (~100 us of dependent float64 work), so what matters is
+  // how many of them are in flight per CU -- 8 single-wave workgroups instead of 2 four-wave ones
+  hipLaunchKernelGGL(mvdr_scm_eig<M>, g, dim3(64), 0, s, a, ws);
   hipLaunchKernelGGL(mvdr_solve<M>, dim3(a.B, a.S), dim3(256), (size_t)a.F * M * 2 * sizeof(double), s, a.B, a.S, a.F,
                      (double)a.epsi, ws);
   hipLaunchKernelGGL(mvdr_apply<M>, g, dim3(256), 0, s, a, out, (const double*)ws);
