@@ -532,7 +532,8 @@ __device__ __forceinline__ void conv_epilogue_rows_nb_impl(const ConvArgs& a, f3
       v[2 * i2] = x.x; v[2 * i2 + 1] = x.y;
       const f32x2_e vm = MASKED ? x * m2 : x;
       s1[i2] = s1[i2] + vm;
-      s2[i2] = vm * vm + s2[i2];
+      s2[i2].x = fmaf(vm.x, vm.x, s2[i2].x);
+      s2[i2].y = fmaf(vm.y, vm.y, s2[i2].y);
     }
     if (a.dbg & 8) continue;
     if (a.out_oct) {
@@ -666,7 +667,10 @@ __device__ __forceinline__ void conv_epi_step(int st, f32x16_t (&prev)[4], EpiSt
       const f32x2_e m2 = {mr, mr};
       const f32x2_e vm = x * m2;
       e.s1[q] = e.s1[q] + vm;
-      e.s2[q] = vm * vm + e.s2[q];
+      // explicit FMAs: with contraction left to the compiler the interleaved and the flush instantiation of this piece
+      // rounded differently, which made a tile's sum of squares depend on whether it was the last tile of its workgroup
+      e.s2[q].x = fmaf(vm.x, vm.x, e.s2[q].x);
+      e.s2[q].y = fmaf(vm.y, vm.y, e.s2[q].y);
     } else if (q == 8 || q == 10) {
       const int b = (q == 8) ? 0 : 8;
       split_pair_t(prev[ROW][b + 0], prev[ROW][b + 1], e.PH[0][0], e.PL[0][0]);
