@@ -47,7 +47,7 @@ def test_bf16x3_stage_taps(nets_bf, sd1):
     _assert_parity(y, g["y"], "bf16x3 miso1 T=32 vs reference golden")
 
 
-@pytest.mark.parametrize("B,T", [(1, 96), (2, 130), (3, 40), (1, 5)])
+@pytest.mark.parametrize("B,T", [(1, 96), (2, 130), (3, 40), (1, 5), (1, 128), (2, 257)])
 def test_bf16x3_forward_shapes(nets_bf, sd1, B, T):
     from oracle import miso_oracle
     m1, _ = nets_bf
@@ -115,3 +115,20 @@ def test_bf16x3_batch_invariance_and_repeatability(nets_bf):
     assert rel_l2(yb[0], y1[0]) < 1e-6
     yb2 = m1(xb).cpu().numpy()
     assert rel_l2(yb2, yb) < 1e-6
+
+
+def test_bf16x3_pipeline_batch_invariance(nets_bf):
+    """The whole MISO1 -> PIT -> MVDR -> MISO3 path on 9 utterances (54 + 18 network samples: every XCD's tile list holds
+    several) equals the same utterances run one by one, beamformer output and enhanced spectrogram alike."""
+    import misonet_amd as mz
+    m1, m3 = nets_bf
+    enh = mz.Enhancer(m1, m3, num_spks=2, ref_ch=0)
+    utts = [_utt_inputs(3 + (i % 3), 130) for i in range(9)]
+    mx = torch.from_numpy(np.stack([u[0] for u in utts])).cuda()
+    cl = torch.from_numpy(np.stack([u[1] for u in utts])).cuda()
+    out_b, ex_b = enh.enhance(mx, cl, want_bf=True)
+    out_b, bf_b = out_b.cpu().numpy(), ex_b["bf"].cpu().numpy()
+    for i in (0, 4, 8):
+        out_1, ex_1 = enh.enhance(mx[i:i + 1], cl[i:i + 1], want_bf=True)
+        assert rel_l2(bf_b[i], ex_1["bf"][0].cpu().numpy()) < 1e-6, i
+        assert rel_l2(out_b[i], out_1[0].cpu().numpy()) < 1e-6, i
