@@ -132,3 +132,13 @@ def test_bf16x3_pipeline_batch_invariance(nets_bf):
         out_1, ex_1 = enh.enhance(mx[i:i + 1], cl[i:i + 1], want_bf=True)
         assert rel_l2(bf_b[i], ex_1["bf"][0].cpu().numpy()) < 1e-6, i
         assert rel_l2(out_b[i], out_1[0].cpu().numpy()) < 1e-6, i
+
+
+def test_bf16x3_long_utterance(nets_bf, sd1):
+    """8 s at 16 kHz (T = 2001: 16 frame tiles per row, twice the BASELINE geometry) against the oracle."""
+    from oracle import miso_oracle
+    m1, _ = nets_bf
+    mx, _ = _utt_inputs(2, 2001)
+    y = m1(torch.from_numpy(mx[None]).cuda()).cpu().numpy()
+    y_ref = miso_oracle.miso1_forward(torch.from_numpy(mx[None]), sd1).numpy()
+    _assert_parity(y, y_ref, "bf16x3 miso1 T=2001 vs oracle")
