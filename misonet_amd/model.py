@@ -13,6 +13,8 @@ Differences from the reference, on purpose:
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from collections import OrderedDict
 from typing import Dict, Optional, Sequence
@@ -51,6 +53,9 @@ class _Trunk:
         names = [L.misonet_net_tensor_name(self._net, i).decode() for i in range(L.misonet_net_num_tensors(self._net))]
         if names != list(self.spec.keys()):
             raise RuntimeError("library tensor list differs from weights.tensor_spec")
+        default_prec = os.environ.get("MISONET_PRECISION")      # e.g. MISONET_PRECISION=bf16x3 for an unmodified harness
+        if default_prec:
+            self.set_precision(default_prec)
 
     def __del__(self):
         try:
