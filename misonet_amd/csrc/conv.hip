@@ -144,7 +144,6 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2) ? 3 : 2)) void conv3x
   // staging roles
   const int sq = tid & 31, sci = tid >> 5;
   const int tg = t0 + 4 * sq;
-  const bool tok = tg < Tp;
   const int hr = tid >> 4, hci = (tid >> 1) & 7, hside = tid & 1;
   const int htg = hside ? t0 + TT : t0 - 1;
   const bool hok = (hr < NR) && htg >= 0 && htg < T && (fin0 + hr) >= 0 && (fin0 + hr) < Fin;

@@ -598,7 +598,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
           const bf16x8* st_ = s_stage + (g & 1) * SN;                                                           \
           auto hook = [&](int stp) {                                                                            \
             if ((ROW) >= 0)                                                                                     \
-              conv_epi_step<((ROW) >= 0 ? (ROW) : 0), 3 * NR>(stp, prev, es, prs_h, prs_l, OP16, sred_prev, lane); \
+              conv_epi_step<((ROW) >= 0 ? (ROW) : 0), 3 * NR>(stp, prev, es, prs_h, prs_l, OP16, lane); \
           };                                                                                                    \
           if (wave_live && !(a.dbg & 1)) {                                                                      \
             __builtin_amdgcn_s_setprio(1);                                                                      \
@@ -629,14 +629,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
           const unsigned nrec = (unsigned)(a.Cout >> 3) * OP16;
           prs_h = make_rsrc_u(pa, nrec);
           prs_l = make_rsrc_u(pa + (unsigned long long)(a.out_sstride >> 3) * OP16, nrec);
-          float* sred_cur = s_red + (ti & 1) * (4 * COP * 2) + wave * (COP * 2);
           if (NDEF <= 2 && FTR > 2) {
 #pragma unroll
-            for (int stp = 0; stp < 3 * NR; ++stp) conv_epi_step<2, 3 * NR>(stp, acc, es, prs_h, prs_l, OP16, sred_cur, lane);
+            for (int stp = 0; stp < 3 * NR; ++stp) conv_epi_step<2, 3 * NR>(stp, acc, es, prs_h, prs_l, OP16, lane);
           }
           if (NDEF <= 3 && FTR > 3) {
 #pragma unroll
-            for (int stp = 0; stp < 3 * NR; ++stp) conv_epi_step<3, 3 * NR>(stp, acc, es, prs_h, prs_l, OP16, sred_cur, lane);
+            for (int stp = 0; stp < 3 * NR; ++stp) conv_epi_step<3, 3 * NR>(stp, acc, es, prs_h, prs_l, OP16, lane);
           }
 #pragma unroll
           for (int r4 = 0; r4 < NDEF; ++r4) prev[r4] = acc[r4];
@@ -650,9 +649,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
       {
         float* sred_prev = s_red + ((ti + 1) & 1) * (4 * COP * 2) + wave * (COP * 2);
 #pragma unroll
-        for (int stp = 0; stp < 3 * NR; ++stp) conv_epi_step<0, 3 * NR>(stp, prev, es, prs_h, prs_l, OP16, sred_prev, lane);
+        for (int stp = 0; stp < 3 * NR; ++stp) conv_epi_step<0, 3 * NR>(stp, prev, es, prs_h, prs_l, OP16, lane);
 #pragma unroll
-        for (int stp = 0; stp < 3 * NR; ++stp) conv_epi_step<1, 3 * NR>(stp, prev, es, prs_h, prs_l, OP16, sred_prev, lane);
+        for (int stp = 0; stp < 3 * NR; ++stp) conv_epi_step<1, 3 * NR>(stp, prev, es, prs_h, prs_l, OP16, lane);
         conv_epi_reduce(es, sred_prev, lane);
       }
 #undef RUN_CHUNK

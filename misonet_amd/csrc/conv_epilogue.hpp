@@ -645,8 +645,7 @@ struct EpiState {
 
 template <int ROW, int NSTEP>
 __device__ __forceinline__ void conv_epi_step(int st, f32x16_t (&prev)[4], EpiState& e, const __amdgpu_buffer_rsrc_t rs_h,
-                                              const __amdgpu_buffer_rsrc_t rs_l, unsigned P16, float* s_red_w,
-                                              int lane) {
+                                              const __amdgpu_buffer_rsrc_t rs_l, unsigned P16, int lane) {
   constexpr int NPIECE = 12;
   constexpr int PP = (NPIECE + NSTEP - 1) / NSTEP;
   const f32x2_e kl2e = {1.4426950408889634f, 1.4426950408889634f};

@@ -14,7 +14,6 @@
 
 namespace mn {
 
-constexpr int MAXM = 8;
 
 struct cd { double re, im; };
 __device__ inline cd cmul(cd a, cd b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }

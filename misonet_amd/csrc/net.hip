@@ -485,7 +485,7 @@ int misonet_net_create(const misonet_cfg* cfg, misonet_net** out) {
 
 int misonet_net_destroy(misonet_net* n) {
   if (!n) return MISONET_OK;
-  if (n->w_dev) hipFree(n->w_dev);
+  if (n->w_dev) (void)hipFree(n->w_dev);
   delete n;
   return MISONET_OK;
 }
@@ -622,7 +622,7 @@ int misonet_net_commit(misonet_net* n) {
       for (int co = 0; co < 128; ++co)
         for (int ci = 0; ci < 128; ++ci) arena[H.o_pw + (long long)ci * 128 + co] = P[(long long)co * 128 + ci];
     }
-  if (n->w_dev) { hipFree(n->w_dev); n->w_dev = nullptr; }
+  if (n->w_dev) { (void)hipFree(n->w_dev); n->w_dev = nullptr; }
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&n->w_dev), arena.size() * sizeof(float)));
   HIPCHK(hipMemcpy(n->w_dev, arena.data(), arena.size() * sizeof(float), hipMemcpyHostToDevice));
   HIPCHK(conv_init());
