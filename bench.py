@@ -116,10 +116,10 @@ def roofline_objects(precision, B, T, steps, dt_conv_ms, n_launch, value_per_gpu
     conv_s = dt_conv_ms / 1e3
     ach_tf = flops_step * steps / conv_s / 1e12
     ach_tb = bytes_step * steps / conv_s / 1e12
-    traffic, busy = None, None
+    traffic, busy, clk = None, None, None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))[precision]
-        traffic, busy = tj["bytes_per_launch"], tj.get("mfma_busy_frac")
+        traffic, busy, clk = tj["bytes_per_launch"], tj.get("mfma_busy_frac"), tj.get("clock_ghz_observed")
     except Exception:
         pass
     common = {"kernel": {"f32": "conv3x3_mfma", "bf16x3": "conv3x3_bf16x3_dma2", "bf16x3p": "conv3x3_bf16x3"}[precision],
@@ -127,7 +127,10 @@ def roofline_objects(precision, B, T, steps, dt_conv_ms, n_launch, value_per_gpu
               "algorithmic_gflop_per_launch": round(flops_step * steps / max(n_launch, 1) / 1e9, 2),
               "algorithmic_gbyte_per_launch": round(bytes_step * steps / max(n_launch, 1) / 1e9, 3),
               "traffic": traffic, "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, x2 fetch correction)",
-              "mfma_busy_frac_pmc": busy}
+              "mfma_busy_frac_pmc": busy,
+              # engine clock seen in the PMC pass (the peaks below are the guide's 2.4 GHz figures; under the bf16x3 load
+              # the part is power-limited, profiles/r01_clocks_power_*.txt)
+              "clock_ghz_observed_pmc": clk}
     mfma_peak = PEAK_F32_MFMA_TF if precision == "f32" else PEAK_BF16_MFMA_TF
     r_mfma = dict(common, bound="mfma", achieved=round(ach_tf, 3), peak=mfma_peak, unit="TFLOP/s",
                   frac=round(ach_tf / mfma_peak, 4))
