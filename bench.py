@@ -167,13 +167,22 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # testing hooks for a 1-GPU box (the driver's multi-GPU runs use neither): all ranks on device 0 over gloo exercises
+    # the rendezvous / barrier / MAX-reduce path of this script without a second GPU
+    one_dev = bool(os.environ.get("MISONET_BENCH_ONE_DEVICE"))
+    backend = os.environ.get("MISONET_BENCH_BACKEND", "nccl")
+    if one_dev:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import misonet_amd as mz
     from misonet_amd import _lib, stft, weights as W
