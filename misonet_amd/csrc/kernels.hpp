@@ -54,7 +54,8 @@ struct ConvArgs {
   int xcd;                  // 1: 1-D grid with the XCD-aware tile order of conv_tile() (ntx, nty, nsamp valid)
   int ntx, nty, nsamp;      // frame tiles, row tiles, samples of this launch
   unsigned long long* dbg_buf;   // timeline stamps of one workgroup (MISONET_TIMELINE=1, experiments only)
-  int dbg;                  // timing experiments only (MISONET_WS_DEBUG bits): 1 = consumers skip MFMAs, 2 = producers idle, 4 = skip epilogue
+  int dbg;                  // timing experiments only (MISONET_WS_DEBUG bits): 1 skip MFMAs, 4 skip epilogue, 8 skip stores,
+                            // 16 skip statistics reductions, 32 no deferred epilogue
 };
 // Workgroup -> tile.  Hardware hands consecutive workgroup ids to the 8 XCDs round-robin and every XCD has its own
 // L2, so with the natural (t, f, n) order the 8 frame tiles of a row sit on 8 different XCDs and every halo line is
@@ -99,8 +100,6 @@ hipError_t conv_bf16_init();
 hipError_t launch_conv_bf16_dma(const ConvArgs& a, int n_samples, hipStream_t s);   // conv_bf16_dma.hip (oct input)
 hipError_t launch_conv_wprep(const ConvArgs& a, const float* wf, int n_samples, hipStream_t s);
 hipError_t conv_bf16_dma_init();
-hipError_t launch_conv_bf16_r8(const ConvArgs& a, int n_samples, hipStream_t s);   // conv_bf16_r8.hip: stride-1 layers
-hipError_t conv_bf16_r8_init();
 
 // ---- TCN (reference model.py:486-632) -----------------------------------------------------------------------------
 // x0 = IN2d(raw) materialised as the residual stream + its per-(n,c) statistics
