@@ -405,10 +405,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
     const unsigned grp_ = (K) / per;                                                                            \
     unsigned tile_ = (K) - grp_ * per;                                                                          \
     n = (int)(grp_ * 8u + xcd);                                                                                 \
-    t0 = (int)(tile_ % (unsigned)a.ntx) * TT;                                                                   \
-    tile_ /= (unsigned)a.ntx;                                                                                   \
+    /* row tile fastest: the 32 workgroups of an XCD work on neighbouring rows of one frame tile (+1 % over frame */ \
+    /* tile fastest; the fetch traffic is the same, the halo rows are simply still warm in the L2) */              \
+    f0 = (int)(tile_ % (unsigned)a.nty) * FTR;                                                                  \
+    tile_ /= (unsigned)a.nty;                                                                                   \
     cg = (int)(tile_ % (unsigned)a.ncg);                                                                        \
-    f0 = (int)(tile_ / (unsigned)a.ncg) * FTR;                                                                  \
+    t0 = (int)(tile_ / (unsigned)a.ncg) * TT;                                                                   \
   }
 
   if (producer) {
