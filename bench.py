@@ -2,7 +2,10 @@
 """Throughput bench of the MISO1 -> MVDR -> MISO3 hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by the driver as  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1: either launched by the driver as ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``
+(RANK / LOCAL_RANK / WORLD_SIZE in the environment) or started plainly -- then this script re-executes itself under
+``torch.distributed.run`` with N ranks on 127.0.0.1, one rank per GPU over RCCL.
 
 A "step" = one pass of the complete reference semantics (6 x MISO_1 forward over the circular mic shifts +
 shift alignment + clean alignment + 2 x MVDR + 2 x MISO_3 forward; reference tester.py:865-939) over one batch of
@@ -10,9 +13,13 @@ synthetic 6-mic / 16 kHz / 4 s utterances (T = 1001 frames, F = 129) already res
 BASELINE.json configs[3] (batch 16 per GPU, full pipeline); utterances are sharded over ranks with no data-path
 collective (weak scaling).  Prints ONE JSON line on rank 0.
 
+The timed loop is un-instrumented.  The headline arithmetic is fp32-faithful (``HEADLINE_PRECISION``); the other
+arithmetic modes are timed beside it with the same steps / warm-up and reported under ``alt_precision``.
+
 Extra objects on the line:
-  roofline     -- dominant kernel conv3x3_mfma (fp32 MFMA bound): algorithmic FLOPs / its summed launch time,
-                  timed live with HIP events on the launch stream during the timed steps (misonet_profile_*).
+  roofline     -- dominant kernel (the 3x3 conv launches, MFMA bound): algorithmic FLOPs / summed launch time, from a
+                  SEPARATE pass of the same workload with HIP events around every launch on the launch stream
+                  (misonet_profile_*); ``instrumented_ms_per_step`` shows what the events cost.
   cpu_baseline -- the CPU oracle (oracle/: stock torch-CPU + NumPy restatement of the reference) timed on this
                   host's cores on a bounded sample (rank 0, N = 1 only).
 """
@@ -20,6 +27,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,9 +40,19 @@ sys.path.insert(0, ROOT)
 
 N_MIC, N_SPK, N_SAMPLES = 6, 2, 64000
 PEAK_F32_MFMA_TF = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, fp32 matrix peak (spec)
-PEAK_BF16_MFMA_TF = 2500.0      # dense bf16 matrix peak (spec); the bf16x3 mode issues 3 bf16 MFMA FLOPs per algorithmic FLOP
+PEAK_BF16_MFMA_TF = 2500.0      # dense bf16 matrix peak (spec)
 PEAK_HBM_TBS = 8.0
 ALGO_BYTES_PER_UTT = 6.23e9     # 8 forwards x 0.776 GB + 2 x 13.43 MB
+
+# arithmetic of the 3x3 convs: name -> (dominant kernel, bf16 MFMA products issued per algorithmic product, or 0 for
+# the f32 MFMA, fp32-faithful?)
+MODES = {
+    "f32":     ("conv3x3_mfma", 0, True),            # v_mfma_f32_32x32x2_f32: exact f32, bitwise an fmaf chain
+    "bf16x6":  ("conv3x3_bf16x6", 6, True),          # operands split EXACTLY into 3 bf16 pieces (24 bits), 6 leading terms
+    "bf16x3":  ("conv3x3_bf16x3_dma2", 3, False),    # 2 bf16 pieces (16 bits), 3 terms: inside 1e-3 but not fp32-faithful
+    "bf16x3p": ("conv3x3_bf16x3", 3, False),
+}
+HEADLINE_PRECISION = "f32"
 
 
 def conv_flops_per_forward(in_ch, out_ch, T, en=(24, 32, 32, 32, 32, 64, 128), de=(128, 64, 32, 32, 32, 32, 24)):
@@ -105,8 +124,21 @@ def run_steps(enh, mix, clean, out, steps, warmup, dist, L, _lib, profile):
     return dt, list(ms), list(cnt)
 
 
-def roofline_objects(precision, B, T, steps, dt_conv_ms, n_launch, value_per_gpu):
+def _traffic_entry(precision):
+    """measured HBM bytes per conv launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/)"""
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if precision in tj:
+                return tj[precision], f"profiles/{name}"
+        except Exception:
+            pass
+    return None, None
+
+
+def roofline_objects(precision, B, T, steps, dt_conv_ms, n_launch):
     """roofline of the dominant kernel (the 3x3 conv launches) for one precision mode."""
+    kernel, terms, _ = MODES[precision]
     fl1 = conv_flops_per_forward(2 * N_MIC, 2 * N_SPK, T)
     fl3 = conv_flops_per_forward(2 * (N_MIC + 2), 2, T)
     by1 = conv_bytes_per_forward(2 * N_MIC, 2 * N_SPK, T)
@@ -116,34 +148,49 @@ def roofline_objects(precision, B, T, steps, dt_conv_ms, n_launch, value_per_gpu
     conv_s = dt_conv_ms / 1e3
     ach_tf = flops_step * steps / conv_s / 1e12
     ach_tb = bytes_step * steps / conv_s / 1e12
-    traffic, busy, clk = None, None, None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))[precision]
-        traffic, busy, clk = tj["bytes_per_launch"], tj.get("mfma_busy_frac"), tj.get("clock_ghz_observed")
-    except Exception:
-        pass
-    common = {"kernel": {"f32": "conv3x3_mfma", "bf16x3": "conv3x3_bf16x3_dma2", "bf16x3p": "conv3x3_bf16x3"}[precision],
+    tj, tsrc = _traffic_entry(precision)
+    traffic = tj["bytes_per_launch"] if tj else None
+    common = {"kernel": kernel,
               "launches_per_step": int(n_launch // steps), "avg_launch_ms": round(dt_conv_ms / max(n_launch, 1), 4),
               "algorithmic_gflop_per_launch": round(flops_step * steps / max(n_launch, 1) / 1e9, 2),
               "algorithmic_gbyte_per_launch": round(bytes_step * steps / max(n_launch, 1) / 1e9, 3),
-              "traffic": traffic, "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, x2 fetch correction)",
-              "mfma_busy_frac_pmc": busy,
-              # engine clock seen in the PMC pass (the peaks below are the guide's 2.4 GHz figures; under the bf16x3 load
-              # the part is power-limited, profiles/r01_clocks_power_*.txt)
-              "clock_ghz_observed_pmc": clk}
-    mfma_peak = PEAK_F32_MFMA_TF if precision == "f32" else PEAK_BF16_MFMA_TF
+              "traffic": traffic,
+              "traffic_source": (tsrc + " (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, x2 fetch correction)") if tsrc else None,
+              "mfma_busy_frac_pmc": tj.get("mfma_busy_frac") if tj else None,
+              # engine clock seen in the PMC pass (the peaks below are the guide's 2.4 GHz figures; under the bf16 MFMA
+              # load the part is power-limited)
+              "clock_ghz_observed_pmc": tj.get("clock_ghz_observed") if tj else None}
+    mfma_peak = PEAK_BF16_MFMA_TF if terms else PEAK_F32_MFMA_TF
     r_mfma = dict(common, bound="mfma", achieved=round(ach_tf, 3), peak=mfma_peak, unit="TFLOP/s",
                   frac=round(ach_tf / mfma_peak, 4))
-    if precision != "f32":
-        r_mfma["issued_tflops"] = round(3 * ach_tf, 1)          # 3 bf16 MFMAs per algorithmic product
-        r_mfma["frac_issued"] = round(3 * ach_tf / mfma_peak, 4)
+    if terms:
+        r_mfma["bf16_products_per_product"] = terms
+        r_mfma["issued_tflops"] = round(terms * ach_tf, 1)
+        r_mfma["frac_issued"] = round(terms * ach_tf / mfma_peak, 4)
     r_hbm = dict(common, bound="hbm", achieved=round(ach_tb * 1e3, 1), peak=PEAK_HBM_TBS * 1e3, unit="GB/s",
                  frac=round(ach_tb / PEAK_HBM_TBS, 4))
     # binding roofline: arithmetic intensity of the layer vs the ridge of the mode's effective matrix peak
-    eff_peak = mfma_peak if precision == "f32" else mfma_peak / 3.0
+    eff_peak = mfma_peak / terms if terms else mfma_peak
     ai = flops_step / bytes_step
     binding = r_mfma if ai >= eff_peak * 1e12 / (PEAK_HBM_TBS * 1e12) else r_hbm
     return binding, (r_hbm if binding is r_mfma else r_mfma)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def relaunch_under_torchrun(n):
+    """``python bench.py --gpus N`` without a launcher: start N ranks of this script on this node."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -153,19 +200,19 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=16, help="utterances per GPU per step (BASELINE configs[3]: 16)")
     ap.add_argument("--frames", type=int, default=1001)
-    ap.add_argument("--precision", choices=["f32", "bf16x3", "bf16x3p"], default="bf16x3",
-                    help="arithmetic of the 3x3 convs: exact f32 MFMA, or 3-term bf16 split on the bf16 MFMA (default)")
-    ap.add_argument("--no-alt", action="store_true", help="skip the short run of the other precision mode (N = 1 only)")
+    ap.add_argument("--precision", choices=sorted(MODES), default=HEADLINE_PRECISION,
+                    help="arithmetic of the 3x3 convs (default: the fp32-faithful headline mode)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the runs of the other precision modes (N = 1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-profile", action="store_true", help="do not bracket launches with HIP events")
+    ap.add_argument("--no-profile", action="store_true", help="skip the event-instrumented pass (no roofline object)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(relaunch_under_torchrun(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # testing hooks for a 1-GPU box (the driver's multi-GPU runs use neither): all ranks on device 0 over gloo exercises
     # the rendezvous / barrier / MAX-reduce path of this script without a second GPU
@@ -210,34 +257,58 @@ def main():
     out = torch.empty((B, N_SPK, T, 129), dtype=torch.complex64, device=dev)
 
     L = _lib.lib()
-    profile = not args.no_profile
-    dt, ms, cnt = run_steps(enh, mix, clean, out, args.steps, args.warmup, dist, L, _lib, profile)
+    # ---- the headline: un-instrumented timed loop ----
+    dt, _, _ = run_steps(enh, mix, clean, out, args.steps, args.warmup, dist, L, _lib, False)
     if not os.environ.get("MISONET_BENCH_NOCHECK"):      # (timing experiments with deliberately wrong results)
         _lib.check(L.misonet_pipeline_check(enh._pipe, enh.workspace(B, T).data_ptr(), _lib.stream_ptr(dev)))
+    dt_rank = dt
+    per_rank = [B * args.steps / dt]
+    rccl_ranks = 1
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank = [B * args.steps / float(x.item()) for x in allt]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        rccl_ranks = dist.get_world_size()
+    # ---- roofline leg: the same steps once more with HIP events around every launch ----
+    prof = None
+    if not args.no_profile:
+        kp = max(1, min(args.steps, 5))
+        dtp, ms, cnt = run_steps(enh, mix, clean, out, kp, 1, dist, L, _lib, True)
+        prof = (kp, dtp, ms, cnt)
 
     if rank == 0:
         utt = world * B * args.steps
         value = utt / dt
         roof, roof2 = None, None
-        if profile and cnt[0] > 0:
-            roof, roof2 = roofline_objects(args.precision, B, T, args.steps, ms[0], cnt[0], value / world)
-            roof["time_share"] = {"conv_ms_per_step": round(ms[0] / args.steps, 2),
-                                  "tcn_ms_per_step": round(ms[1] / args.steps, 2),
-                                  "mvdr_ms_per_step": round(ms[2] / args.steps, 2)}
+        if prof and prof[3][0] > 0:
+            kp, dtp, ms, cnt = prof
+            roof, roof2 = roofline_objects(args.precision, B, T, kp, ms[0], cnt[0])
+            roof["time_share"] = {"conv_ms_per_step": round(ms[0] / kp, 2), "tcn_ms_per_step": round(ms[1] / kp, 2),
+                                  "mvdr_ms_per_step": round(ms[2] / kp, 2), "other_ms_per_step": round(ms[3] / kp, 2)}
+            roof["instrumented_steps"] = kp
+            roof["instrumented_ms_per_step"] = round(dtp / kp * 1e3, 2)
             roof["hbm_frac_pipeline"] = round(ALGO_BYTES_PER_UTT * (value / world) / (PEAK_HBM_TBS * 1e12), 4)
-        alt = None
-        if world == 1 and not args.no_alt and profile:
-            other = "f32" if args.precision != "f32" else "bf16x3"
-            m1.set_precision(other)
-            m3.set_precision(other)
-            k = max(2, min(3, args.steps))
-            dt2, ms2, cnt2 = run_steps(enh, mix, clean, out, k, 1, None, L, _lib, True)
-            r2, _ = roofline_objects(other, B, T, k, ms2[0], cnt2[0], B * k / dt2)
-            alt = {"dtype": other, "value": round(B * k / dt2, 3), "unit": "utt/s", "steps": k, "roofline": r2}
+        alts = []
+        if world == 1 and not args.no_alt:
+            for other in ("f32", "bf16x6", "bf16x3"):
+                if other == args.precision:
+                    continue
+                try:
+                    m1.set_precision(other)
+                    m3.set_precision(other)
+                except ValueError:
+                    continue
+                dt2, _, _ = run_steps(enh, mix, clean, out, args.steps, args.warmup, None, L, _lib, False)
+                a = {"dtype": other, "fp32_faithful": MODES[other][2], "value": round(B * args.steps / dt2, 3),
+                     "unit": "utt/s", "steps": args.steps, "warmup": args.warmup}
+                if not args.no_profile:
+                    k = max(1, min(args.steps, 3))
+                    _, ms2, cnt2 = run_steps(enh, mix, clean, out, k, 0, None, L, _lib, True)
+                    a["roofline"] = roofline_objects(other, B, T, k, ms2[0], cnt2[0])[0]
+                alts.append(a)
             m1.set_precision(args.precision)
             m3.set_precision(args.precision)
         cpu = None
@@ -247,11 +318,12 @@ def main():
             "metric": "utterances/sec MISO1->MVDR->MISO3, 6-mic 16kHz 4s",
             "value": round(value, 3), "unit": "utt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "vs_baseline": None, "dtype": args.precision, "fp32_faithful": MODES[args.precision][2], "data": "synthetic",
             "config": {"workload": "BASELINE configs[3]: synthetic 6-mic 16 kHz 4 s, full MISO1x6 -> align -> MVDRx2 -> MISO3x2",
                        "batch_per_gpu": B, "frames": T, "freq_bins": 129, "parallelism": f"utterance-shard x{world}"},
             "realtime_factor": round(value * (n / 16000.0), 2),
-            "roofline": roof, "roofline_other": roof2, "alt_precision": alt, "cpu_baseline": cpu,
+            "rccl_ranks": rccl_ranks, "per_rank_utt_per_s": [round(v, 3) for v in per_rank],
+            "roofline": roof, "roofline_other": roof2, "alt_precision": alts, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:
@@ -259,14 +331,37 @@ def main():
         dist.destroy_process_group()
 
 
+def _physical_cores():
+    """physical cores of this host (unique (package, core) pairs), logical CPUs if /proc/cpuinfo does not say"""
+    try:
+        seen, phys, core = set(), None, None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                phys = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                core = ln.split(":")[1].strip()
+            elif not ln.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        if seen:
+            return len(seen)
+    except Exception:
+        pass
+    return os.cpu_count() or 1
+
+
 def cpu_baseline(sd1, sd3, T):
     """The oracle (kind "port": our stock-torch-CPU/NumPy restatement of the reference path, B = 1 per call as in
-    tester.py) on this host's cores.  Bounded sample: 1 forward warm-up, then whole utterances until >= 12 s."""
+    tester.py:846-975) on this host's cores.  Bounded sample: one forward warm-up, then 3
+    different utterances end to end with N = the cores this process may use (median reported, stages timed
+    separately), then one utterance with N = 8 threads for comparison with the survey container."""
     from misonet_amd import weights as W
     from oracle import pipeline_oracle, miso_oracle
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = max(1, min(cores, 64))
-    torch.set_num_threads(threads)
+    logical = os.cpu_count() or 1
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else logical
+    physical = _physical_cores()
+    threads = max(1, min(usable, physical))
     n = (T - 1) * 64
 
     def utt(u):
@@ -274,17 +369,36 @@ def cpu_baseline(sd1, sd3, T):
         mix = pipeline_oracle.stft_chunk(obs)
         clean = np.stack([pipeline_oracle.stft_chunk(s0)[0], pipeline_oracle.stft_chunk(s1)[0]])
         return mix, clean
-    mix, clean = utt(0)
-    miso_oracle.miso1_forward(torch.from_numpy(mix[None]), sd1)          # warm-up
-    done, t0 = 0, time.perf_counter()
-    while True:
-        pipeline_oracle.enhance_utterance(mix, clean, sd1, sd3, ref_ch=0)
-        done += 1
-        el = time.perf_counter() - t0
-        if el >= 12.0 or done >= 4:
+
+    def timed(u, stages=None):
+        mix, clean = utt(u)
+        t0 = time.perf_counter()
+        pipeline_oracle.enhance_utterance(mix, clean, sd1, sd3, ref_ch=0, timings=stages)
+        return time.perf_counter() - t0
+
+    torch.set_num_threads(threads)
+    mix0, _ = utt(0)
+    miso_oracle.miso1_forward(torch.from_numpy(mix0[None]), sd1)          # warm-up
+    t_all = time.perf_counter()
+    times, stages = [], []
+    for u in range(3):
+        st = {}
+        times.append(timed(u, st))
+        stages.append(st)
+        if time.perf_counter() - t_all > 40.0:
             break
-    return {"value": round(done / el, 4), "unit": "utt/s", "cores": threads, "kind": "port",
-            "sample": f"{done} utterance(s) of the same synthetic workload (T={T}), B=1 per call, {el:.1f} s"}
+    med = float(np.median(times))
+    stage_med = {k: round(float(np.median([s[k] for s in stages if k in s])), 3) for k in (stages[0] if stages else {})}
+    n8 = None
+    if threads != 8 and usable >= 8:
+        torch.set_num_threads(8)
+        n8 = round(1.0 / timed(3), 4)
+        torch.set_num_threads(threads)
+    return {"value": round(1.0 / med, 4), "unit": "utt/s", "cores": threads, "kind": "port",
+            "host_logical_cpus": logical, "host_physical_cores": physical, "usable_cpus": usable,
+            "value_8_threads": n8, "stage_seconds_median": stage_med,
+            "sample": f"median of {len(times)} utterance(s) of the same synthetic workload (T={T}), B=1 per call, "
+                      f"{sum(times):.1f} s at {threads} threads" + (", plus 1 utterance at 8 threads" if n8 else "")}
 
 
 if __name__ == "__main__":

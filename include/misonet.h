@@ -100,7 +100,10 @@ int misonet_mvdr_debug(const void* ws_dev, int B, int F, int M, void* steer_c128
 
 /* ---- PIT speaker alignment (tester.py:1043-1065 and 889-915) ----------------------------------------------- */
 /* anchor_dev, cand_dev: complex64 [B, S, T, F]; sel_dev: int32 [B, S] with aligned speaker i = cand[sel[i]];
- * dist_dev (may be NULL): float64 [B, S, S], dist[i][j] = sum_{t,f} | |anchor_i| - |cand_j| |.  S must be 2. */
+ * dist_dev (required: it is the call's only scratch, so the call allocates nothing and stays asynchronous): float64
+ * [B, S, S], receives dist[i][j] = sum_{t,f} | |anchor_i| - |cand_j| |.  All S! permutations are enumerated in
+ * itertools.permutations order with the first minimum winning, as the reference's einsum('bij,pij->bp') + argmin
+ * (tester.py:1053-1064); 1 <= S <= 4. */
 int misonet_pit_select(const void* anchor_dev, const void* cand_dev, int B, int S, int T, int F,
                        int* sel_dev, double* dist_dev, misonet_stream stream);
 
@@ -108,6 +111,8 @@ int misonet_pit_select(const void* anchor_dev, const void* cand_dev, int B, int 
 /* MISO1_Inference (6 circular shifts batched as 6B forwards, tester.py:1014-1068) -> clean-reference
  * alignment (tester.py:889-915; skipped when clean_dev == NULL) -> MVDR per speaker (tester.py:917-924) ->
  * MISO3 per speaker (tester.py:936-939).  Everything stays in HBM in the kernels' own layout. */
+/* 2 <= num_mic <= 8; 1 <= num_spk <= 4 (the reference's own clean-reference alignment stacks exactly s0 and s1,
+ * tester.py:889-891, i.e. its harness is 2-speaker; here clean_dev simply carries num_spk sources). */
 int misonet_pipeline_create(misonet_net* miso1, misonet_net* miso3, int num_mic, int num_spk, int ref_ch,
                             float epsi, misonet_pipeline** out);
 int misonet_pipeline_destroy(misonet_pipeline* p);
@@ -130,15 +135,17 @@ int misonet_pipeline_run_wav(misonet_pipeline* p, const float* wav_dev, const fl
 
 /* ---- STFT front-end alone: AudioDataset_Test.STFT + "/scale" + permute (dataloader/data.py:505-522, 540-544) ------ */
 /* wav_dev float32 [B, n_samples, M] -> out_dev complex64 [B, M, T, 129], T = n_samples/64 + 1: hann-256, hop 64,
- * zero boundary padding, un-normalised.  The twiddle table (295 KB) is allocated on first use. */
+ * zero boundary padding, un-normalised.  The twiddle table (295 KB) is allocated once per device, on first use there
+ * (the one allocation outside *_commit). */
 int misonet_stft_frames(int n_samples);
 long long misonet_stft_workspace_bytes(int B, int M, int n_samples);
 int misonet_stft(const float* wav_dev, int B, int n_samples, int M, void* out_dev, void* ws_dev, long long ws_bytes,
                  misonet_stream stream);
 
 /* ---- per-launch timing (bench.py roofline leg): while enabled, the library brackets every conv launch, the TCN
- * section and the MVDR section of each forward with HIP events on the caller's stream.  kinds: 0 = conv3x3_mfma
- * launches, 1 = TCN sections, 2 = MVDR sections, 3 = other.  misonet_profile_end synchronises and sums. */
+ * section and the MVDR section of each forward with HIP events on the caller's stream.  kinds: 0 = 3x3 conv kernel
+ * launches, 1 = TCN sections, 2 = MVDR sections, 3 = other (conv_wprep_k, the per-sample weight preparation of the
+ * DMA dataflow).  State is per device (the current device at the call); misonet_profile_end synchronises and sums. */
 int misonet_profile_begin(int max_launches);
 int misonet_profile_end(double* ms_by_kind /*[4]*/, long long* launches_by_kind /*[4]*/);
 

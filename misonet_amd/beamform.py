@@ -1,7 +1,7 @@
 """Host-side mirror of the reference's array-processing calls on the inference path.
 
 ``Apply_Beamforming(source_stft, mix_stft, epsi)``  -- reference tester.py:1071-1136 (MVDR per frequency bin)
-``pit_select(anchor, cand)``                        -- reference tester.py:1043-1065 / 889-915 (2-speaker PIT)
+``pit_select(anchor, cand)``                        -- reference tester.py:1043-1065 / 889-915 (PIT over all S! permutations)
 
 Both run as HIP kernels through the C ABI (misonet_mvdr / misonet_pit_select in include/misonet.h).
 """
@@ -59,10 +59,11 @@ def Apply_Beamforming(source_stft, mix_stft, epsi=1e-6, device=None, return_debu
 
 
 def pit_select(anchor, cand, return_dist=False):
-    """Speaker alignment by the reference's 2-permutation PIT rule (tester.py:1053-1065, 902-915).
+    """Speaker alignment by the reference's PIT rule (tester.py:1053-1065, 902-915): all S! permutations in
+    itertools.permutations order, first minimum of the summed magnitude distance (1 <= S <= 4).
 
-    anchor, cand: complex [B, 2, T, F] device tensors.  Returns int32 [B, 2] ``sel`` with aligned speaker i =
-    cand[:, sel[:, i]] (and the distance matrix float64 [B, 2, 2] if asked)."""
+    anchor, cand: complex [B, S, T, F] device tensors.  Returns int32 [B, S] ``sel`` with aligned speaker i =
+    cand[:, sel[:, i]] (and the distance matrix float64 [B, S, S] if asked)."""
     a, _ = _dev_c64(anchor, None if isinstance(anchor, torch.Tensor) and anchor.is_cuda else torch.device("cuda"))
     c, _ = _dev_c64(cand, a.device)
     if a.shape != c.shape or a.dim() != 4:

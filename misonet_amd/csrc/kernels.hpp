@@ -150,12 +150,14 @@ struct COut { float* re; float* im; long long ob, os, ot, of; };
 hipError_t launch_mvdr(const MvdrArgs& a, const COut& out, void* ws, hipStream_t s);
 hipError_t launch_mvdr_debug(const void* ws, int B, int S, int F, int M, double* steer, double* w, hipStream_t s);
 
-// dist[b][i][j] = sum_{t,f} | |A_i| - |B_j| | for S = 2, accumulated in float64 with atomics; then sel.
+// dist[b][i][j] = sum_{t,f} | |A_i| - |B_j| | for S = 1..4 speakers, accumulated in float64 with atomics; then sel
+// = the cheapest of the S! permutations (itertools order, first minimum).
 struct PitArgs {
   CView a, b;             // sm = speaker stride here; (b, f, spk, t) addressing
   int B, F, T;
 };
-hipError_t launch_pit_dist(const PitArgs& p, double* dist /*[B][2][2], pre-zeroed*/, hipStream_t s);
-hipError_t launch_pit_pick(const double* dist, int B, int* sel /*[B][2]*/, hipStream_t s);
+// K candidates per anchor: grid row bk = b*K + k uses anchor b and candidate bk
+hipError_t launch_pit_dist_k(const PitArgs& p, int S, int K, double* dist /*[B*K][S][S], pre-zeroed*/, hipStream_t s);
+hipError_t launch_pit_pick(const double* dist, int S, int n, int* sel /*[n][S]*/, hipStream_t s);
 
 }  // namespace mn

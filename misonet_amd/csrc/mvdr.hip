@@ -384,62 +384,102 @@ hipError_t launch_mvdr_debug(const void* ws, int B, int S, int F, int M, double*
   return e;
 }
 
-// ---- PIT distances for S = 2 ---------------------------------------------------------------------------------
-// grid (F, B*K): blockIdx.y = b*K + k, where the candidate view already encodes (b,k) through its strides:
-// a: anchors, element (bk, f, spk, t) with sb = 0 over k handled by the caller passing per-(b*K+k) strides.
+// ---- PIT distances, S speakers (1..4) -----------------------------------------------------------------------------
+// dist[bk][i][j] = sum_{t,f} | |A_i| - |B_j| |   (tester.py:1047-1052, 906-908), float64 accumulation.
+// grid (F, B*K): blockIdx.y = b*K + k; anchors are per b, candidates per (b, k).
+template <int S>
 __global__ __launch_bounds__(256) void pit_dist_k(const PitArgs p, int K, double* dist) {
-  __shared__ double s_tmp[4][4];
+  __shared__ double s_tmp[4][S * S];
   const int f = blockIdx.x, bk = blockIdx.y;
   const int b = bk / K;
   const long long oa = (long long)b * p.a.sb + (long long)f * p.a.sf;
   const long long ob = (long long)bk * p.b.sb + (long long)f * p.b.sf;
-  const float *are0 = p.a.re + oa, *aim0 = p.a.im + oa, *are1 = are0 + p.a.sm, *aim1 = aim0 + p.a.sm;
-  const float *bre0 = p.b.re + ob, *bim0 = p.b.im + ob, *bre1 = bre0 + p.b.sm, *bim1 = bim0 + p.b.sm;
-  double d[4] = {0.0, 0.0, 0.0, 0.0};
+  double d[S * S];
+#pragma unroll
+  for (int i = 0; i < S * S; ++i) d[i] = 0.0;
   for (int t = threadIdx.x; t < p.T; t += 256) {
-    const long long ia = (long long)t * p.a.st, ib = (long long)t * p.b.st;
-    const float a0 = sqrtf(are0[ia] * are0[ia] + aim0[ia] * aim0[ia]);
-    const float a1 = sqrtf(are1[ia] * are1[ia] + aim1[ia] * aim1[ia]);
-    const float b0 = sqrtf(bre0[ib] * bre0[ib] + bim0[ib] * bim0[ib]);
-    const float b1 = sqrtf(bre1[ib] * bre1[ib] + bim1[ib] * bim1[ib]);
-    d[0] += fabsf(a0 - b0);
-    d[1] += fabsf(a0 - b1);
-    d[2] += fabsf(a1 - b0);
-    d[3] += fabsf(a1 - b1);
+    const long long ia = oa + (long long)t * p.a.st, ib = ob + (long long)t * p.b.st;
+    float am[S], bm[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+      const float ar = p.a.re[ia + i * p.a.sm], ai = p.a.im[ia + i * p.a.sm];
+      const float br = p.b.re[ib + i * p.b.sm], bi = p.b.im[ib + i * p.b.sm];
+      am[i] = sqrtf(ar * ar + ai * ai);
+      bm[i] = sqrtf(br * br + bi * bi);
+    }
+#pragma unroll
+    for (int i = 0; i < S; ++i)
+#pragma unroll
+      for (int j = 0; j < S; ++j) d[i * S + j] += fabsf(am[i] - bm[j]);
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < S * S; ++i) {
     double v = d[i];
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
     if (lane == 0) s_tmp[wave][i] = v;
   }
   __syncthreads();
-  if (threadIdx.x < 4) {
+  if (threadIdx.x < S * S) {
     const int i = threadIdx.x;
-    unsafeAtomicAdd(dist + (long long)bk * 4 + i, s_tmp[0][i] + s_tmp[1][i] + s_tmp[2][i] + s_tmp[3][i]);
+    unsafeAtomicAdd(dist + (long long)bk * (S * S) + i, s_tmp[0][i] + s_tmp[1][i] + s_tmp[2][i] + s_tmp[3][i]);
   }
 }
 
-// sel[bk][i] = perm[i] of the cheaper of the two permutations; first minimum on ties (tester.py:1058-1064)
+// sel[bk][i] = perm[i] of the cheapest permutation, cost(perm) = sum_i dist[i][perm[i]]; permutations in the order of
+// itertools.permutations (lexicographic), first minimum on ties (torch.argmin; tester.py:1053-1064, 909-915)
+template <int S>
 __global__ void pit_pick_k(const double* dist, int n, int* sel) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const double c0 = dist[i * 4 + 0] + dist[i * 4 + 3];
-  const double c1 = dist[i * 4 + 1] + dist[i * 4 + 2];
-  const int p = (c1 < c0) ? 1 : 0;
-  sel[i * 2 + 0] = p;
-  sel[i * 2 + 1] = 1 - p;
+  const double* d = dist + (long long)i * (S * S);
+  int perm[S], best[S];
+#pragma unroll
+  for (int k = 0; k < S; ++k) { perm[k] = k; best[k] = k; }
+  double cbest = 0.0;
+  bool first = true;
+  for (;;) {
+    double c = 0.0;
+#pragma unroll
+    for (int k = 0; k < S; ++k) c += d[k * S + perm[k]];
+    if (first || c < cbest) {
+      cbest = c; first = false;
+#pragma unroll
+      for (int k = 0; k < S; ++k) best[k] = perm[k];
+    }
+    // next lexicographic permutation
+    int a = S - 2;
+    while (a >= 0 && perm[a] > perm[a + 1]) --a;
+    if (a < 0) break;
+    int b2 = S - 1;
+    while (perm[b2] < perm[a]) --b2;
+    { const int t = perm[a]; perm[a] = perm[b2]; perm[b2] = t; }
+    for (int lo = a + 1, hi = S - 1; lo < hi; ++lo, --hi) { const int t = perm[lo]; perm[lo] = perm[hi]; perm[hi] = t; }
+  }
+  for (int k = 0; k < S; ++k) sel[i * S + k] = best[k];
 }
 
-hipError_t launch_pit_dist_k(const PitArgs& p, int K, double* dist, hipStream_t s) {
-  hipLaunchKernelGGL(pit_dist_k, dim3(p.F, p.B * K), dim3(256), 0, s, p, K, dist);
+hipError_t launch_pit_dist_k(const PitArgs& p, int S, int K, double* dist, hipStream_t s) {
+  const dim3 g(p.F, p.B * K);
+  switch (S) {
+    case 1: hipLaunchKernelGGL(pit_dist_k<1>, g, dim3(256), 0, s, p, K, dist); break;
+    case 2: hipLaunchKernelGGL(pit_dist_k<2>, g, dim3(256), 0, s, p, K, dist); break;
+    case 3: hipLaunchKernelGGL(pit_dist_k<3>, g, dim3(256), 0, s, p, K, dist); break;
+    case 4: hipLaunchKernelGGL(pit_dist_k<4>, g, dim3(256), 0, s, p, K, dist); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
-hipError_t launch_pit_dist(const PitArgs& p, double* dist, hipStream_t s) { return launch_pit_dist_k(p, 1, dist, s); }
-hipError_t launch_pit_pick(const double* dist, int n, int* sel, hipStream_t s) {
-  hipLaunchKernelGGL(pit_pick_k, dim3((n + 63) / 64), dim3(64), 0, s, dist, n, sel);
+hipError_t launch_pit_pick(const double* dist, int S, int n, int* sel, hipStream_t s) {
+  const dim3 g((n + 63) / 64);
+  switch (S) {
+    case 1: hipLaunchKernelGGL(pit_pick_k<1>, g, dim3(64), 0, s, dist, n, sel); break;
+    case 2: hipLaunchKernelGGL(pit_pick_k<2>, g, dim3(64), 0, s, dist, n, sel); break;
+    case 3: hipLaunchKernelGGL(pit_pick_k<3>, g, dim3(64), 0, s, dist, n, sel); break;
+    case 4: hipLaunchKernelGGL(pit_pick_k<4>, g, dim3(64), 0, s, dist, n, sel); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 

@@ -8,13 +8,13 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <string>
 #include <vector>
 
 namespace mn {
 hipError_t launch_unpack_ex(const float* src, int Cbuf, int Tp, int S, int T, int F, int c_re0, int c_im0, int mode,
                             int M, const int* sel, float2* dst, int n_out, int* nan_flag, hipStream_t s);
-hipError_t launch_pit_dist_k(const PitArgs& p, int K, double* dist, hipStream_t s);
 hipError_t launch_compose_sel(const int* shift_sel, const int* clean_sel, int B, int M, int S, int* out, hipStream_t s);
 hipError_t launch_assemble3(const float* in1, long long in1_bstride, const float* out1, long long out1_bstride,
                             const int* sel, int B, int M, int S, int ref_ch, int F, int Tp, float* in3,
@@ -52,19 +52,30 @@ struct Prof {
   std::vector<ProfRec> recs;
   bool overflow = false;
 };
-static Prof g_prof;
+// one state per device (events belong to the device that was current when they were created); a process that drives
+// several GPUs profiles each of them independently
+constexpr int MAX_DEV = 64;
+static Prof g_profs[MAX_DEV];
+static std::atomic<int> g_prof_any{0};          // fast path: no hipGetDevice per launch while nobody profiles
+static int cur_dev() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MAX_DEV) d = 0;
+  return d;
+}
 struct ProfScope {
-  hipStream_t s; int kind; hipEvent_t e0 = nullptr, e1 = nullptr; bool active = false;
+  hipStream_t s; int kind; hipEvent_t e0 = nullptr, e1 = nullptr; bool active = false; Prof* pr = nullptr;
   ProfScope(hipStream_t s_, int kind_) : s(s_), kind(kind_) {
-    if (!g_prof.on) return;
-    if (g_prof.used + 2 > g_prof.pool.size()) { g_prof.overflow = true; return; }
-    e0 = g_prof.pool[g_prof.used++];
-    e1 = g_prof.pool[g_prof.used++];
+    if (!g_prof_any.load(std::memory_order_relaxed)) return;
+    pr = &g_profs[cur_dev()];
+    if (!pr->on) return;
+    if (pr->used + 2 > pr->pool.size()) { pr->overflow = true; return; }
+    e0 = pr->pool[pr->used++];
+    e1 = pr->pool[pr->used++];
     active = (hipEventRecord(e0, s) == hipSuccess);
   }
   ~ProfScope() {
     if (!active) return;
-    if (hipEventRecord(e1, s) == hipSuccess) g_prof.recs.push_back({kind, e0, e1});
+    if (hipEventRecord(e1, s) == hipSuccess) pr->recs.push_back({kind, e0, e1});
   }
 };
 
@@ -376,7 +387,10 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
     a.wps_nstride = L.wps_nstride;
     a.btab = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + L.btab_base) + (long long)n0 * L.btab_nstride;
     a.btab_nstride = L.btab_nstride;
-    HIPCHK(launch_conv_wprep(a, n->w_dev + c.wf_off, nb, s));      // not event-timed: part of the step, not of the conv kernel
+    {
+      ProfScope pw(s, PK_OTHER);                                   // its own kind: part of the step, not of the conv kernel
+      HIPCHK(launch_conv_wprep(a, n->w_dev + c.wf_off, nb, s));
+    }
     ProfScope ps(s, PK_CONV);
     HIPCHK(launch_conv_bf16_dma(a, nb, s));
     return MISONET_OK;
@@ -471,7 +485,7 @@ const char* misonet_strerror(int code) {
   }
 }
 const char* misonet_last_error(void) { return g_err; }
-int misonet_version(void) { return 100; }
+int misonet_version(void) { return 200; }
 
 int misonet_net_create(const misonet_cfg* cfg, misonet_net** out) {
   if (!cfg || !out) return fail(MISONET_EINVAL, "null argument");
@@ -734,13 +748,11 @@ int misonet_mvdr_debug(const void* ws, int B, int F, int M, void* steer, void* w
 
 int misonet_pit_select(const void* anchor, const void* cand, int B, int S, int T, int F, int* sel, double* dist,
                        misonet_stream stream) {
-  if (!anchor || !cand || !sel) return fail(MISONET_EINVAL, "null argument");
-  if (S != 2) return fail(MISONET_EINVAL, "PIT alignment supports num_spks == 2 only (got %d)", S);
+  if (!anchor || !cand || !sel || !dist) return fail(MISONET_EINVAL, "null argument (dist is required scratch: B*S*S doubles)");
+  if (S < 1 || S > 4) return fail(MISONET_EINVAL, "PIT alignment enumerates S! permutations: 1 <= num_spks <= 4 (got %d)", S);
+  if (B <= 0 || T <= 0 || F <= 0) return fail(MISONET_EINVAL, "B, T, F must be positive");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  double* d = dist;
-  bool own = false;
-  if (!d) { HIPCHK(hipMalloc(reinterpret_cast<void**>(&d), (size_t)B * 4 * sizeof(double))); own = true; }
-  HIPCHK(hipMemsetAsync(d, 0, (size_t)B * 4 * sizeof(double), s));
+  HIPCHK(hipMemsetAsync(dist, 0, (size_t)B * S * S * sizeof(double), s));
   const float* a = reinterpret_cast<const float*>(anchor);
   const float* c = reinterpret_cast<const float*>(cand);
   PitArgs p;
@@ -748,23 +760,27 @@ int misonet_pit_select(const void* anchor, const void* cand, int B, int S, int T
   p.a = {a, a + 1, 2LL * S * T * F, 2, 2LL * T * F, 2 * F};
   p.b = {c, c + 1, 2LL * S * T * F, 2, 2LL * T * F, 2 * F};
   p.B = B; p.F = F; p.T = T;
-  HIPCHK(launch_pit_dist(p, d, s));
-  HIPCHK(launch_pit_pick(d, B, sel, s));
-  if (own) { HIPCHK(hipStreamSynchronize(s)); HIPCHK(hipFree(d)); }
+  HIPCHK(launch_pit_dist_k(p, S, 1, dist, s));
+  HIPCHK(launch_pit_pick(dist, S, B, sel, s));
   return MISONET_OK;
 }
 
 // ---- STFT front-end ------------------------------------------------------------------------------------------------
-static float* g_twid = nullptr;
+// twiddle table + the > 64 KB dynamic-LDS attribute of stft_pack_k, per device (the table lives in the memory of the
+// device that was current when it was first needed)
+static float* g_twid[MAX_DEV] = {};
 static int get_twiddles(const float** out) {
-  if (!g_twid) {
+  const int d = cur_dev();
+  if (!g_twid[d]) {
     std::vector<float> tw((size_t)stft_twiddle_count());
     stft_build_twiddles(tw.data());
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&g_twid), tw.size() * sizeof(float)));
-    HIPCHK(hipMemcpy(g_twid, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
+    float* p = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&p), tw.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(p, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(stft_init());
+    g_twid[d] = p;
   }
-  *out = g_twid;
+  *out = g_twid[d];
   return MISONET_OK;
 }
 
@@ -813,7 +829,7 @@ static PipeLayout pipe_layout(const misonet_pipeline* p, int B, int T) {
   P.L3 = make_layout(p->n3, B * p->S, T);
   const int F = p->n1->cfg.n_freq, Tp = P.L1.Tp;
   long long o = 256;                                   // [0]: nan flag
-  P.off_dist = o;  o += align_up((long long)(B * p->M + B) * 4 * 8, 256);
+  P.off_dist = o;  o += align_up((long long)(B * p->M + B) * p->S * p->S * 8, 256);
   P.off_sel = o;   o += align_up((long long)(B * p->M * p->S * 2 + B * p->S) * 4, 256);
   P.off_mvdr = o;  o += align_up(mvdr_ws_bytes(B, p->S, F, p->M), 256);
   P.clean_bstride = (long long)2 * p->S * F * Tp;
@@ -827,7 +843,7 @@ static PipeLayout pipe_layout(const misonet_pipeline* p, int B, int T) {
 int misonet_pipeline_create(misonet_net* n1, misonet_net* n3, int num_mic, int num_spk, int ref_ch, float epsi,
                             misonet_pipeline** out) {
   if (!n1 || !n3 || !out) return fail(MISONET_EINVAL, "null argument");
-  if (num_spk != 2) return fail(MISONET_EINVAL, "the pipeline supports num_spks == 2 (PIT over 2 permutations)");
+  if (num_spk < 1 || num_spk > 4) return fail(MISONET_EINVAL, "num_spk must be in [1, 4] (PIT enumerates num_spk! permutations)");
   if (num_mic < 2 || num_mic > 8) return fail(MISONET_EINVAL, "num_mic must be in [2, 8]");
   if (ref_ch < 0 || ref_ch >= num_mic) return fail(MISONET_EINVAL, "ref_ch out of range");
   if (n1->cfg.in_ch != 2 * num_mic || n1->cfg.out_ch != 2 * num_spk)
@@ -859,8 +875,8 @@ static int pipeline_run_impl(misonet_pipeline* p, const void* mix, const void* c
   void* ws3 = base + P.off_ws3;
   const int M = p->M, S = p->S, F = p->n1->cfg.n_freq, Tp = P.L1.Tp;
   misonet_net *n1 = p->n1, *n3 = p->n3;
-  double* dist_shift = reinterpret_cast<double*>(base + P.off_dist);          // [B*M][4]
-  double* dist_clean = dist_shift + (long long)B * M * 4;                      // [B][4]
+  double* dist_shift = reinterpret_cast<double*>(base + P.off_dist);          // [B*M][S][S]
+  double* dist_clean = dist_shift + (long long)B * M * S * S;                  // [B][S][S]
   int* sel_shift = reinterpret_cast<int*>(base + P.off_sel);                   // [B*M][S]
   int* sel_final = sel_shift + (long long)B * M * S;                           // [B*M][S]
   int* sel_clean = sel_final + (long long)B * M * S;                           // [B][S]
@@ -886,8 +902,8 @@ static int pipeline_run_impl(misonet_pipeline* p, const void* mix, const void* c
     q.a = {anc, anc + S * plane, (long long)M * out1_bs, Tp, plane, 1};
     q.b = {out1, out1 + S * plane, out1_bs, Tp, plane, 1};
     q.B = B; q.F = F; q.T = T;
-    HIPCHK(launch_pit_dist_k(q, M, dist_shift, s));
-    HIPCHK(launch_pit_pick(dist_shift, B * M, sel_shift, s));
+    HIPCHK(launch_pit_dist_k(q, S, M, dist_shift, s));
+    HIPCHK(launch_pit_pick(dist_shift, S, B * M, sel_shift, s));
   }
   // 3. align to the clean references at ref_ch (tester.py:889-915), optional
   if (clean || clean_wav) {
@@ -901,8 +917,8 @@ static int pipeline_run_impl(misonet_pipeline* p, const void* mix, const void* c
     q.a = {cl, cl + S * plane, P.clean_bstride, Tp, plane, 1};
     q.b = {cand, cand + S * plane, (long long)M * out1_bs, Tp, plane, 1};
     q.B = B; q.F = F; q.T = T;
-    HIPCHK(launch_pit_dist_k(q, 1, dist_clean, s));
-    HIPCHK(launch_pit_pick(dist_clean, B, sel_clean, s));
+    HIPCHK(launch_pit_dist_k(q, S, 1, dist_clean, s));
+    HIPCHK(launch_pit_pick(dist_clean, S, B, sel_clean, s));
   }
   HIPCHK(launch_compose_sel(sel_shift, (clean || clean_wav) ? sel_clean : nullptr, B, M, S, sel_final, s));
 
@@ -963,29 +979,33 @@ int misonet_pipeline_check(misonet_pipeline* p, const void* ws, misonet_stream s
 // ---- per-launch profiling -----------------------------------------------------------------------------------------
 int misonet_profile_begin(int max_launches) {
   if (max_launches <= 0) return fail(MISONET_EINVAL, "max_launches must be positive");
-  while (g_prof.pool.size() < (size_t)max_launches * 2) {
+  Prof& pr = g_profs[cur_dev()];
+  while (pr.pool.size() < (size_t)max_launches * 2) {
     hipEvent_t e;
     HIPCHK(hipEventCreate(&e));
-    g_prof.pool.push_back(e);
+    pr.pool.push_back(e);
   }
-  g_prof.used = 0;
-  g_prof.recs.clear();
-  g_prof.overflow = false;
-  g_prof.on = true;
+  pr.used = 0;
+  pr.recs.clear();
+  pr.overflow = false;
+  if (!pr.on) g_prof_any.fetch_add(1);
+  pr.on = true;
   return MISONET_OK;
 }
 int misonet_profile_end(double* ms_by_kind, long long* launches_by_kind) {
-  g_prof.on = false;
+  Prof& pr = g_profs[cur_dev()];
+  if (pr.on) g_prof_any.fetch_sub(1);
+  pr.on = false;
   if (!ms_by_kind || !launches_by_kind) return fail(MISONET_EINVAL, "null argument");
   for (int k = 0; k < PK_N; ++k) { ms_by_kind[k] = 0.0; launches_by_kind[k] = 0; }
-  for (const ProfRec& r : g_prof.recs) {
+  for (const ProfRec& r : pr.recs) {
     HIPCHK(hipEventSynchronize(r.e1));
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, r.e0, r.e1));
     ms_by_kind[r.kind] += ms;
     launches_by_kind[r.kind] += 1;
   }
-  if (g_prof.overflow) return fail(MISONET_ENOMEM, "profile event pool exhausted");
+  if (pr.overflow) return fail(MISONET_ENOMEM, "profile event pool exhausted");
   return MISONET_OK;
 }
 

@@ -61,8 +61,12 @@ __global__ __launch_bounds__(256) void tcn_prepare_k(const float* raw, long long
 // d = PReLU(dwconv(ELU(IN1d(x)))), kernel 3, dilation = padding = dil, no bias (model.py:556-558)
 // One workgroup per 4 channels of one sample, one WAVE per (n, c) row: a = ELU(IN1d(x)) is computed once per frame
 // into the wave's LDS row (zero outside [0, T): Conv1d pads its input, i.e. the ELU output), then every lane produces
-// 4 consecutive frames per pass from LDS.  One float64 atomic pair per workgroup for the gLN sums.
-constexpr int DW_MAXT = 2048;          // frames per row kept in LDS (4 rows x 8 KB)
+// 4 consecutive frames per pass from LDS.  Rows longer than the LDS row are walked in segments of DW_SEG frames with a
+// DW_HALO-frame halo on both sides (dil <= DW_HALO), so there is no limit on T; T = 1001 is one segment.  One float64
+// atomic pair per workgroup for the gLN sums.
+constexpr int DW_MAXT = 2048;                      // frames per row kept in LDS (4 rows x 8 KB)
+constexpr int DW_HALO = 64;                        // largest dilation of TemporalConvNet(2, 7, ...): 2^6
+constexpr int DW_SEG = DW_MAXT - 2 * DW_HALO;      // output frames per segment
 __global__ __launch_bounds__(256) void tcn_dw_k(const float* x, const double* x_stats, const float* wdw,
                                                 const float* prelu, float* d, double* gln_stats, int C, int T,
                                                 int Tp, int dil) {
@@ -79,34 +83,44 @@ __global__ __launch_bounds__(256) void tcn_dw_k(const float* x, const double* x_
   float* dst = d + ((long long)n * C + c) * Tp;
   float* a = s_a[wave];
   const int Tq = (T + 3) & ~3;
-  for (int t = lane * 4; t < Tq; t += 256) {
-    const float4 v = *reinterpret_cast<const float4*>(src + t);          // Tp is a multiple of 32 >= Tq
-    float4 o;
-    o.x = (t + 0 < T) ? elu_fast(fmaf(v.x, sc, sh)) : 0.f;
-    o.y = (t + 1 < T) ? elu_fast(fmaf(v.y, sc, sh)) : 0.f;
-    o.z = (t + 2 < T) ? elu_fast(fmaf(v.z, sc, sh)) : 0.f;
-    o.w = (t + 3 < T) ? elu_fast(fmaf(v.w, sc, sh)) : 0.f;
-    *reinterpret_cast<float4*>(a + t) = o;
-  }
-  __syncthreads();
-  float s1 = 0.f, s2 = 0.f;
-  for (int t = lane * 4; t < Tq; t += 256) {
-    float o[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int tc = t + i;
-      const int tl = tc - dil, tr = tc + dil;
-      float acc = w1 * a[tc];
-      if (tl >= 0) acc = fmaf(w0, a[tl], acc);
-      if (tr < Tq) acc = fmaf(w2, a[tr], acc);                             // a[] is zero for T <= t < Tq
-      acc = acc > 0.f ? acc : slope * acc;
-      o[i] = acc;
-      if (tc < T) { s1 += acc; s2 = fmaf(acc, acc, s2); }
+  double r1 = 0.0, r2 = 0.0;
+  for (int ts = 0; ts < Tq; ts += DW_SEG) {
+    if (ts) __syncthreads();                                             // the previous segment is consumed
+    // LDS slot j holds frame ts - DW_HALO + j
+    for (int j = lane * 4; j < DW_MAXT; j += 256) {
+      const int t = ts - DW_HALO + j;
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t >= 0 && t < Tq) {                                            // Tp is a multiple of 32 >= Tq
+        const float4 v = *reinterpret_cast<const float4*>(src + t);
+        o.x = (t + 0 < T) ? elu_fast(fmaf(v.x, sc, sh)) : 0.f;
+        o.y = (t + 1 < T) ? elu_fast(fmaf(v.y, sc, sh)) : 0.f;
+        o.z = (t + 2 < T) ? elu_fast(fmaf(v.z, sc, sh)) : 0.f;
+        o.w = (t + 3 < T) ? elu_fast(fmaf(v.w, sc, sh)) : 0.f;
+      }
+      *reinterpret_cast<float4*>(a + j) = o;
     }
-    *reinterpret_cast<float4*>(dst + t) = make_float4(o[0], o[1], o[2], o[3]);
+    __syncthreads();
+    const int te = (ts + DW_SEG < Tq) ? ts + DW_SEG : Tq;
+    float s1 = 0.f, s2 = 0.f;
+    for (int t = ts + lane * 4; t < te; t += 256) {
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int tc = t + i;
+        const int j = tc - ts + DW_HALO;
+        float acc = w1 * a[j];
+        acc = fmaf(w0, a[j - dil], acc);                                 // zero outside [0, T)
+        acc = fmaf(w2, a[j + dil], acc);
+        acc = acc > 0.f ? acc : slope * acc;
+        o[i] = acc;
+        if (tc < T) { s1 += acc; s2 = fmaf(acc, acc, s2); }
+      }
+      *reinterpret_cast<float4*>(dst + t) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    // per-lane partials of a segment hold <= 32 terms in float; accumulate in float64
+    r1 += (double)s1;
+    r2 += (double)s2;
   }
-  // per-lane partials hold <= 16 terms in float; reduce in float64
-  double r1 = s1, r2 = s2;
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) {
     r1 += __shfl_xor(r1, m, 64);
@@ -274,7 +288,7 @@ hipError_t launch_tcn_prepare(const float* raw, long long raw_bstride, int raw_c
 
 hipError_t launch_tcn_dw(const float* x, const double* x_stats, const float* wdw, const float* prelu, float* d,
                          double* gln_stats, int C, int T, int Tp, int dilation, int n_samples, hipStream_t s) {
-  if (((T + 3) & ~3) > DW_MAXT) return hipErrorInvalidValue;
+  if (dilation < 1 || dilation > DW_HALO) return hipErrorInvalidValue;
   if (C % 4) return hipErrorInvalidValue;
   hipLaunchKernelGGL(tcn_dw_k, dim3(C / 4, n_samples), dim3(256), 0, s, x, x_stats, wdw, prelu, d, gln_stats, C, T, Tp,
                      dilation);

@@ -71,8 +71,15 @@ class _Trunk:
             raise RuntimeError("misonet_amd needs a ROCm device (no CPU fallback)")
         if device is None:
             device = torch.cuda.current_device()
-        self._device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
-        self._committed = False
+        d = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        if d.type != "cuda":
+            raise RuntimeError(f"misonet_amd runs on ROCm devices only (got {d})")
+        if d.index is None:            # "cuda" -> "cuda:<current>": torch.device("cuda") != torch.device("cuda:0")
+            d = torch.device("cuda", torch.cuda.current_device())
+        if d != self._device:
+            self._committed = False    # weights are uploaded to the device that is current at commit
+            self._ws.clear()
+        self._device = d
         return self
 
     def to(self, device):

@@ -22,6 +22,7 @@ import torch
 from . import _lib
 from . import stft as S
 from .model import MISO_1, MISO_3
+from .weights import N_FREQ
 
 
 def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
@@ -75,6 +76,8 @@ class Enhancer:
         if model._device is None:
             model.cuda(model_sep._device)
         self.device = model_sep._device
+        if model._device != self.device:
+            raise RuntimeError(f"MISO_1 is on {self.device} but MISO_3 on {model._device}")
         model_sep._commit()
         model._commit()
         self._pipe = C.c_void_p()
@@ -90,6 +93,28 @@ class Enhancer:
         except Exception:
             pass
 
+    def _ready(self):
+        """Re-commit after a later ``load_state_dict`` / ``.cuda()`` on either model (a checkpoint loaded after the
+        Enhancer was built clears the committed state) and follow a device move."""
+        if self.model_sep._device != self.model._device:
+            raise RuntimeError(f"MISO_1 is on {self.model_sep._device} but MISO_3 on {self.model._device}")
+        if self.model_sep._device != self.device:
+            self.device = self.model_sep._device
+            self._ws.clear()
+        self.model_sep._commit()
+        self.model._commit()
+
+    def _check_c64(self, x, name, shape=None):
+        """shared argument check of enhance / separate: complex tensor on this Enhancer's device, optional shape"""
+        if not isinstance(x, torch.Tensor) or not x.is_complex():
+            raise TypeError(f"{name} must be a complex torch tensor")
+        if x.device != self.device:
+            raise RuntimeError(f"Expected all tensors to be on the same device, but found {name} on {x.device} and the "
+                               f"models on {self.device}")
+        if shape is not None and tuple(x.shape) != tuple(shape):
+            raise ValueError(f"{name} must be {list(shape)}, got {list(x.shape)}")
+        return x.to(torch.complex64).contiguous()
+
     def workspace(self, B, T):
         ws = self._ws.get((B, T))
         if ws is None:
@@ -104,17 +129,23 @@ class Enhancer:
         """mix complex [B,M,T,F] (device); clean complex [B,S,T,F] = clean sources at ref_ch (tester.py:889-891) or
         None to skip the clean-reference re-ordering.  Returns MISO3 output complex64 [B,S,T,F]
         (and a dict with 'bf' [B,S,T,F] / 'miso1' [B,S,M,T,F] when requested)."""
-        mix = mix.to(torch.complex64).contiguous()
+        self._ready()
+        if not isinstance(mix, torch.Tensor) or mix.dim() != 4:
+            raise ValueError("mix must be a 4-D complex tensor [B, M, T, F]")
+        mix = self._check_c64(mix, "mix")
         B, M, T, F = mix.shape
         if M != self.num_ch:
             raise ValueError(f"expected {self.num_ch} microphones, got {M}")
+        if F != N_FREQ:
+            raise ValueError(f"the networks are defined for F = {N_FREQ} frequency bins, got {F}")
         if clean is not None:
-            clean = clean.to(torch.complex64).contiguous()
-            if tuple(clean.shape) != (B, self.num_spks, T, F):
-                raise ValueError("clean must be [B, num_spks, T, F]")
+            clean = self._check_c64(clean, "clean", (B, self.num_spks, T, F))
         ws = self.workspace(B, T)
         if out is None:
             out = torch.empty((B, self.num_spks, T, F), dtype=torch.complex64, device=self.device)
+        elif (not isinstance(out, torch.Tensor) or out.dtype != torch.complex64 or out.device != self.device
+              or tuple(out.shape) != (B, self.num_spks, T, F) or not out.is_contiguous()):
+            raise ValueError(f"out must be a contiguous complex64 tensor [{B}, {self.num_spks}, {T}, {F}] on {self.device}")
         bf = torch.empty_like(out) if want_bf else None
         m1 = torch.empty((B, self.num_spks, M, T, F), dtype=torch.complex64, device=self.device) if want_miso1 else None
         L = _lib.lib()
@@ -135,11 +166,19 @@ class Enhancer:
         time-major as ``librosa.load(...).T``), clean_wav float32 [B, n_samples, S] = the clean sources at ref_ch, or
         None.  The STFT front-end runs as a HIP kernel straight into the network's layout; returns what
         :meth:`enhance` returns (T = n_samples // 64 + 1 frames)."""
+        self._ready()
+        if not isinstance(wav, torch.Tensor) or wav.dim() != 3 or wav.is_complex():
+            raise ValueError("wav must be a real 3-D tensor [B, n_samples, M]")
+        if wav.device != self.device:
+            raise RuntimeError(f"Expected all tensors to be on the same device, but found wav on {wav.device} and the "
+                               f"models on {self.device}")
         wav = wav.to(torch.float32).contiguous()
         B, Ls, M = wav.shape
         if M != self.num_ch:
             raise ValueError(f"expected {self.num_ch} microphones, got {M}")
         if clean_wav is not None:
+            if not isinstance(clean_wav, torch.Tensor) or clean_wav.device != self.device:
+                raise RuntimeError(f"clean_wav must be a tensor on {self.device}")
             clean_wav = clean_wav.to(torch.float32).contiguous()
             if tuple(clean_wav.shape) != (B, Ls, self.num_spks):
                 raise ValueError("clean_wav must be [B, n_samples, num_spks]")
@@ -164,10 +203,17 @@ class Enhancer:
     def separate(self, mix: torch.Tensor, clean: Optional[torch.Tensor] = None, check_nan=True) -> torch.Tensor:
         """Separation stage only: MISO1_Inference over the circular shifts + alignments (tester.py:1014-1068, 889-915).
         mix complex [B,M,T,F] -> aligned estimates complex64 [B,S,M,T,F] (speaker, microphone)."""
-        mix = mix.to(torch.complex64).contiguous()
+        self._ready()
+        if not isinstance(mix, torch.Tensor) or mix.dim() != 4:
+            raise ValueError("mix must be a 4-D complex tensor [B, M, T, F]")
+        mix = self._check_c64(mix, "mix")
         B, M, T, F = mix.shape
+        if M != self.num_ch:
+            raise ValueError(f"expected {self.num_ch} microphones, got {M}")
+        if F != N_FREQ:
+            raise ValueError(f"the networks are defined for F = {N_FREQ} frequency bins, got {F}")
         if clean is not None:
-            clean = clean.to(torch.complex64).contiguous()
+            clean = self._check_c64(clean, "clean", (B, self.num_spks, T, F))
         ws = self.workspace(B, T)
         m1 = torch.empty((B, self.num_spks, M, T, F), dtype=torch.complex64, device=self.device)
         L = _lib.lib()

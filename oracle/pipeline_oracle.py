@@ -57,26 +57,38 @@ def miso1_inference(mix, sd1, ref_ch=0):
     return out, sel_all
 
 
-def enhance_utterance(mix, clean, sd1, sd3, ref_ch=0, epsi=1e-6) -> Dict[str, np.ndarray]:
+def enhance_utterance(mix, clean, sd1, sd3, ref_ch=0, epsi=1e-6, timings: Optional[dict] = None) -> Dict[str, np.ndarray]:
     """tester.py:865-939 for one utterance / one 4 s split.
 
     mix   complex [M,T,F]; clean complex [S,T,F] (clean sources at ref_ch, tester.py:889-891)
     Returns miso1 [S,M,T,F] (after clean alignment), bf [S,T,F], out [S,T,F] (MISO3), sel_clean [S].
+    ``timings`` (optional dict) receives the wall seconds of the stages: miso1_x6, mvdr_x2, miso3_x2 (bench.py's
+    cpu_baseline leg).
     """
+    import time
+    t0 = time.perf_counter()
     est, sel_shift = miso1_inference(mix, sd1, ref_ch)
     sel, _ = mvdr_oracle.pit_select(np.asarray(clean)[None], est[None, :, ref_ch])       # tester.py:902-915
     est = est[sel[0]]
+    t1 = time.perf_counter()
     S = est.shape[0]
     mix_bf = np.transpose(np.asarray(mix), (2, 0, 1))[None]                                # [1,F,M,T] tester.py:921
     bf, out = [], []
     mix_t = torch.as_tensor(np.asarray(mix))[None]
+    t_bf = t_m3 = 0.0
     for s in range(S):
+        ta = time.perf_counter()
         src = np.transpose(est[s], (2, 0, 1))[None]                                        # tester.py:923
         b = mvdr_oracle.apply_beamforming(src, mix_bf, epsi)                               # [1,T,F]
         bf.append(b[0])
+        tb = time.perf_counter()
         o = miso_oracle.miso3_forward(mix_t, torch.from_numpy(b)[:, None],
                                       torch.from_numpy(est[s, ref_ch])[None, None], sd3)   # tester.py:937-939,1242
         out.append(o[0, 0].numpy())
+        t_bf += tb - ta
+        t_m3 += time.perf_counter() - tb
+    if timings is not None:
+        timings.update(miso1_x6=t1 - t0, mvdr_x2=t_bf, miso3_x2=t_m3)
     return dict(miso1=est, bf=np.stack(bf), out=np.stack(out), sel_clean=sel[0], sel_shift=sel_shift)
 
 

@@ -27,6 +27,7 @@ def test_bench_single_process_line():
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 12.5          # north_star: >= 50x real time
+    assert d["fp32_faithful"] is True, "the headline must run fp32-faithful arithmetic (reference model.py:77-80)"
     rf = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
@@ -35,13 +36,15 @@ def test_bench_single_process_line():
 
 def test_bench_two_ranks_on_one_device():
     env = dict(os.environ, MISONET_BENCH_ONE_DEVICE="1", MISONET_BENCH_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--no-cpu-baseline", "--no-alt", "--batch", "4"]
+    # plain ``python bench.py --gpus 2``: the script starts its own ranks (torch.distributed.run on 127.0.0.1)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-alt",
+           "--batch", "4"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
     assert d["config"]["batch_per_gpu"] == 4
+    assert d["rccl_ranks"] == 2 and len(d["per_rank_utt_per_s"]) == 2
     # whole-job aggregate: 2 ranks x 4 utterances x 2 steps over the max-over-ranks time
     assert abs(d["value"] - 2 * 4 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-2

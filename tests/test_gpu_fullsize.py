@@ -1,0 +1,116 @@
+"""Full-size GPU parity (BASELINE.json configs[1]-[3]: T = 1001 frames = 4 s at 16 kHz, batch 16 -- the reference's unit
+of work is the full chunk, tester.py:917-939, config/NN_BSS.yml:72-78): the bench batch itself runs through
+``Enhancer.enhance`` in every arithmetic mode and utterances picked from inside the batch are compared stage by stage
+(MISO1 at all mics, both beamformer outputs, MISO3) with the CPU oracle run utterance by utterance; Apply_Beamforming
+alone at [1,129,6,1001].  Also the ill-conditioned-statistics case for the modes that fold the instance norm into the
+weights."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2, mag_parity
+from test_gpu_parity import _assert_parity, _utt_inputs, _need_gpu
+
+pytestmark = pytest.mark.gpu
+
+B_BENCH, T_FULL = 16, 1001
+CHECK_UTTS = (3, 12)               # positions inside the batch of 16 (different XCD / tile-walk positions)
+# measured per-mode bound on the end-to-end magnitude rel-L2 (tolerance of the path: 1e-3); fp32-faithful modes must be
+# indistinguishable from each other
+MODE_TOL = {"f32": 2e-5, "bf16x6": 2e-5, "bf16x3": 3e-4, "bf16x3p": 3e-4}
+
+
+def _modes():
+    from misonet_amd.model import _Trunk
+    return [m for m in ("f32", "bf16x6", "bf16x3") if m in _Trunk.PRECISIONS]
+
+
+@pytest.fixture(scope="module")
+def bench_batch(sd1, sd3):
+    """the 16 synthetic utterances of bench.py (rank 0) + the oracle's result for CHECK_UTTS (about 10 s each)"""
+    _need_gpu()
+    from oracle import pipeline_oracle
+    ins = [_utt_inputs(u, T_FULL) for u in range(B_BENCH)]
+    refs = {u: pipeline_oracle.enhance_utterance(ins[u][0], ins[u][1], sd1, sd3, ref_ch=0) for u in CHECK_UTTS}
+    mix = torch.from_numpy(np.stack([i[0] for i in ins]))
+    clean = torch.from_numpy(np.stack([i[1] for i in ins]))
+    return mix, clean, refs
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x6", "bf16x3"])
+def test_full_size_batch16_pipeline_vs_oracle(bench_batch, sd1, sd3, mode):
+    import misonet_amd as mz
+    from misonet_amd import weights as W
+    if mode not in _modes():
+        pytest.skip(f"mode {mode} not built")
+    mix, clean, refs = bench_batch
+    m1 = mz.MISO_1(2, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN").cuda(0)
+    m1.load_state_dict(sd1)
+    m3 = mz.MISO_3(1, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN").cuda(0)
+    m3.load_state_dict(sd3)
+    m1.eval().set_precision(mode)
+    m3.eval().set_precision(mode)
+    enh = mz.Enhancer(m1, m3, num_spks=2, ref_ch=0)
+    out, extra = enh.enhance(mix.cuda(), clean.cuda(), want_bf=True, want_miso1=True)
+    assert tuple(out.shape) == (B_BENCH, 2, T_FULL, 129)
+    tol = MODE_TOL[mode]
+    for u in CHECK_UTTS:
+        r = refs[u]
+        _assert_parity(extra["miso1"][u].cpu().numpy(), r["miso1"], f"[{mode}] utt {u} miso1 (all mics) T=1001 B=16")
+        _assert_parity(extra["bf"][u].cpu().numpy(), r["bf"], f"[{mode}] utt {u} bf T=1001 B=16")
+        _assert_parity(out[u].cpu().numpy(), r["out"], f"[{mode}] utt {u} miso3 T=1001 B=16")
+        e = mag_parity(out[u].cpu().numpy(), r["out"])[0]
+        assert e <= tol, f"[{mode}] utt {u}: end-to-end rel-L2 {e:.3e} above the mode's measured bound {tol:.0e}"
+    del enh, m1, m3
+    torch.cuda.empty_cache()
+
+
+def test_full_size_mvdr_alone():
+    """Apply_Beamforming at the reference's call shape [1,129,6,1001] (tester.py:920-924)."""
+    _need_gpu()
+    from misonet_amd import Apply_Beamforming
+    from oracle import mvdr_oracle
+    mx, cl = _utt_inputs(5, T_FULL)
+    mix = np.transpose(mx, (2, 0, 1))[None]                              # [1,F,M,T]
+    r = np.random.default_rng(55)
+    # a plausible source estimate: the clean image of speaker 0 at every mic, perturbed
+    src = (0.6 * mix + 0.05 * (r.standard_normal(mix.shape) + 1j * r.standard_normal(mix.shape))).astype(np.complex64)
+    out, dbg = Apply_Beamforming(src, mix, return_debug=True)
+    ref = mvdr_oracle.mvdr_parts(src, mix, dtype=np.complex128)
+    e_s = rel_l2(dbg["steer1"].cpu().numpy(), ref["steer1"])
+    e_w = rel_l2(dbg["w"].cpu().numpy(), ref["w"])
+    e_o = rel_l2(out.numpy(), ref["out"])
+    print(f"[mvdr full size] steer {e_s:.3e} w {e_w:.3e} out {e_o:.3e}")
+    assert tuple(out.shape) == (1, T_FULL, 129)
+    assert e_s < 1e-4 and e_w < 1e-4 and e_o < 1e-4
+
+
+@pytest.mark.parametrize("mode", ["bf16x6", "bf16x3"])
+def test_folded_norm_ill_conditioned_statistics(sd1, mode):
+    """The DMA dataflow folds the instance norm of a layer's input into the weights (W' = W * rstd, shift table): the
+    products W' * x cancel against the shift when |mean| >> std.  Inputs with a large DC offset per channel and weights
+    with large biases (post-ELU means far from zero) against the oracle."""
+    _need_gpu()
+    import misonet_amd as mz
+    from misonet_amd import weights as W
+    from oracle import miso_oracle
+    if mode not in _modes():
+        pytest.skip(f"mode {mode} not built")
+    sd = {k: v.copy() for k, v in sd1.items()}
+    r = np.random.default_rng(17)
+    for k in sd:
+        if k.endswith(".bias") and sd[k].ndim == 1:
+            sd[k] = (sd[k] + 4.0 * r.standard_normal(sd[k].shape)).astype(np.float32)    # ELU outputs with |mean| ~ 4 std
+    T = 96
+    x = (r.standard_normal((2, 6, T, 129)) + 1j * r.standard_normal((2, 6, T, 129))).astype(np.complex64)
+    x += np.complex64(25.0 + 10.0j)                                                       # DC offset 25x the std
+    m1 = mz.MISO_1(2, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN").cuda(0)
+    m1.load_state_dict(sd)
+    m1.eval().set_precision(mode)
+    y = m1(torch.from_numpy(x).cuda()).cpu().numpy()
+    y_ref = np.concatenate([miso_oracle.miso1_forward(torch.from_numpy(x[b:b + 1]), sd).numpy() for b in range(2)])
+    _assert_parity(y, y_ref, f"[{mode}] ill-conditioned statistics (DC offset, large biases)")
+    m1.set_precision("f32")
+    y32 = m1(torch.from_numpy(x).cuda()).cpu().numpy()
+    e32, em = mag_parity(y32, y_ref)[0], mag_parity(y, y_ref)[0]
+    print(f"[ill-conditioned] f32 {e32:.3e}  {mode} {em:.3e}")

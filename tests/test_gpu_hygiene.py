@@ -1,0 +1,109 @@
+"""GPU tests of the round-2 boundary work: PIT over S! permutations (S = 3 golden from the real reference), no limit on
+the number of frames in the TCN, device handling of the host-side mirror, Enhancer re-commit."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, rel_l2
+from test_gpu_parity import _assert_parity, _utt_inputs, _need_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+def test_three_speaker_separation_vs_reference_golden(sd3):
+    """Enhancer.separate with num_spks = 3 against G10 (Tester_Enhance.MISO1_Inference of the real reference)."""
+    _need_gpu()
+    import misonet_amd as mz
+    from misonet_amd import weights as W
+    g = golden("g10_miso1_inference_S3_T32.npz")
+    sd = W.make_state_dict(W.miso1_spec(num_spks=3), seed=2)
+    m1 = mz.MISO_1(3, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN").cuda(0)
+    m1.load_state_dict(sd)
+    m3 = mz.MISO_3(1, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN").cuda(0)
+    m3.load_state_dict(sd3)
+    enh = mz.Enhancer(m1.eval(), m3.eval(), num_spks=3, ref_ch=0)
+    est = enh.separate(torch.from_numpy(g["x"]).cuda(), None)[0].cpu().numpy()          # [S,M,T,F]
+    assert est.shape == (3, 6, 32, 129)
+    _assert_parity(est[:, :, ::2], g["est_even"], "3-speaker MISO1_Inference vs reference golden")
+    assert rel_l2(np.abs(est).sum(-1), g["mag_sum"]) < 1e-4
+
+
+@pytest.mark.parametrize("S", [1, 3, 4])
+def test_pit_select_general_s_vs_oracle(S):
+    _need_gpu()
+    from misonet_amd.beamform import pit_select
+    from oracle import mvdr_oracle
+    r = np.random.default_rng(90 + S)
+    B, T, F = 7, 29, 129
+    a = (r.standard_normal((B, S, T, F)) + 1j * r.standard_normal((B, S, T, F))).astype(np.complex64)
+    c = np.empty_like(a)
+    for b in range(B):                                     # a random permutation of the anchors + noise per item
+        c[b] = a[b, r.permutation(S)]
+    c += 0.1 * (r.standard_normal(c.shape) + 1j * r.standard_normal(c.shape)).astype(np.complex64)
+    sel, dist = pit_select(torch.from_numpy(a).cuda(), torch.from_numpy(c).cuda(), return_dist=True)
+    sel_ref, dist_ref = mvdr_oracle.pit_select(a, c)
+    assert np.array_equal(sel.cpu().numpy(), sel_ref)
+    assert rel_l2(dist.cpu().numpy(), dist_ref) < 1e-5
+    # all candidates equal: every permutation ties, the first (identity) wins (argmin convention)
+    same = np.repeat(a[:, :1], S, axis=1)
+    sel_t = pit_select(torch.from_numpy(a).cuda(), torch.from_numpy(same).cuda())
+    assert np.array_equal(sel_t.cpu().numpy(), np.tile(np.arange(S), (B, 1)))
+
+
+def test_long_utterance_no_frame_limit(sd1):
+    """T = 2500 frames (10 s): the depth-wise TCN kernel walks rows longer than its LDS row in segments; the reference
+    has no length limit (model.py:553-567)."""
+    _need_gpu()
+    import misonet_amd as mz
+    from misonet_amd import weights as W
+    from oracle import miso_oracle
+    m1 = mz.MISO_1(2, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN").cuda(0)
+    m1.load_state_dict(sd1)
+    mx, _ = _utt_inputs(2, 2500)
+    y = m1.eval()(torch.from_numpy(mx[None]).cuda())
+    y_ref = miso_oracle.miso1_forward(torch.from_numpy(mx[None]), sd1).numpy()
+    _assert_parity(y.cpu().numpy(), y_ref, "miso1 T=2500 vs oracle")
+    tcn = m1.tap("tcn_out", 1, 2500).cpu().numpy()
+    taps = {}
+    miso_oracle.miso1_forward(torch.from_numpy(mx[None]), sd1, taps)
+    ref = taps["tcn_out"].numpy()
+    ref = ref[..., None] if ref.ndim == 3 else ref
+    assert rel_l2(tcn, ref) < 1e-4
+
+
+def test_device_handling(sd1, sd3):
+    """.to('cuda') (index-less) must not reject cuda:0 inputs; an Enhancer follows a later load_state_dict;
+    wrong shapes / devices raise Python errors instead of faulting on the GPU."""
+    _need_gpu()
+    import misonet_amd as mz
+    from misonet_amd import weights as W
+    m1 = mz.MISO_1(2, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN").to("cuda")
+    assert m1._device == torch.device("cuda", torch.cuda.current_device())
+    m1.load_state_dict(sd1)
+    x = torch.zeros((1, 6, 8, 129), dtype=torch.complex64, device="cuda:0")
+    x.real.normal_()
+    y0 = m1.eval()(x)
+    m3 = mz.MISO_3(1, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN").cuda("cuda")
+    m3.load_state_dict(sd3)
+    enh = mz.Enhancer(m1, m3.eval(), num_spks=2, ref_ch=0)
+    o0 = enh.enhance(x)
+    # a checkpoint loaded AFTER the Enhancer was built clears the committed state: enhance must re-commit
+    sd1b = {k: (v * 1.5 if k.endswith("conv2d.weight") else v) for k, v in sd1.items()}
+    m1.load_state_dict(sd1b)
+    o1 = enh.enhance(x)
+    assert torch.isfinite(torch.view_as_real(o1)).all() and tuple(o1.shape) == tuple(o0.shape)
+    m1.load_state_dict(sd1)
+    assert rel_l2(enh.enhance(x).cpu().numpy(), o0.cpu().numpy()) < 1e-5
+    with pytest.raises(RuntimeError):
+        enh.enhance(x.cpu())                                                       # CPU tensor
+    with pytest.raises(ValueError):
+        enh.enhance(x[:, :5])                                                      # wrong mic count
+    with pytest.raises(ValueError):
+        enh.enhance(x, torch.zeros((1, 3, 8, 129), dtype=torch.complex64, device="cuda"))   # clean shape
+    with pytest.raises(ValueError):
+        enh.enhance(x, out=torch.zeros((1, 2, 8, 128), dtype=torch.complex64, device="cuda"))
+    with pytest.raises(ValueError):
+        enh.separate(x[:, :4])
+    with pytest.raises(RuntimeError):
+        enh.separate(x.cpu())
+    assert y0.shape == (1, 2, 8, 129)

@@ -112,3 +112,16 @@ def test_g9_utterance_wise_mvdr(sd1):
     for s in range(2):
         d = np.abs(wav[s].astype(np.int32) - g[f"wav{s}"].astype(np.int32))
         assert d.max() <= 2, d.max()
+
+
+def test_g10_three_speaker_pit():
+    """MISO1_Inference with num_spks = 3: the PIT alignment over all 3! permutations (tester.py:1053-1064); golden from
+    the real reference (oracle/gen_golden_pit3.py).  The shifts pick non-trivial permutations incl. 3-cycles."""
+    from misonet_amd import weights as W
+    g = golden("g10_miso1_inference_S3_T32.npz")
+    sd = W.make_state_dict(W.miso1_spec(num_spks=3), seed=2)
+    est, sel = pipeline_oracle.miso1_inference(g["x"][0], sd, ref_ch=0)
+    assert est.shape == (3, 6, 32, 129)
+    assert len({tuple(r) for r in sel.tolist()}) >= 3, sel
+    assert rel_l2(est[:, :, ::2], g["est_even"]) < 2e-5
+    assert rel_l2(np.abs(est).sum(-1), g["mag_sum"]) < 2e-5
