@@ -353,9 +353,9 @@ def _physical_cores():
 
 def cpu_baseline(sd1, sd3, T):
     """The oracle (kind "port": our stock-torch-CPU/NumPy restatement of the reference path, B = 1 per call as in
-    tester.py:846-975) on this host's cores.  Bounded sample: one forward warm-up, then 3
-    different utterances end to end with N = the cores this process may use (median reported, stages timed
-    separately), then one utterance with N = 8 threads for comparison with the survey container."""
+    tester.py:846-975) on this host's cores.  Bounded sample: one forward warm-up, one
+    utterance at each of a ladder of thread counts (8 ... physical cores), then 3 different utterances end to end at
+    the fastest count (median reported, stages timed separately).  ``cores`` = the threads of the quoted value."""
     from misonet_amd import weights as W
     from oracle import pipeline_oracle, miso_oracle
     logical = os.cpu_count() or 1
@@ -376,29 +376,36 @@ def cpu_baseline(sd1, sd3, T):
         pipeline_oracle.enhance_utterance(mix, clean, sd1, sd3, ref_ch=0, timings=stages)
         return time.perf_counter() - t0
 
-    torch.set_num_threads(threads)
+    # B = 1 convolutions do not scale to a whole 2-socket host (128 threads were 5x SLOWER than 8 on the EPYC 9575F box):
+    # probe a ladder of thread counts on one utterance each and quote the best one, stating every probe
     mix0, _ = utt(0)
+    torch.set_num_threads(min(8, threads))
     miso_oracle.miso1_forward(torch.from_numpy(mix0[None]), sd1)          # warm-up
-    t_all = time.perf_counter()
+    ladder = sorted({c for c in (8, 16, 32, 64, threads) if c <= threads})
+    probes, t_all = {}, time.perf_counter()
+    for c in ladder:
+        torch.set_num_threads(c)
+        probes[c] = timed(0)
+        if time.perf_counter() - t_all > 30.0 or (len(probes) >= 2 and probes[c] > 1.5 * min(probes.values())):
+            break
+    best = min(probes, key=probes.get)
+    torch.set_num_threads(best)
     times, stages = [], []
-    for u in range(3):
+    for u in (1, 2, 3):
         st = {}
         times.append(timed(u, st))
         stages.append(st)
-        if time.perf_counter() - t_all > 40.0:
+        if time.perf_counter() - t_all > 50.0:
             break
     med = float(np.median(times))
-    stage_med = {k: round(float(np.median([s[k] for s in stages if k in s])), 3) for k in (stages[0] if stages else {})}
-    n8 = None
-    if threads != 8 and usable >= 8:
-        torch.set_num_threads(8)
-        n8 = round(1.0 / timed(3), 4)
-        torch.set_num_threads(threads)
-    return {"value": round(1.0 / med, 4), "unit": "utt/s", "cores": threads, "kind": "port",
+    stage_med = {k: round(float(np.median([s[k] for s in stages if k in s])), 3) for k in stages[0]}
+    return {"value": round(1.0 / med, 4), "unit": "utt/s", "cores": best, "kind": "port",
             "host_logical_cpus": logical, "host_physical_cores": physical, "usable_cpus": usable,
-            "value_8_threads": n8, "stage_seconds_median": stage_med,
-            "sample": f"median of {len(times)} utterance(s) of the same synthetic workload (T={T}), B=1 per call, "
-                      f"{sum(times):.1f} s at {threads} threads" + (", plus 1 utterance at 8 threads" if n8 else "")}
+            "utt_per_s_by_threads": {str(c): round(1.0 / t, 4) for c, t in probes.items()},
+            "stage_seconds_median": stage_med,
+            "sample": f"median of {len(times)} utterance(s) of the same synthetic workload (T={T}), B=1 per call "
+                      f"(reference semantics), at the best of the probed thread counts ({best}); "
+                      f"{sum(times) + sum(probes.values()):.1f} s of CPU work in all"}
 
 
 if __name__ == "__main__":

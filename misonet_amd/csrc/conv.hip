@@ -97,8 +97,10 @@ __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[NCO][4], const float* s
 // of chunk k and are normalised and written to LDS after it, so HBM/L2 latency hides under the matrix work.
 // Staging roles are division-free: thread (q = tid & 31, ci = tid >> 5) owns frames t0+4q..t0+4q+3 of channel ci
 // for every staged row; threads < 16*NR own the two halo frames t0-1 / t0+128 of one (row, channel).
-template <int NCO, int MODE>
-__global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2) ? 3 : 2)) void conv3x3_mfma(const ConvArgs a) {
+// OCTP = 3: the instantiations that write the bf16x6 oct layout (hi | mid | lo parts; the planar-input layers in front
+// of a dense block when the network runs in the bf16x6 mode).
+template <int NCO, int MODE, int OCTP = 0>
+__global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0) ? 3 : 2)) void conv3x3_mfma(const ConvArgs a) {
   constexpr int COP = NCO * 32;
   constexpr int NR = MODE == 0 ? 6 : (MODE == 1 ? 9 : 3);
   constexpr int SF = MODE == 1 ? 2 : 1;
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2) ? 3 : 2)) void conv3x
   }
 
   float* s_red = smem;   // [FT waves][COP][2]  (safe: the loop ends with a barrier after the last reads)
-  conv_epilogue<NCO>(a, acc, n, cg, f, t0, row_ok, lane, s_red + wave * (COP * 2));
+  conv_epilogue<NCO, 4, OCTP>(a, acc, n, cg, f, t0, row_ok, lane, s_red + wave * (COP * 2));
   if (a.act) {
     __syncthreads();
     if (tid < COP * 2) {
@@ -291,9 +293,9 @@ static size_t conv_lds_bytes(int NR, int cop, int Cin) {
   return (size_t)(CK * NR * TW + 9 * CK * cop) * sizeof(float) + (size_t)nchunk * CK * sizeof(float2);
 }
 
-template <int NCO, int MODE>
+template <int NCO, int MODE, int OCTP = 0>
 static hipError_t set_lds_attr() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma<NCO, MODE>),
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma<NCO, MODE, OCTP>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
 }
 
@@ -304,7 +306,11 @@ hipError_t conv_init() {
   if ((e = set_lds_attr<1, 2>()) != hipSuccess) return e;
   if ((e = set_lds_attr<2, 0>()) != hipSuccess) return e;
   if ((e = set_lds_attr<2, 1>()) != hipSuccess) return e;
-  return set_lds_attr<2, 2>();
+  if ((e = set_lds_attr<2, 2>()) != hipSuccess) return e;
+  if ((e = set_lds_attr<1, 0, 3>()) != hipSuccess) return e;
+  if ((e = set_lds_attr<1, 2, 3>()) != hipSuccess) return e;
+  if ((e = set_lds_attr<2, 0, 3>()) != hipSuccess) return e;
+  return set_lds_attr<2, 2, 3>();
 }
 
 int conv_xcd_env() {
@@ -320,12 +326,19 @@ hipError_t launch_conv(const ConvArgs& a_in, int n_samples, hipStream_t s) {
   const int mode = a.tr2 ? 2 : (a.sf == 2 ? 1 : 0);
   if (a.NR != conv_rows(a.sf, a.tr2)) return hipErrorInvalidValue;
 #define MN_LAUNCH(NCO, MODE) hipLaunchKernelGGL((conv3x3_mfma<NCO, MODE>), grid, dim3(256), lds, s, a)
-  if (a.cop == 32) {
+#define MN_LAUNCH3(NCO, MODE) hipLaunchKernelGGL((conv3x3_mfma<NCO, MODE, 3>), grid, dim3(256), lds, s, a)
+  if (a.out_oct) {
+    // planar float32 in, bf16x6 oct layout out: only the layer shapes that occur in front of a dense block
+    if (a.out_oct != 3 || mode == 1 || (a.Cout & 7) || (a.out_c0 & 7) || (a.out_sstride & 7)) return hipErrorInvalidValue;
+    if (a.cop == 32) { if (mode == 0) MN_LAUNCH3(1, 0); else MN_LAUNCH3(1, 2); }
+    else { if (mode == 0) MN_LAUNCH3(2, 0); else MN_LAUNCH3(2, 2); }
+  } else if (a.cop == 32) {
     if (mode == 0) MN_LAUNCH(1, 0); else if (mode == 1) MN_LAUNCH(1, 1); else MN_LAUNCH(1, 2);
   } else {
     if (mode == 0) MN_LAUNCH(2, 0); else if (mode == 1) MN_LAUNCH(2, 1); else MN_LAUNCH(2, 2);
   }
 #undef MN_LAUNCH
+#undef MN_LAUNCH3
   return hipGetLastError();
 }
 

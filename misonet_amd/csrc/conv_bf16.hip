@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 1) ? 2 : 1)) void conv3x
 
   // ---- epilogue (conv_epilogue.hpp) ----
   float* s_red = reinterpret_cast<float*>(smem_b);   // [FT][COP][2]
-  conv_epilogue<NCO, 4, true>(a, acc, n, cg, f, t0, row_ok, lane, s_red + wave * (COP * 2), s_bias);
+  conv_epilogue<NCO, 4, 2>(a, acc, n, cg, f, t0, row_ok, lane, s_red + wave * (COP * 2), s_bias);
   STAMP();
   if (a.act) {
     __syncthreads();

@@ -1,0 +1,484 @@
+// conv3x3_bf16x6: the 3x3 convolution family (reference model.py:401-482) in FP32-FAITHFUL arithmetic on the bf16 matrix
+// cores.  The reference computes these layers in float32 (model.py:77-80 `.float()`, nn.Conv2d / nn.ConvTranspose2d
+// model.py:401-466); this kernel keeps that arithmetic class at 2.67x the rate of the fp32 MFMA:
+//
+//   * both operands are represented EXACTLY as three bf16 pieces, x = x_h + x_m + x_l (float32 has 24 significant
+//     bits = 3 x 8, bf16 has float32's exponent range; split3_pair_t in conv_epilogue.hpp);
+//   * a product is evaluated as the six leading partial products
+//         w_h x_h + (w_h x_m + w_m x_h) + (w_h x_l + w_m x_m + w_l x_h)
+//     each on v_mfma_f32_32x32x16_bf16 with float32 accumulation; every partial product of two bf16 numbers is exact in
+//     float32, and the three dropped ones (w_m x_l, w_l x_m, w_l x_l) are below 2^-23 |w x| -- the size of ONE float32
+//     rounding of the product, of which the fp32 FMA chain of the reference makes one per accumulation step;
+//   * 6 x 32 cycles per 32x32x16 block against 8 x 64 on v_mfma_f32_32x32x2_f32.
+//
+// Data flow = the DMA dataflow of conv_bf16_dma.hip with three parts instead of two:
+//   * activations travel in the "oct3" layout: per sample [hi | mid | lo] parts, each [c/8][f][Tp][8] bf16 (8 channels
+//     of one frame = one 16-byte unit = one lane's MFMA operand), values RAW (bias + ELU, no instance norm), written
+//     pre-split by the PRODUCER's epilogue;
+//   * the instance norm of a layer's input is folded into per-sample weights W'[n] = W * rstd[n][ci] (float32, then split
+//     exactly into three bf16 pieces by conv_wprep6_k) plus the border-aware shift table of conv_epilogue.hpp;
+//   * staging is `buffer_load_dwordx4 ... lds` (LDS-DMA) issued by four producer waves of a persistent 8-wave workgroup
+//     (one per CU, XCD-local tile walk), two complete stages in LDS, one workgroup barrier per K-chunk.
+// What is different from the bf16x3 kernel besides the third part:
+//   * a K-chunk is 8 input channels (one octet), so NO layer pads K (Cin = 24 / 72 / 120 cost 25 / 10 / 6 % there);
+//   * the 16-deep K of an MFMA is filled by PAIRING TIME TAPS: lanes 0-31 (k = 0..7) read the 8 channels at time tap
+//     kt = 0 and lanes 32-63 (k = 8..15) the same 8 channels at kt = 1 -- for the B operand that is just a per-lane LDS
+//     address (frame + half), for the A operand a [kt0 | kt1] weight image.  The odd tap kt = 2 is paired ACROSS PARTS:
+//     B = [x_h | x_m] with A = [w_h | w_h] gives hh + hm, A = [w_m | w_m] gives mh + mm, and B = [x_l | x_h] with
+//     A = [w_h | w_l] gives hl + lh.  27 MFMAs per (output row, chunk) = 9 taps x 6 terms x 8 channels / 16: no padding;
+//   * row reuse as in the bf16x3 kernel: an input fragment of staged row R serves the output rows f' with f' + kf = R,
+//     and the 18 weight fragments of a phase stay in registers: 48 LDS fragment reads per 108 MFMAs;
+//   * all layer types run 4-row tiles (the 9 staged rows of a stride-2 tile fit: 140 KB for two stages).
+#include "kernels.hpp"
+#include "conv_epilogue.hpp"
+#include "conv_bf16_core.hpp"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+namespace mn {
+
+#define MN_LDS(p) ((__attribute__((address_space(3))) void*)(p))
+
+constexpr int X6_TW = 130;                  // staged frames per input row: slot j <-> frame t0 - 1 + j
+constexpr int X6_WPAIR = 3 * 3 * 2 * 32;    // units of the [kf][part][kt0 | kt1][co] image
+constexpr int X6_WU = X6_WPAIR + 3 * 3 * 32;   // + [kf][part][co] of kt = 2: 864 x 16 bytes per (chunk, group)
+
+template <int SF, bool TR2>
+__device__ __forceinline__ constexpr bool use6(int fr, int kf, int R) {
+  return TR2 ? ((((fr + kf) & 1) == 0) && (((fr + kf) >> 1) == R)) : (SF * fr + kf == R);
+}
+
+// MFMA work of one K-chunk (8 input channels) for one consumer wave: 32 frames x 4 output rows x 32 output channels.
+//   sx: the three input part images [part][NR][X6_TW] (16-byte units), sw: the weight image of the chunk.
+// Phase A (time taps 0|1 paired in K): per staged row R three B fragments (h, m, l) and per (fr, kf) six MFMAs;
+// phase B (time tap 2, parts paired in K): two B fragments and three MFMAs per (fr, kf).  Small terms first.
+template <int NR, int SF, bool TR2>
+__device__ __forceinline__ void chunk_mfma6(f32x16 (&acc)[4], const bf16x8* sx, const bf16x8* sw, int wave, int half,
+                                            int l31) {
+  constexpr int XN = NR * X6_TW;
+  const int wa = half * 32 + l31;                          // + ((kf * 3 + p) * 2) * 32
+  const int xa = 32 * wave + l31 + half;                   // + p * XN + R * X6_TW     (kt = half)
+  bf16x8 A[3][3], B[2][3];
+#pragma unroll
+  for (int kf = 0; kf < 3; ++kf)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) A[kf][p] = sw[((kf * 3 + p) * 2) * 32 + wa];
+  // phase-B operands: A2[kf][0] = [w_h | w_h], [1] = [w_m | w_m], [2] = [w_h | w_l]; B2[0] = [x_h | x_m], [1] = [x_l | x_h]
+  const int w2 = X6_WPAIR + l31;                           // + (kf * 3 + p) * 32
+  const int p2 = half ? 2 : 0;
+  const int xb0 = (half ? XN : 0) + 32 * wave + l31 + 2;
+  const int xb1 = (half ? 0 : 2 * XN) + 32 * wave + l31 + 2;
+  bf16x8 A2[3][3], B2[2][2];
+  constexpr int NSTEP = 2 * NR;
+#pragma unroll
+  for (int st = -1; st < NSTEP; ++st) {
+    if (st + 1 < NR) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) B[(st + 1) & 1][p] = sx[p * XN + (st + 1) * X6_TW + xa];
+    } else if (st + 1 < NSTEP) {
+      const int R_ = st + 1 - NR;
+      B2[(st + 1) & 1][0] = sx[xb0 + R_ * X6_TW];
+      B2[(st + 1) & 1][1] = sx[xb1 + R_ * X6_TW];
+    }
+    if (st == NR - 2 || (NR == 1 && st == -1)) {
+      // the weight fragments of phase B, one step ahead of their first use
+#pragma unroll
+      for (int kf = 0; kf < 3; ++kf) {
+        A2[kf][0] = sw[w2 + (kf * 3 + 0) * 32];
+        A2[kf][1] = sw[w2 + (kf * 3 + 1) * 32];
+        A2[kf][2] = sw[w2 + (kf * 3 + p2) * 32];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);     // keep the next step's ds_reads AHEAD of this step's MFMAs
+    if (st >= 0 && st < NR) {
+      const int R = st, cur = st & 1;
+      // terms lh, hl, mm, mh, hm, hh; inside a term consecutive MFMAs hit different accumulators
+#pragma unroll
+      for (int term = 0; term < 6; ++term) {
+        const int ap = term == 0 ? 2 : ((term == 2 || term == 3) ? 1 : 0);
+        const int bp = term == 1 ? 2 : ((term == 2 || term == 4) ? 1 : 0);
+#pragma unroll
+        for (int fr = 0; fr < 4; ++fr)
+#pragma unroll
+          for (int kf = 0; kf < 3; ++kf)
+            if (use6<SF, TR2>(fr, kf, R))
+              acc[fr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[kf][ap], B[cur][bp], acc[fr], 0, 0, 0);
+      }
+    } else if (st >= NR) {
+      const int R = st - NR, cur = st & 1;
+#pragma unroll
+      for (int term = 0; term < 3; ++term) {               // hl + lh, mh + mm, hh + hm
+        const int aq = 2 - term;
+        const int bq = term == 0 ? 1 : 0;
+#pragma unroll
+        for (int fr = 0; fr < 4; ++fr)
+#pragma unroll
+          for (int kf = 0; kf < 3; ++kf)
+            if (use6<SF, TR2>(fr, kf, R))
+              acc[fr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2[kf][aq], B2[cur][bq], acc[fr], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ONE persistent workgroup per CU, 8 waves: waves 0-3 = consumers (MFMAs + tile epilogue), waves 4-7 = producers (LDS-DMA
+// of the next chunk, epilogue tables of the next tile, float64 statistics atomics of the previous tile).  Workgroup b
+// belongs to XCD b & 7 and walks that XCD's own samples (n % 8 == xcd) tile by tile, row tile fastest.  One workgroup
+// barrier per K-chunk g: producers arrive when the DMA of chunk g has landed, consumers when the MFMAs of chunk g - 1
+// are done; chunks are numbered across tiles, so the first chunk of the next tile is in flight during the epilogue.
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int nslots) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (the LDS-DMA builtin has no host form)
+  constexpr int COP = 32;
+  constexpr int SF = MODE == 1 ? 2 : 1;
+  constexpr bool TR2 = MODE == 2;
+  constexpr int NR = MODE == 0 ? 6 : (MODE == 1 ? 9 : 3);      // staged input rows of a 4-row tile
+  constexpr int XN = NR * X6_TW;                               // units per input part image
+  constexpr int SN = 3 * XN + X6_WU;                           // units per stage: [x_h | x_m | x_l | w]
+  constexpr int NXI = (XN + 255) / 256;
+  constexpr int NWI = (X6_WU + 255) / 256;
+  extern __shared__ __align__(16) unsigned char smem_b[];
+  bf16x8* s_stage = reinterpret_cast<bf16x8*>(smem_b);         // [2][SN]
+  float* s_tab = reinterpret_cast<float*>(s_stage + 2 * SN);   // [2 sets][bs | bl | br][FT][2][16]
+  float* s_red = s_tab + 2 * 3 * FT * COP;                     // [2 sets][4 waves][COP][2]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave >= 4;
+  const int rw = wave & 3;                                     // index inside the role
+  const int half = lane >> 5, l31 = lane & 31;
+  const int T = a.T, Tp = a.Tp, Fin = a.Fin, Cin = a.Cin;
+  const int nchunk = Cin >> 3;
+
+  const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+  const unsigned per = (unsigned)(a.ntx * a.nty * a.ncg);                    // tiles per sample
+  const unsigned nk = (unsigned)((a.nsamp + 7 - (int)xcd) / 8) * per;        // tiles of this XCD's samples
+  unsigned k = slot;
+  if (k >= nk) return;
+
+  int t0, f0, n, cg;
+#define TILE_COORDS(K)                                                                                          \
+  {                                                                                                             \
+    const unsigned grp_ = (K) / per;                                                                            \
+    unsigned tile_ = (K) - grp_ * per;                                                                          \
+    n = (int)(grp_ * 8u + xcd);                                                                                 \
+    f0 = (int)(tile_ % (unsigned)a.nty) * FT;                                                                   \
+    tile_ /= (unsigned)a.nty;                                                                                   \
+    cg = (int)(tile_ % (unsigned)a.ncg);                                                                        \
+    t0 = (int)(tile_ / (unsigned)a.ncg) * TT;                                                                   \
+  }
+
+  if (producer) {
+    // =============================================== producers ===============================================
+    const unsigned P16 = (unsigned)Fin * (unsigned)Tp * 16u;                 // bytes per octet plane
+    const unsigned in_rec = (unsigned)((a.in_c0 + Cin) >> 3) * P16;
+    const unsigned long long part_b = (unsigned long long)(a.in_sstride >> 3) * P16;   // bytes between the parts
+    const unsigned wbytes = (unsigned)nchunk * (unsigned)X6_WU * 16u;        // one (sample, group) weight image set
+    const unsigned wo = (unsigned)(tid & 255) * 16u;
+    __amdgpu_buffer_rsrc_t rs_x0, rs_x1, rs_x2, rs_w;
+    unsigned xo[NXI];
+
+#define TILE_SETUP()                                                                                            \
+  {                                                                                                             \
+    const int fin0_ = TR2 ? (f0 >> 1) - 1 : SF * f0 - a.padf;                                                   \
+    const unsigned long long in_b_ =                                                                            \
+        reinterpret_cast<unsigned long long>(a.in) + (unsigned long long)n * a.in_bstride * 4ull;               \
+    rs_x0 = make_rsrc_e(in_b_, in_rec);                                                                         \
+    rs_x1 = make_rsrc_e(in_b_ + part_b, in_rec);                                                                \
+    rs_x2 = make_rsrc_e(in_b_ + 2 * part_b, in_rec);                                                            \
+    rs_w = make_rsrc_e(reinterpret_cast<unsigned long long>(a.wps) + (unsigned long long)n * a.wps_nstride +    \
+                           (unsigned long long)cg * wbytes, wbytes);                                            \
+    _Pragma("unroll") for (int i = 0; i < NXI; ++i) {                                                           \
+      const int u = (i * 4 + rw) * 64 + lane;                                                                   \
+      const int r = u / X6_TW, j = u - r * X6_TW;                                                               \
+      const int fin = fin0_ + r;                                                                                \
+      const int t = t0 - 1 + j;                                                                                 \
+      const bool ok = u < XN && fin >= 0 && fin < Fin && t >= 0 && t < T;                                       \
+      xo[i] = ok ? ((unsigned)((a.in_c0 >> 3) * Fin + fin) * (unsigned)Tp + (unsigned)t) * 16u : 0x80000000u;   \
+    }                                                                                                           \
+  }
+
+    // chunk KC of the current tile -> stage SB (xo walks one octet plane per chunk)
+#define DMA_STAGE(KC, SB)                                                                                       \
+  {                                                                                                             \
+    bf16x8* st_ = s_stage + (SB) * SN;                                                                          \
+    _Pragma("unroll") for (int i = 0; i < NXI; ++i) {                                                           \
+      const int ub = (i * 4 + rw) * 64;                                                                         \
+      if (ub < XN) {                                                                                            \
+        if (ub + 64 <= XN || ub + lane < XN) {                                                                  \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x0, MN_LDS(st_ + ub), 16, xo[i], 0, 0, 0);                \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x1, MN_LDS(st_ + XN + ub), 16, xo[i], 0, 0, 0);           \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x2, MN_LDS(st_ + 2 * XN + ub), 16, xo[i], 0, 0, 0);       \
+        }                                                                                                       \
+      }                                                                                                         \
+      if (xo[i] != 0x80000000u) xo[i] += P16;                                                                   \
+    }                                                                                                           \
+    const unsigned wsoff_ = (unsigned)(KC) * (unsigned)X6_WU * 16u;                                             \
+    _Pragma("unroll") for (int i = 0; i < NWI; ++i) {                                                           \
+      const int ub = (i * 4 + rw) * 64;                                                                         \
+      if (ub < X6_WU) {                                                                                         \
+        if (ub + 64 <= X6_WU || ub + lane < X6_WU)                                                              \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, MN_LDS(st_ + 3 * XN + ub), 16, wo + (unsigned)i * 4096u, \
+                                                   wsoff_, 0, 0);                                               \
+      }                                                                                                         \
+    }                                                                                                           \
+  }
+
+    // epilogue tables of the current tile, set TS: producer wave rw builds output row f0 + rw, lane = output channel
+#define TILE_TABLES(TS)                                                                                         \
+  {                                                                                                             \
+    if (lane < COP) {                                                                                           \
+      const int f_ = f0 + rw;                                                                                   \
+      float b3[3] = {0.f, 0.f, 0.f};                                                                            \
+      if (a.btab) {                                                                                             \
+        const float* bt_ = a.btab + (long long)n * a.btab_nstride + (long long)(cg * COP + lane) * 9;           \
+        _Pragma("unroll") for (int kf = 0; kf < 3; ++kf) {                                                      \
+          bool ok_;                                                                                             \
+          if (TR2) {                                                                                            \
+            const int q_ = f_ + kf - 2;                                                                         \
+            ok_ = (q_ >= 0) && !(q_ & 1) && (q_ >> 1) < Fin;                                                    \
+          } else {                                                                                              \
+            const int fi_ = SF * f_ + kf - a.padf;                                                              \
+            ok_ = fi_ >= 0 && fi_ < Fin;                                                                        \
+          }                                                                                                     \
+          _Pragma("unroll") for (int kt = 0; kt < 3; ++kt) {                                                    \
+            const float v_ = bt_[kt * 3 + kf];                                                                  \
+            b3[kt] += ok_ ? v_ : 0.f;                                                                           \
+          }                                                                                                     \
+        }                                                                                                       \
+      }                                                                                                         \
+      b3[1] += a.bias[cg * COP + lane];                                                                         \
+      /* accumulator order: channel co = (i&3) + 8*(i>>2) + 4*h  ->  h = (co>>2)&1, i = (co&3) + 4*(co>>3) */    \
+      const int slot_ = (rw * 2 + ((lane >> 2) & 1)) * 16 + (lane & 3) + 4 * (lane >> 3);                       \
+      float* tb_ = s_tab + (TS) * (3 * FT * COP);                                                               \
+      tb_[slot_] = b3[0] + b3[1] + b3[2];                                                                       \
+      tb_[FT * COP + slot_] = b3[0];                                                                            \
+      tb_[2 * FT * COP + slot_] = b3[2];                                                                        \
+    }                                                                                                           \
+  }
+
+    // float64 statistics of a finished tile (producer wave 0): sum of the four consumer partials per channel
+#define TILE_STATS(PN, PCG, RS)                                                                                 \
+  {                                                                                                             \
+    if (a.act && rw == 0) {                                                                                     \
+      const float* sr_ = s_red + (RS) * (4 * COP * 2);                                                          \
+      const int co_l = lane >> 1, which = lane & 1;                                                             \
+      const int co = (PCG) * COP + co_l;                                                                        \
+      if (co < a.Cout) {                                                                                        \
+        float tot = 0.f;                                                                                        \
+        for (int w = 0; w < 4; ++w) tot += sr_[(w * COP + co_l) * 2 + which];                                   \
+        unsafeAtomicAdd(a.out_stats + ((long long)(PN) * a.out_sstride + a.out_c0 + co) * 2 + which, (double)tot); \
+      }                                                                                                         \
+    }                                                                                                           \
+  }
+
+    TILE_COORDS(k)
+    TILE_SETUP()
+    DMA_STAGE(0, 0)
+    TILE_TABLES(0)
+    unsigned g = 0, ti = 0;
+    int p1_n = 0, p1_cg = 0;                                   // the previous tile, whose statistics are still to be flushed
+    for (;;) {
+      bool more = false;
+      const int c_n = n, c_cg = cg;
+      for (int kc = 0; kc < nchunk; ++kc, ++g) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // chunk g has landed (hipcc does not count LDS-DMA loads)
+        __syncthreads();                                       // barrier g
+        if (kc == 0 && ti >= 1) TILE_STATS(p1_n, p1_cg, (ti + 1) & 1)
+        if (kc + 1 < nchunk) {
+          DMA_STAGE(kc + 1, (g + 1) & 1)
+        } else {
+          k += (unsigned)nslots;
+          more = k < nk;
+          if (more) {
+            TILE_COORDS(k)
+            TILE_SETUP()
+            DMA_STAGE(0, (g + 1) & 1)
+            TILE_TABLES((ti + 1) & 1)
+          }
+        }
+      }
+      p1_n = c_n; p1_cg = c_cg;
+      ++ti;
+      if (!more) break;
+    }
+    __syncthreads();                                           // final barrier: the last epilogue is done
+    TILE_STATS(p1_n, p1_cg, (ti + 1) & 1)
+#undef TILE_SETUP
+#undef DMA_STAGE
+#undef TILE_TABLES
+#undef TILE_STATS
+  } else {
+    // =============================================== consumers ===============================================
+    TILE_COORDS(k)
+    unsigned g = 0, ti = 0;
+    for (;;) {
+      f32x16 acc[4];
+      const bool wave_live = (t0 + 32 * wave < T);             // this consumer's frames exist (ragged last tile)
+      for (int kc = 0; kc < nchunk; ++kc, ++g) {
+        __syncthreads();                                       // barrier g: stage g & 1 holds chunk g
+        if (kc == 0) {                                         // accumulators start at bias + folded shift (tables of this
+          const float* tb = s_tab + (ti & 1) * (3 * FT * COP); // tile: written by the producers before barrier g)
+          conv_acc_init_rows(acc, t0 + 32 * wave, T, lane, tb, tb + FT * COP, tb + 2 * FT * COP);
+        }
+        if (wave_live && !(a.dbg & 1)) {
+          const bf16x8* st = s_stage + (g & 1) * SN;
+          __builtin_amdgcn_s_setprio(1);
+          chunk_mfma6<NR, SF, TR2>(acc, st, st + 3 * XN, wave, half, l31);
+          __builtin_amdgcn_s_setprio(0);
+        }
+      }
+      if (!(a.dbg & 4))
+        conv_epilogue_rows_nb<3>(a, acc, n, cg, f0, t0 + 32 * wave, lane, s_red + (ti & 1) * (4 * COP * 2) + wave * (COP * 2), 4);
+      ++ti;
+      k += (unsigned)nslots;
+      if (k >= nk) break;
+      TILE_COORDS(k)
+    }
+    __syncthreads();                                           // final barrier
+  }
+#undef TILE_COORDS
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// conv_wprep6_k: fold the instance norm of a layer's input into per-sample weights, split exactly into three bf16 parts.
+//   wf   : [ncg][nchunk][9 taps][32 co][8 ci] float32 (zero padded), shared by all samples; tap = kt * 3 + kf
+//   wps  : [n][ncg][nchunk][X6_WU] 16-byte units: unit ((kf*3 + p)*2 + kt)*32 + co for kt < 2, X6_WPAIR + (kf*3 + p)*32 + co
+//          for kt = 2, each = the 8 channels of the chunk of part p of  wf * rstd[n][ci]
+//   btab : [n][ncg*32][9] float32 = sum_ci wf[..ci..] * (-mean * rstd)[n][ci]   (float64 accumulation, fixed order)
+// One workgroup of 288 threads per (sample, group); thread = (tap, output channel).
+__global__ __launch_bounds__(288) void conv_wprep6_k(const float* wf, const double* in_stats, int in_sstride, int in_c0,
+                                                     int Cin, int ident_c, int Fin, int T, int nchunk, int ncg,
+                                                     u32x4_t* wps, long long wps_nstride_b, float* btab,
+                                                     long long btab_nstride) {
+  extern __shared__ float2 s_nrm[];                  // [nchunk*8] (scale, shift)
+  const int n = blockIdx.x / ncg, cg = blockIdx.x - n * ncg;
+  const int tid = threadIdx.x;
+  for (int c = tid; c < nchunk * 8; c += 288) {
+    float mean = 0.f, rstd = (c < Cin) ? 1.f : 0.f;
+    if (c >= ident_c && c < Cin) {
+      const double* st = in_stats + ((long long)n * in_sstride + in_c0 + c) * 2;
+      const double cnt = (double)Fin * (double)T;
+      const double m = st[0] / cnt;
+      double var = st[1] / cnt - m * m;
+      var = var > 0.0 ? var : 0.0;
+      mean = (float)m;
+      rstd = (float)(1.0 / sqrt(var + (double)IN_EPS));
+    }
+    s_nrm[c] = make_float2(rstd, -mean * rstd);
+  }
+  __syncthreads();
+  const int tap = tid >> 5, co = tid & 31;
+  const int kt = tap / 3, kf = tap - 3 * kt;
+  const float* wsrc = wf + ((long long)cg * nchunk * 9 + tap) * (32 * 8) + co * 8;
+  u32x4_t* wdst = reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(wps) + (long long)n * wps_nstride_b) +
+                  (long long)cg * nchunk * X6_WU;
+  const int ubase = kt < 2 ? (kf * 3 * 2 + kt) * 32 + co : X6_WPAIR + (kf * 3) * 32 + co;
+  const int ustep = kt < 2 ? 2 * 32 : 32;            // units between the parts
+  double bsum = 0.0;
+  constexpr int U = 4;                               // chunks per batch: the loads of a batch are issued together
+  for (int kc0 = 0; kc0 < nchunk; kc0 += U) {
+    float4 wl[U][2];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int kc = (kc0 + u < nchunk) ? kc0 + u : nchunk - 1;
+      const float4* src = reinterpret_cast<const float4*>(wsrc + (long long)kc * (9 * 32 * 8));
+      wl[u][0] = src[0];
+      wl[u][1] = src[1];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int kc = kc0 + u;
+      if (kc < nchunk) {
+        const float4 w0 = wl[u][0], w1 = wl[u][1];
+        const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        float ws[8];
+        float bs = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float2 m = s_nrm[kc * 8 + e];
+          ws[e] = wv[e] * m.x;
+          bs = fmaf(wv[e], m.y, bs);
+        }
+        bsum += (double)bs;
+        u32x4_t ph, pm, pl;
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+          unsigned a_, b_, c_;
+          split3_pair_t(ws[2 * e2], ws[2 * e2 + 1], a_, b_, c_);
+          ph[e2] = a_; pm[e2] = b_; pl[e2] = c_;
+        }
+        u32x4_t* d = wdst + (long long)kc * X6_WU + ubase;
+        d[0] = ph;
+        d[ustep] = pm;
+        d[2 * ustep] = pl;
+      }
+    }
+  }
+  btab[(long long)n * btab_nstride + (long long)(cg * 32 + co) * 9 + tap] = (float)bsum;
+}
+
+static size_t x6_lds_bytes(int NR) {
+  return (size_t)(2 * (3 * NR * X6_TW + X6_WU)) * 16 + (size_t)(2 * 3 * FT * 32 + 2 * 4 * 32 * 2) * sizeof(float);
+}
+
+hipError_t conv_bf16x6_init() {
+  hipError_t e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6<0>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6<1>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6<2>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+long long conv_bf16x6_wps_bytes(int Cin, int Cout) {
+  return (long long)((Cout + 31) / 32) * (Cin / 8) * X6_WU * 16;
+}
+
+hipError_t launch_conv_wprep6(const ConvArgs& a, const float* wf, int n_samples, hipStream_t s) {
+  const int nchunk = a.Cin >> 3;
+  hipLaunchKernelGGL(conv_wprep6_k, dim3(n_samples * a.ncg), dim3(288), (size_t)nchunk * 8 * sizeof(float2), s, wf,
+                     a.in_stats, a.in_sstride, a.in_c0, a.Cin, a.ident_c, a.Fin, a.T, nchunk, a.ncg,
+                     reinterpret_cast<u32x4_t*>(const_cast<void*>(a.wps)), a.wps_nstride, const_cast<float*>(a.btab),
+                     a.btab_nstride);
+  return hipGetLastError();
+}
+
+hipError_t launch_conv_bf16x6(const ConvArgs& a_in, int n_samples, hipStream_t s) {
+  ConvArgs a = a_in;
+  if (a.in_oct != 3 || !a.wps || a.cop != 32 || (a.Cin & 7) || (a.in_c0 & 7) || (a.in_sstride & 7)) return hipErrorInvalidValue;
+  if (a.out_oct && (a.out_oct != 3 || (a.Cout & 7) || (a.out_c0 & 7) || (a.out_sstride & 7))) return hipErrorInvalidValue;
+  {
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("MISONET_WS_DEBUG"); dbg = e ? atoi(e) : 0; }
+    a.dbg = dbg;
+  }
+  a.dbg_buf = nullptr;
+  (void)conv_grid(a, n_samples, TT, FT, 1);                       // tile geometry: 4 rows x 128 frames
+  static int g_cus = 0;
+  if (!g_cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+    g_cus = prop.multiProcessorCount;
+  }
+  // persistent launch: one workgroup per CU, capped by the largest per-XCD tile list
+  const long long nk_max = (long long)((n_samples + 7) / 8) * a.ntx * a.nty * a.ncg;
+  int nslots = g_cus / 8;
+  if (nslots < 1) nslots = 1;
+  if (nslots > nk_max) nslots = (int)nk_max;
+  const dim3 pgrid((unsigned)(8 * nslots), 1, 1);
+  const int mode = a.tr2 ? 2 : (a.sf == 2 ? 1 : 0);
+  if (mode == 0) hipLaunchKernelGGL((conv3x3_bf16x6<0>), pgrid, dim3(512), x6_lds_bytes(6), s, a, nslots);
+  else if (mode == 1) hipLaunchKernelGGL((conv3x3_bf16x6<1>), pgrid, dim3(512), x6_lds_bytes(9), s, a, nslots);
+  else hipLaunchKernelGGL((conv3x3_bf16x6<2>), pgrid, dim3(512), x6_lds_bytes(3), s, a, nslots);
+  return hipGetLastError();
+}
+
+}  // namespace mn

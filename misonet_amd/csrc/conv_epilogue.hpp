@@ -103,13 +103,81 @@ __device__ __forceinline__ void split_pair_t(float x0, float x1, unsigned& hi, u
   lo = __builtin_bit_cast(unsigned, l);
 }
 
+// two values -> three packed bf16 pairs with x = hi + mid + lo EXACTLY (bf16x6 mode): hi = rne(x), mid = rne(x - hi),
+// lo = x - hi - mid.  x - hi is exact in float32 and has at most 16 significant bits, x - hi - mid at most 8, so the
+// last conversion does not round (float32 has 24 significant bits = 3 x 8); bf16 has the exponent range of float32.
+__device__ __forceinline__ void split3_pair_t(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+  f32x2_t x = {x0, x1};
+  const bf16x2_t h = __builtin_convertvector(x, bf16x2_t);
+  const unsigned hu = __builtin_bit_cast(unsigned, h);
+  f32x2_t r;
+  r.x = x0 - __builtin_bit_cast(float, hu << 16);
+  r.y = x1 - __builtin_bit_cast(float, hu & 0xffff0000u);
+  const bf16x2_t m = __builtin_convertvector(r, bf16x2_t);
+  const unsigned mu = __builtin_bit_cast(unsigned, m);
+  f32x2_t q;
+  q.x = r.x - __builtin_bit_cast(float, mu << 16);
+  q.y = r.y - __builtin_bit_cast(float, mu & 0xffff0000u);
+  const bf16x2_t l = __builtin_convertvector(q, bf16x2_t);
+  hi = hu;
+  mid = mu;
+  lo = __builtin_bit_cast(unsigned, l);
+}
+
+// One accumulator row (16 values of one lane: channel (i&3) + 8*(i>>2) + 4*half of a 32-channel group at one frame)
+// -> NP bf16 parts in the oct layout: part p of octet pair k is one 16-byte store per lane (lanes 0-31 store octet 2k,
+// lanes 32-63 octet 2k + 1, after a half-wave swap).  rs[p]: descriptor of part p; vo: byte offset of (row, frame) in
+// the plane of octet (group base + half); ok0 / ok1: this lane's octet of pair 0 / 1 exists and its frame is valid.
+template <int NP>
+__device__ __forceinline__ void store_oct_row(const float (&v)[16], const __amdgpu_buffer_rsrc_t (&rs)[3], unsigned vo,
+                                              unsigned P16, bool ok0, bool ok1) {
+  unsigned P[3][4][2];
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    if (NP == 3) {
+      split3_pair_t(v[4 * o + 0], v[4 * o + 1], P[0][o][0], P[1][o][0], P[2][o][0]);
+      split3_pair_t(v[4 * o + 2], v[4 * o + 3], P[0][o][1], P[1][o][1], P[2][o][1]);
+    } else {
+      split_pair_t(v[4 * o + 0], v[4 * o + 1], P[0][o][0], P[1][o][0]);
+      split_pair_t(v[4 * o + 2], v[4 * o + 3], P[0][o][1], P[1][o][1]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        auto rr = __builtin_amdgcn_permlane32_swap(P[p][2 * k][d], P[p][2 * k + 1][d], false, false);
+        P[p][2 * k][d] = rr[0]; P[p][2 * k + 1][d] = rr[1];
+      }
+    }
+    if (k == 0 ? ok0 : ok1) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const u32x4_t u = {P[p][2 * k][0], P[p][2 * k][1], P[p][2 * k + 1][0], P[p][2 * k + 1][1]};
+        __builtin_amdgcn_raw_buffer_store_b128(u, rs[p], vo + (unsigned)(2 * k) * P16, 0, 0);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_e(unsigned long long pa, unsigned bytes) {
+  // NB: readfirstlane returns int -- unsigned temporaries, an int OR-ed into the 64-bit pointer would be sign-extended
+  const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pa);
+  const unsigned phi = __builtin_amdgcn_readfirstlane((unsigned)(pa >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)phi << 32) | plo), 0,
+                                           __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+}
+
 // s_red: [COP][2] floats of THIS wave's row (the caller adds the rows of a tile).  COP = NCO * 32.
 // s_bias: optional LDS copy of this group's bias [COP].
 // s_b4:   optional LDS table [COP][4] = (bL, bC, bR, bL + bC + bR) of THIS wave's row: the bias plus the folded
 //         instance-norm shift of the DMA dataflow, split by time tap so that the first / last frame of the utterance
 //         (whose left / right taps fall into the zero padding) can drop their share.
-// OCT:    compile the oct-layout output path (a.out_oct selects it at run time).
-template <int NCO, int NSEG, bool OCT, bool ACT>
+// OCTP:   0, or the number of bf16 parts of the oct-layout output path to compile: 2 (bf16x3: hi | lo) or 3 (bf16x6:
+//         hi | mid | lo); a.out_oct selects it at run time.
+template <int NCO, int NSEG, int OCTP, bool ACT>
 __device__ __forceinline__ void conv_epilogue_impl(const ConvArgs& a, f32x16_t (&acc)[NCO][NSEG], int n, int cg, int f,
                                                    int t0, bool row_ok, int lane, float* s_red,
                                                    const float* s_bias, const float* s_b4) {
@@ -126,22 +194,18 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvArgs& a, f32x16_t (
   const bool unmasked = all_t && full_c;
   const bool t_edge = s_b4 && (t0 == 0 || t0 + NSEG * 32 >= T);             // uniform: tile holds frame 0 or T - 1
 
-  if (OCT && a.out_oct) {
-    // ---- oct layout: per (octet, frame) one 16-byte unit in the hi half and one in the lo half ----
+  if (OCTP && a.out_oct) {
+    // ---- oct layout: per (octet, frame) one 16-byte unit in each of the OCTP parts ----
+    constexpr int NP = OCTP ? OCTP : 2;
     const unsigned P16 = (unsigned)a.Fout * (unsigned)Tp * 16u;             // bytes per octet plane
-    const char* ob = reinterpret_cast<const char*>(a.out) + (long long)n * a.out_bstride * 4 +
-                     (long long)(a.out_c0 >> 3) * P16;
-    const unsigned long long pa = reinterpret_cast<unsigned long long>(ob);
-    const unsigned long long pb = pa + (unsigned long long)(a.out_sstride >> 3) * P16;
-    const int nrec = __builtin_amdgcn_readfirstlane((int)((unsigned)(a.Cout >> 3) * P16));
-    // NB: readfirstlane returns int -- go through unsigned temporaries, an int OR-ed into the 64-bit pointer would be
-    // sign-extended and corrupt the high half whenever bit 31 of the low half is set
-    const unsigned pa_lo = __builtin_amdgcn_readfirstlane((unsigned)pa), pa_hi = __builtin_amdgcn_readfirstlane((unsigned)(pa >> 32));
-    const unsigned pb_lo = __builtin_amdgcn_readfirstlane((unsigned)pb), pb_hi = __builtin_amdgcn_readfirstlane((unsigned)(pb >> 32));
-    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<void*>(((unsigned long long)pa_hi << 32) | pa_lo), 0, nrec, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<void*>(((unsigned long long)pb_hi << 32) | pb_lo), 0, nrec, 0x00020000);
+    const unsigned long long pa = reinterpret_cast<unsigned long long>(a.out) + (unsigned long long)n * a.out_bstride * 4ull +
+                                  (unsigned long long)(a.out_c0 >> 3) * P16;
+    const unsigned long long part_b = (unsigned long long)(a.out_sstride >> 3) * P16;
+    const unsigned nrec = (unsigned)(a.Cout >> 3) * P16;
+    __amdgpu_buffer_rsrc_t rs[3];
+    rs[0] = make_rsrc_e(pa, nrec);
+    rs[1] = make_rsrc_e(pa + part_b, nrec);
+    rs[2] = NP == 3 ? make_rsrc_e(pa + 2 * part_b, nrec) : rs[1];
     unsigned voff[NSEG];
 #pragma unroll
     for (int s = 0; s < NSEG; ++s)
@@ -178,31 +242,10 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvArgs& a, f32x16_t (
           s1[r] += vm;
           s2[r] = fmaf(vm, vm, s2[r]);
         }
-        unsigned H[4][2], L[4][2];
-#pragma unroll
-        for (int o = 0; o < 4; ++o) {
-          split_pair_t(v[4 * o + 0], v[4 * o + 1], H[o][0], L[o][0]);
-          split_pair_t(v[4 * o + 2], v[4 * o + 3], H[o][1], L[o][1]);
-        }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {                 // octet pair (2k, 2k+1): lanes 0-31 store 2k, lanes 32-63 store 2k+1
-#pragma unroll
-          for (int d = 0; d < 2; ++d) {
-            auto rh = __builtin_amdgcn_permlane32_swap(H[2 * k][d], H[2 * k + 1][d], false, false);
-            H[2 * k][d] = rh[0]; H[2 * k + 1][d] = rh[1];
-            auto rl = __builtin_amdgcn_permlane32_swap(L[2 * k][d], L[2 * k + 1][d], false, false);
-            L[2 * k][d] = rl[0]; L[2 * k + 1][d] = rl[1];
-          }
-          const u32x4_t uh = {H[2 * k][0], H[2 * k][1], H[2 * k + 1][0], H[2 * k + 1][1]};
-          const u32x4_t ul = {L[2 * k][0], L[2 * k][1], L[2 * k + 1][0], L[2 * k + 1][1]};
-          // this lane's octet (2k + half of group j) exists and its frame is inside the utterance
-          const bool ook = tm[s] && (cbase + j * 32 + (2 * k + half) * 8 < a.Cout);
-          const unsigned off = voff[s] + (unsigned)((cbase >> 3) + j * 4 + 2 * k) * P16;
-          if (!(a.dbg & 8) && (unmasked || ook)) {
-            __builtin_amdgcn_raw_buffer_store_b128(uh, rs_h, off, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(ul, rs_l, off, 0, 0);
-          }
-        }
+        // this lane's octet (2k + half of group j) exists and its frame is inside the utterance
+        const bool ok0 = !(a.dbg & 8) && (unmasked || (tm[s] && (cbase + j * 32 + (0 + half) * 8 < a.Cout)));
+        const bool ok1 = !(a.dbg & 8) && (unmasked || (tm[s] && (cbase + j * 32 + (2 + half) * 8 < a.Cout)));
+        store_oct_row<NP>(v, rs, voff[s] + (unsigned)((cbase >> 3) + j * 4) * P16, P16, ok0, ok1);
       }
       if (ACT && !(a.dbg & 16)) {
         const float x1 = reduce16_halfwave(s1, lane);
@@ -297,12 +340,12 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvArgs& a, f32x16_t (
 
 // ACT (ELU + statistics) is a compile-time parameter of the implementation: a run-time test inside the unrolled element
 // loops turns into a branch per element and serialises the exp latency.
-template <int NCO, int NSEG = 4, bool OCT = false>
+template <int NCO, int NSEG = 4, int OCTP = 0>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16_t (&acc)[NCO][NSEG], int n, int cg, int f,
                                               int t0, bool row_ok, int lane, float* s_red,
                                               const float* s_bias = nullptr, const float* s_b4 = nullptr) {
-  if (a.act) conv_epilogue_impl<NCO, NSEG, OCT, true>(a, acc, n, cg, f, t0, row_ok, lane, s_red, s_bias, s_b4);
-  else conv_epilogue_impl<NCO, NSEG, OCT, false>(a, acc, n, cg, f, t0, row_ok, lane, s_red, s_bias, s_b4);
+  if (a.act) conv_epilogue_impl<NCO, NSEG, OCTP, true>(a, acc, n, cg, f, t0, row_ok, lane, s_red, s_bias, s_b4);
+  else conv_epilogue_impl<NCO, NSEG, OCTP, false>(a, acc, n, cg, f, t0, row_ok, lane, s_red, s_bias, s_b4);
 }
 
 // Tile epilogue of the row-reuse mapping (conv_bf16_dma.hip): one wave owns 32 frames [tw, tw + 32) of FOUR output rows
@@ -494,11 +537,10 @@ __device__ __forceinline__ void conv_acc_init_rows(f32x16_t (&acc)[4], int tw, i
   }
 }
 
-template <bool MASKED, bool ACT>
+template <bool MASKED, bool ACT, int NP>
 __device__ __forceinline__ void conv_epilogue_rows_nb_impl(const ConvArgs& a, f32x16_t (&acc)[4], int cg, int f0, int tw,
-                                                           int lane, const __amdgpu_buffer_rsrc_t rs_h,
-                                                           const __amdgpu_buffer_rsrc_t rs_l, f32x2_e (&s1)[8],
-                                                           f32x2_e (&s2)[8], int rows) {
+                                                           int lane, const __amdgpu_buffer_rsrc_t (&rs)[3],
+                                                           f32x2_e (&s1)[8], f32x2_e (&s2)[8], int rows) {
   constexpr int COP = 32;
   const int half = lane >> 5, l31 = lane & 31;
   const int T = a.T, Tp = a.Tp;
@@ -537,41 +579,21 @@ __device__ __forceinline__ void conv_epilogue_rows_nb_impl(const ConvArgs& a, f3
     }
     if (a.dbg & 8) continue;
     if (a.out_oct) {
-      unsigned H[4][2], L[4][2];
-#pragma unroll
-      for (int o = 0; o < 4; ++o) {
-        split_pair_t(v[4 * o + 0], v[4 * o + 1], H[o][0], L[o][0]);
-        split_pair_t(v[4 * o + 2], v[4 * o + 3], H[o][1], L[o][1]);
-      }
       const unsigned vo = (unsigned)(f * Tp + t) * 16u + (unsigned)half * P16 + (unsigned)(cbase >> 3) * P16;
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-          auto rh = __builtin_amdgcn_permlane32_swap(H[2 * k][d], H[2 * k + 1][d], false, false);
-          H[2 * k][d] = rh[0]; H[2 * k + 1][d] = rh[1];
-          auto rl = __builtin_amdgcn_permlane32_swap(L[2 * k][d], L[2 * k + 1][d], false, false);
-          L[2 * k][d] = rl[0]; L[2 * k + 1][d] = rl[1];
-        }
-        const u32x4_t uh = {H[2 * k][0], H[2 * k][1], H[2 * k + 1][0], H[2 * k + 1][1]};
-        const u32x4_t ul = {L[2 * k][0], L[2 * k][1], L[2 * k + 1][0], L[2 * k + 1][1]};
-        if (ok && (k == 0 ? oct_ok0 : oct_ok1)) {
-          __builtin_amdgcn_raw_buffer_store_b128(uh, rs_h, vo + (unsigned)(2 * k) * P16, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(ul, rs_l, vo + (unsigned)(2 * k) * P16, 0, 0);
-        }
-      }
+      store_oct_row<NP>(v, rs, vo, P16, ok && oct_ok0, ok && oct_ok1);
     } else {
       const unsigned vo = ok ? ((unsigned)(f * Tp + t) * 4u + (unsigned)(4 * half) * P4) : 0x80000000u;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int kr = (i & 3) + 8 * (i >> 2);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[i]), rs_h, vo + (unsigned)(cbase + kr) * P4, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[i]), rs[0], vo + (unsigned)(cbase + kr) * P4, 0, 0);
       }
     }
   }
 }
 
-// rows: output rows of the tile (4, or 2 for the stride-2 layers)
+// rows: output rows of the tile (4, or 2 for the stride-2 layers of the bf16x3 kernel); NP: bf16 parts of an oct output
+template <int NP = 2>
 __device__ __forceinline__ void conv_epilogue_rows_nb(const ConvArgs& a, f32x16_t (&acc)[4], int n, int cg, int f0, int tw,
                                                       int lane, float* s_red, int rows = 4) {
   const int half = lane >> 5;
@@ -582,31 +604,27 @@ __device__ __forceinline__ void conv_epilogue_rows_nb(const ConvArgs& a, f32x16_
   for (int i = 0; i < 8; ++i) { s1[i] = f32x2_e{0.f, 0.f}; s2[i] = f32x2_e{0.f, 0.f}; }
   const unsigned P16 = (unsigned)a.Fout * (unsigned)Tp * 16u;
   const unsigned P4 = (unsigned)a.Fout * (unsigned)Tp * 4u;
-  unsigned long long pa, pb;
-  unsigned nrec;
+  __amdgpu_buffer_rsrc_t rs[3];
   if (a.out_oct) {
-    pa = reinterpret_cast<unsigned long long>(a.out) + (unsigned long long)n * a.out_bstride * 4ull +
-         (unsigned long long)(a.out_c0 >> 3) * P16;
-    pb = pa + (unsigned long long)(a.out_sstride >> 3) * P16;
-    nrec = (unsigned)(a.Cout >> 3) * P16;
+    const unsigned long long pa = reinterpret_cast<unsigned long long>(a.out) + (unsigned long long)n * a.out_bstride * 4ull +
+                                  (unsigned long long)(a.out_c0 >> 3) * P16;
+    const unsigned long long part_b = (unsigned long long)(a.out_sstride >> 3) * P16;
+    const unsigned nrec = (unsigned)(a.Cout >> 3) * P16;
+    rs[0] = make_rsrc_e(pa, nrec);
+    rs[1] = make_rsrc_e(pa + part_b, nrec);
+    rs[2] = NP == 3 ? make_rsrc_e(pa + 2 * part_b, nrec) : rs[1];
   } else {
-    pa = reinterpret_cast<unsigned long long>(a.out + (long long)n * a.out_bstride + (long long)a.out_c0 * a.Fout * Tp);
-    pb = pa;
-    nrec = (unsigned)a.Cout * P4;
+    rs[0] = make_rsrc_e(reinterpret_cast<unsigned long long>(a.out + (long long)n * a.out_bstride + (long long)a.out_c0 * a.Fout * Tp),
+                        (unsigned)a.Cout * P4);
+    rs[1] = rs[0];
+    rs[2] = rs[0];
   }
-  const unsigned pa_lo = __builtin_amdgcn_readfirstlane((unsigned)pa), pa_hi = __builtin_amdgcn_readfirstlane((unsigned)(pa >> 32));
-  const unsigned pb_lo = __builtin_amdgcn_readfirstlane((unsigned)pb), pb_hi = __builtin_amdgcn_readfirstlane((unsigned)(pb >> 32));
-  const int nrec_s = __builtin_amdgcn_readfirstlane((int)nrec);
-  const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(
-      reinterpret_cast<void*>(((unsigned long long)pa_hi << 32) | pa_lo), 0, nrec_s, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc(
-      reinterpret_cast<void*>(((unsigned long long)pb_hi << 32) | pb_lo), 0, nrec_s, 0x00020000);
 
   if (a.act) {
-    if (fast) conv_epilogue_rows_nb_impl<false, true>(a, acc, cg, f0, tw, lane, rs_h, rs_l, s1, s2, rows);
-    else conv_epilogue_rows_nb_impl<true, true>(a, acc, cg, f0, tw, lane, rs_h, rs_l, s1, s2, rows);
+    if (fast) conv_epilogue_rows_nb_impl<false, true, NP>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows);
+    else conv_epilogue_rows_nb_impl<true, true, NP>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows);
   } else {
-    conv_epilogue_rows_nb_impl<true, false>(a, acc, cg, f0, tw, lane, rs_h, rs_l, s1, s2, rows);
+    conv_epilogue_rows_nb_impl<true, false, NP>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows);
   }
 
   if (a.act && !(a.dbg & 16)) {

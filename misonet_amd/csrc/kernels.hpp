@@ -46,7 +46,8 @@ struct ConvArgs {
   int cop;                  // 32 or 64 output channels per group
   // "oct" activation layout of the bf16x3 DMA dataflow (conv_bf16_dma.hip): per sample [hi | lo] halves, each
   // [c/8][f][Tp][8] bf16 (8 channels of one frame = one 16-byte unit), values RAW (bias + ELU, no instance norm).
-  int in_oct, out_oct;      // layout of the input / output buffer: 0 planar float32, 1 oct
+  int in_oct, out_oct;      // layout of the input / output buffer: 0 planar float32, 1 oct (bf16x3: hi | lo halves),
+                            // 3 oct3 (bf16x6, conv_bf16x6.hip: hi | mid | lo parts, 6 bytes per element)
   const void* wps;          // per-sample weights with the instance norm of the input folded in (conv_wprep), LDS image order
   long long wps_nstride;    // bytes between samples (0: one image shared by all samples)
   const float* btab;        // [n][ncg*32][9] border-aware shift table: sum_ci W[co][ci][tap] * shift[ci], or nullptr
@@ -100,6 +101,11 @@ hipError_t conv_bf16_init();
 hipError_t launch_conv_bf16_dma(const ConvArgs& a, int n_samples, hipStream_t s);   // conv_bf16_dma.hip (oct input)
 hipError_t launch_conv_wprep(const ConvArgs& a, const float* wf, int n_samples, hipStream_t s);
 hipError_t conv_bf16_dma_init();
+// bf16x6 (fp32-faithful) DMA dataflow, conv_bf16x6.hip: oct3 input, oct3 or planar output
+hipError_t launch_conv_bf16x6(const ConvArgs& a, int n_samples, hipStream_t s);
+hipError_t launch_conv_wprep6(const ConvArgs& a, const float* wf6, int n_samples, hipStream_t s);
+hipError_t conv_bf16x6_init();
+long long conv_bf16x6_wps_bytes(int Cin, int Cout);   // per-sample folded-weight bytes of one layer
 
 // ---- TCN (reference model.py:486-632) -----------------------------------------------------------------------------
 // x0 = IN2d(raw) materialised as the residual stream + its per-(n,c) statistics
@@ -125,7 +131,8 @@ hipError_t launch_unpack(const float* src, long long src_bstride, int Tp, int S,
 // planar view (+ optional instance norm) -> float32 [n][C][T][F]  (diagnostic taps)
 hipError_t launch_export(const float* src, long long src_bstride, int c0, int C, int Fq, int T, int Tp,
                          const double* stats, int sstride, int ident_c, float* dst, int n_samples, hipStream_t s,
-                         int oct = 0);   // oct: source in the oct layout (sstride = channels of the whole buffer)
+                         int oct = 0);   // oct: bf16 parts of a source in the oct layout (0 planar, 2, 3; sstride = channels
+                                         // of the whole buffer)
 
 // ---- MVDR + PIT -------------------------------------------------------------------------------------------------
 // Accessor for a multichannel complex STFT with frames contiguous: element (b, f, m, t) =

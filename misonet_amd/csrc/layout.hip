@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void unpack_k(const float* src, int Cbuf, int 
   if (nan_flag && bad) atomicOr(nan_flag, 1);
 }
 
-// oct != 0: the source buffer is in the oct layout of the bf16x3 DMA dataflow (kernels.hpp), value = hi + lo
+// oct = 2 / 3: the source buffer is in the oct layout of the bf16x3 / bf16x6 DMA dataflow (kernels.hpp), value = the sum
+// of its bf16 parts (exact for three parts)
 __global__ __launch_bounds__(256) void export_k(const float* src, long long src_bstride, int c0, int C, int Fq, int T,
                                                 int Tp, const double* stats, int sstride, int ident_c, float* dst,
                                                 int oct) {
@@ -112,7 +113,8 @@ __global__ __launch_bounds__(256) void export_k(const float* src, long long src_
     for (int f = fr; f < Fq; f += 8)
       if (tl < nt) {
         const long long e = (((long long)(ch >> 3) * Fq + f) * Tp + t0 + tl) * 8 + (ch & 7);
-        const float v = __uint_as_float((unsigned)hb[e] << 16) + __uint_as_float((unsigned)hb[half_e + e] << 16);
+        float v = __uint_as_float((unsigned)hb[e] << 16) + __uint_as_float((unsigned)hb[half_e + e] << 16);
+        if (oct == 3) v += __uint_as_float((unsigned)hb[2 * half_e + e] << 16);
         s_v[f][tl] = (v - mean) * rstd;
       }
   } else {

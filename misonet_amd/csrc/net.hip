@@ -102,6 +102,7 @@ struct ConvL {
   long long w_off = 0, b_off = 0;   // offsets (floats) into the device weight arena
   long long w16_off = 0;            // offset (floats) of the bf16 hi/lo packed weights
   long long wf_off = 0;             // offset (floats) of the float32 weights in bf16-image order (conv_wprep_k source)
+  long long wf6_off = 0;            // offset (floats) of the float32 weights [cg][chunk of 8][tap][32][8] (conv_wprep6_k source)
 };
 
 struct TcnHalf { int dw, prelu, gamma, beta, pw; long long o_dw, o_prelu, o_gamma, o_beta, o_pw; };
@@ -131,7 +132,7 @@ struct misonet_net {
   std::vector<Tap> taps;
   float* w_dev = nullptr;
   bool committed = false;
-  int precision = 0;             // 0: exact f32 MFMA, 1: bf16x3 split MFMA
+  int precision = 0;             // 0: exact f32 MFMA, 1: bf16x3 planar, 2: bf16x3 DMA dataflow, 3: bf16x6 DMA dataflow
 };
 
 static int find_tensor(const misonet_net* n, const std::string& name) {
@@ -288,6 +289,20 @@ static int build_plan(misonet_net* n) {
 
 static long long align_up(long long x, long long a) { return (x + a - 1) / a * a; }
 
+// precision 2 ("bf16x3") and 3 ("bf16x6"), the DMA dataflows: the dense-block buffers and everything between them travel
+// in the oct layout (2 bf16 parts = the bytes of float32, or 3 parts = 6 bytes per element); the network input/output,
+// the F <= 3 bottleneck buffers and the TCN stay planar float32.  Returns the ConvArgs::in_oct / out_oct code.
+static inline int buf_oct(const misonet_net* n, int b) {
+  if (n->precision != 2 && n->precision != 3) return 0;
+  const bool o = (b >= B_E0 && b <= B_E4) || (b >= B_D2 && b <= B_D6) || (b >= B_X2 && b <= B_X6);
+  return o ? (n->precision == 3 ? 3 : 1) : 0;
+}
+// floats per sample of buffer b (an oct3 buffer holds 1.5 floats per element; C is a multiple of 8 there)
+static inline long long bstride(const misonet_net* n, const Layout& L, int b) {
+  const long long e = (long long)n->bufs[b].C * n->bufs[b].F * L.Tp;
+  return buf_oct(n, b) == 3 ? e + e / 2 : e;
+}
+
 static Layout make_layout(const misonet_net* n, int N, int T) {
   Layout L;
   L.N = N; L.T = T; L.Tp = frames_pitch(T);
@@ -304,13 +319,14 @@ static Layout make_layout(const misonet_net* n, int N, int T) {
   long long d = 0;
   for (int b = 0; b < NBUF; ++b) {
     L.data_off[b] = d;
-    d += align_up((long long)N * n->bufs[b].C * n->bufs[b].F * L.Tp, 64);
+    d += align_up((long long)N * bstride(n, L, b), 64);
   }
   long long wmax = 0, cmax = 0;
   auto scan = [&](const std::vector<ConvL>& v) {
     for (const ConvL& c : v) {
       const long long g = (c.Cout + 31) / 32, k = (c.Cin + 15) / 16;
       wmax = std::max(wmax, g * k * (2LL * 9 * 2 * 32 * 16));
+      wmax = std::max(wmax, conv_bf16x6_wps_bytes((c.Cin + 7) / 8 * 8, c.Cout));
       cmax = std::max(cmax, g * 32);
     }
   };
@@ -328,16 +344,6 @@ static inline float* buf_ptr(const Layout& L, void* ws, int b) {
 }
 static inline double* stats_base(void* ws) { return reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + 256); }
 static inline double* stats_ptr(const Layout& L, void* ws, int b) { return stats_base(ws) + L.stats_off[b]; }
-static inline long long bstride(const misonet_net* n, const Layout& L, int b) {
-  return (long long)n->bufs[b].C * n->bufs[b].F * L.Tp;
-}
-
-// precision 2 ("bf16x3" DMA dataflow): the dense-block buffers and everything between them travel in the oct layout;
-// the network input/output, the F <= 3 bottleneck buffers and the TCN stay planar float32.
-static inline bool buf_is_oct(const misonet_net* n, int b) {
-  if (n->precision != 2) return false;
-  return (b >= B_E0 && b <= B_E4) || (b >= B_D2 && b <= B_D6) || (b >= B_X2 && b <= B_X6);
-}
 
 static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL& c, hipStream_t s, int n0 = 0, int nb = -1) {
   ConvArgs a;
@@ -367,9 +373,11 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
   a.out += (long long)n0 * a.out_bstride;
   a.in_stats += (long long)n0 * a.in_sstride * 2;
   a.out_stats += (long long)n0 * a.out_sstride * 2;
-  if (a.w16) { a.cop = 32; a.ncg = (c.Cout + 31) / 32; }
-  a.in_oct = buf_is_oct(n, c.in_buf);
-  a.out_oct = buf_is_oct(n, c.out_buf);
+  a.in_oct = buf_oct(n, c.in_buf);
+  a.out_oct = buf_oct(n, c.out_buf);
+  // bf16x6: the planar-input layers (network input, F <= 3 bottleneck) run on the exact f32 kernel
+  if (n->precision == 3 && !a.in_oct) a.w16 = nullptr;
+  if (a.w16 || a.in_oct) { a.cop = 32; a.ncg = (c.Cout + 31) / 32; }
   static int sync_dbg = -1;                 // MISONET_SYNC_DEBUG=1: name every conv launch and wait for it (fault hunting)
   if (sync_dbg < 0) { const char* e = getenv("MISONET_SYNC_DEBUG"); sync_dbg = e ? atoi(e) : 0; }
   struct SyncDbg {
@@ -382,6 +390,19 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
       fprintf(stderr, "%s\n", hipGetErrorString(e));
     }
   } sync_guard{s, a, sync_dbg};
+  if (a.in_oct == 3) {
+    a.wps = reinterpret_cast<char*>(ws) + L.wps_base + (long long)n0 * L.wps_nstride;
+    a.wps_nstride = L.wps_nstride;
+    a.btab = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + L.btab_base) + (long long)n0 * L.btab_nstride;
+    a.btab_nstride = L.btab_nstride;
+    {
+      ProfScope pw(s, PK_OTHER);
+      HIPCHK(launch_conv_wprep6(a, n->w_dev + c.wf6_off, nb, s));
+    }
+    ProfScope ps(s, PK_CONV);
+    HIPCHK(launch_conv_bf16x6(a, nb, s));
+    return MISONET_OK;
+  }
   if (a.in_oct) {
     a.wps = reinterpret_cast<char*>(ws) + L.wps_base + (long long)n0 * L.wps_nstride;
     a.wps_nstride = L.wps_nstride;
@@ -597,6 +618,28 @@ static void pack_conv_bf16(const misonet_net* n, const ConvL& c, std::vector<flo
               }
 }
 
+// bf16x6 path: float32 weights [cg][chunk of 8 ci][tap = kt*3 + kf][32 co][8 ci], zero padded (conv_wprep6_k source)
+static void pack_conv_wf6(const misonet_net* n, const ConvL& c, std::vector<float>& arena) {
+  const std::vector<float>& W = n->tensors[c.wt].host;
+  const int nchunk = (c.Cin + 7) / 8;
+  const int ncg = (c.Cout + 31) / 32;
+  float* wf = arena.data() + c.wf6_off;
+  for (int cg = 0; cg < ncg; ++cg)
+    for (int kc = 0; kc < nchunk; ++kc)
+      for (int kt = 0; kt < 3; ++kt)
+        for (int kf = 0; kf < 3; ++kf)
+          for (int col = 0; col < 32; ++col)
+            for (int e = 0; e < 8; ++e) {
+              const int ci = kc * 8 + e, co = cg * 32 + col;
+              float v = 0.f;
+              if (ci < c.Cin && co < c.Cout) {
+                if (c.transposed) v = W[(((long long)ci * c.Cout + co) * 3 + (2 - kt)) * 3 + (2 - kf)];
+                else v = W[(((long long)co * c.Cin + ci) * 3 + kt) * 3 + kf];
+              }
+              wf[((((long long)cg * nchunk + kc) * 9 + (kt * 3 + kf)) * 32 + col) * 8 + e] = v;
+            }
+}
+
 int misonet_net_commit(misonet_net* n) {
   if (!n) return fail(MISONET_EINVAL, "null argument");
   for (const Tensor& t : n->tensors)
@@ -610,6 +653,7 @@ int misonet_net_commit(misonet_net* n) {
       c.b_off = take((long long)c.ncg * c.cop);
       c.w16_off = take((long long)((c.Cout + 31) / 32) * ((c.Cin + 15) / 16) * 2 * 9 * 2 * 32 * 8 / 2);   // u16 -> floats
       c.wf_off = take((long long)((c.Cout + 31) / 32) * ((c.Cin + 15) / 16) * 9 * 2 * 32 * 8);
+      c.wf6_off = take((long long)((c.Cout + 31) / 32) * ((c.Cin + 7) / 8) * 9 * 32 * 8);
     }
   };
   place(n->enc);
@@ -623,8 +667,8 @@ int misonet_net_commit(misonet_net* n) {
       tb.h[h].o_pw = take(128 * 128);
     }
   std::vector<float> arena((size_t)off, 0.f);
-  for (const ConvL& c : n->enc) { pack_conv(n, c, arena); pack_conv_bf16(n, c, arena); }
-  for (const ConvL& c : n->dec) { pack_conv(n, c, arena); pack_conv_bf16(n, c, arena); }
+  for (const ConvL& c : n->enc) { pack_conv(n, c, arena); pack_conv_bf16(n, c, arena); pack_conv_wf6(n, c, arena); }
+  for (const ConvL& c : n->dec) { pack_conv(n, c, arena); pack_conv_bf16(n, c, arena); pack_conv_wf6(n, c, arena); }
   for (const TcnBlock& tb : n->tcn)
     for (int h = 0; h < 2; ++h) {
       const TcnHalf& H = tb.h[h];
@@ -642,13 +686,15 @@ int misonet_net_commit(misonet_net* n) {
   HIPCHK(conv_init());
   HIPCHK(conv_bf16_init());
   HIPCHK(conv_bf16_dma_init());
+  HIPCHK(conv_bf16x6_init());
   n->committed = true;
   return MISONET_OK;
 }
 
 int misonet_net_set_precision(misonet_net* n, int mode) {
   if (!n) return fail(MISONET_EINVAL, "null argument");
-  if (mode < 0 || mode > 2) return fail(MISONET_EINVAL, "precision mode must be 0 (f32), 1 (bf16x3, planar) or 2 (bf16x3, DMA dataflow)");
+  if (mode < 0 || mode > 3)
+    return fail(MISONET_EINVAL, "precision mode must be 0 (f32), 1 (bf16x3, planar), 2 (bf16x3, DMA dataflow) or 3 (bf16x6)");
   n->precision = mode;
   return MISONET_OK;
 }
@@ -711,7 +757,7 @@ int misonet_net_tap(misonet_net* n, const char* name, const void* ws, int B, int
       void* w = const_cast<void*>(ws);
       HIPCHK(launch_export(buf_ptr(L, w, t.buf), bstride(n, L, t.buf), t.c0, t.C, n->bufs[t.buf].F, T, L.Tp,
                            t.normalised ? stats_ptr(L, w, t.buf) : nullptr, n->bufs[t.buf].C, 0, dst, B,
-                           reinterpret_cast<hipStream_t>(stream), buf_is_oct(n, t.buf) ? 1 : 0));
+                           reinterpret_cast<hipStream_t>(stream), buf_oct(n, t.buf) == 3 ? 3 : (buf_oct(n, t.buf) ? 2 : 0)));
       return MISONET_OK;
     }
   return fail(MISONET_EINVAL, "unknown tap '%s'", name);
