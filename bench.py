@@ -52,7 +52,7 @@ MODES = {
     "bf16x3":  ("conv3x3_bf16x3_dma2", 3, False),    # 2 bf16 pieces (16 bits), 3 terms: inside 1e-3 but not fp32-faithful
     "bf16x3p": ("conv3x3_bf16x3", 3, False),
 }
-HEADLINE_PRECISION = "f32"
+HEADLINE_PRECISION = "bf16x6"
 
 
 def conv_flops_per_forward(in_ch, out_ch, T, en=(24, 32, 32, 32, 32, 64, 128), de=(128, 64, 32, 32, 32, 32, 24)):
