@@ -28,7 +28,12 @@
 //     A = [w_h | w_l] gives hl + lh.  27 MFMAs per (output row, chunk) = 9 taps x 6 terms x 8 channels / 16: no padding;
 //   * row reuse as in the bf16x3 kernel: an input fragment of staged row R serves the output rows f' with f' + kf = R,
 //     and the 18 weight fragments of a phase stay in registers: 48 LDS fragment reads per 108 MFMAs;
-//   * all layer types run 4-row tiles (the 9 staged rows of a stride-2 tile fit: 140 KB for two stages).
+//   * all layer types run 4-row tiles (the 9 staged rows of a stride-2 tile fit: 140 KB for two stages);
+//   * the tile epilogue (ELU, statistics, exact 3-way split, 16-byte stores: ~200 VALU instructions per row and lane)
+//     runs on the PRODUCER waves, which otherwise only issue 16 DMA instructions per chunk: a consumer hands the four
+//     accumulator rows of a finished tile over through a 2-slot LDS mailbox, one row per K-chunk of the NEXT tile
+//     (ds_write_b128 x 4), so its own instruction stream is MFMAs + operand reads only and the epilogue VALU work
+//     executes in the shadow of the matrix pipe on the same SIMD.
 #include "kernels.hpp"
 #include "conv_epilogue.hpp"
 #include "conv_bf16_core.hpp"
@@ -144,6 +149,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
   bf16x8* s_stage = reinterpret_cast<bf16x8*>(smem_b);         // [2][SN]
   float* s_tab = reinterpret_cast<float*>(s_stage + 2 * SN);   // [2 sets][bs | bl | br][FT][2][16]
   float* s_red = s_tab + 2 * 3 * FT * COP;                     // [2 sets][4 waves][COP][2]
+  float4* s_hand = reinterpret_cast<float4*>(s_red + 2 * 4 * COP * 2);   // [2 slots][4 waves][4 quads][64 lanes] (MODE != 1)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -153,6 +159,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
   const int half = lane >> 5, l31 = lane & 31;
   const int T = a.T, Tp = a.Tp, Fin = a.Fin, Cin = a.Cin;
   const int nchunk = Cin >> 3;
+  // deferred epilogue: the producers post-process row r of a finished tile during K-chunk r of the next one
+  const bool deferred = MODE != 1 && nchunk >= 4 && a.act && a.out_oct == 3 && !(a.dbg & 32);
+
+  // MISONET_TIMELINE=1: clock64() stamps of the third tile of workgroup 8 (consumer wave 0 -> slots 0.., producer wave 4
+  // -> slots 32..); experiments only
+  unsigned long long* const tl = (a.dbg_buf && blockIdx.x == 8 && lane == 0 && (wave == 0 || wave == 4)) ? a.dbg_buf + (wave ? 32 : 0) : nullptr;
+  int tl_i = 0;
+  unsigned long long tl_base = 0;
+#define STAMP(TI) do { if (tl && (TI) == 2 && tl_i < 30) { const unsigned long long c_ = clock64(); if (!tl_i) tl_base = c_; tl[tl_i++] = c_ - tl_base; tl[31] = tl_i; } } while (0)
 
   const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
   const unsigned per = (unsigned)(a.ntx * a.nty * a.ncg);                    // tiles per sample
@@ -276,19 +291,95 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
     }                                                                                                           \
   }
 
+    // deferred epilogue of row ROW of the PREVIOUS tile (coordinates p1_*), read from mailbox slot ROW & 1
+#define EPI_ROW(ROW)                                                                                            \
+  {                                                                                                             \
+    const float4* hq_ = s_hand + (((ROW) & 1) * 4 + rw) * (4 * 64) + lane;                                      \
+    float v_[16];                                                                                               \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                             \
+      const float4 h_ = hq_[q * 64];                                                                            \
+      v_[4 * q + 0] = h_.x; v_[4 * q + 1] = h_.y; v_[4 * q + 2] = h_.z; v_[4 * q + 3] = h_.w;                   \
+    }                                                                                                           \
+    const int f_ = p1_f0 + (ROW);                                                                               \
+    const int t_ = p1_t0 + 32 * rw + l31;                                                                       \
+    const bool ok_ = f_ < a.Fout && t_ < T;                                                                     \
+    const float mf_ = ok_ ? 1.f : 0.f;                                                                          \
+    _Pragma("unroll") for (int i2 = 0; i2 < 8; ++i2) {                                                          \
+      f32x2_e x_ = {v_[2 * i2], v_[2 * i2 + 1]};                                                                \
+      f32x2_e e_ = x_ * f32x2_e{1.4426950408889634f, 1.4426950408889634f};                                      \
+      e_.x = __builtin_amdgcn_exp2f(e_.x);                                                                      \
+      e_.y = __builtin_amdgcn_exp2f(e_.y);                                                                      \
+      e_ = e_ - f32x2_e{1.f, 1.f};                                                                              \
+      x_.x = x_.x > 0.f ? x_.x : e_.x;                                                                          \
+      x_.y = x_.y > 0.f ? x_.y : e_.y;                                                                          \
+      v_[2 * i2] = x_.x; v_[2 * i2 + 1] = x_.y;                                                                 \
+      const f32x2_e vm_ = x_ * f32x2_e{mf_, mf_};                                                               \
+      es1[i2] = es1[i2] + vm_;                                                                                  \
+      es2[i2].x = fmaf(vm_.x, vm_.x, es2[i2].x);                                                                \
+      es2[i2].y = fmaf(vm_.y, vm_.y, es2[i2].y);                                                                \
+    }                                                                                                           \
+    const unsigned vo_ = (unsigned)(f_ * Tp + t_) * 16u + (unsigned)(half + (p1_cg * COP >> 3)) * OP16;         \
+    store_oct_row<3>(v_, ers, vo_, OP16, ok_ && (p1_cg * COP + (0 + half) * 8 < a.Cout),                        \
+                     ok_ && (p1_cg * COP + (2 + half) * 8 < a.Cout));                                           \
+  }
+    // statistics of the previous tile: this wave's partial sums -> s_red set RS
+#define EPI_REDUCE(RS)                                                                                          \
+  {                                                                                                             \
+    float f1_[16], f2_[16];                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                             \
+      f1_[2 * i] = es1[i].x; f1_[2 * i + 1] = es1[i].y; f2_[2 * i] = es2[i].x; f2_[2 * i + 1] = es2[i].y;       \
+      es1[i] = f32x2_e{0.f, 0.f}; es2[i] = f32x2_e{0.f, 0.f};                                                   \
+    }                                                                                                           \
+    const float x1_ = reduce16_halfwave(f1_, lane);                                                             \
+    const float x2_ = reduce16_halfwave(f2_, lane);                                                             \
+    if ((lane & 16) == 0) {                                                                                     \
+      const int q_ = lane & 15;                                                                                 \
+      const int co_l_ = (q_ & 3) + 8 * (q_ >> 2) + 4 * half;                                                    \
+      float* sr_ = s_red + (RS) * (4 * COP * 2) + rw * (COP * 2);                                               \
+      sr_[co_l_ * 2 + 0] = x1_;                                                                                 \
+      sr_[co_l_ * 2 + 1] = x2_;                                                                                 \
+    }                                                                                                           \
+  }
+    // output descriptors of the tile that becomes "previous"
+#define EPI_SETUP(PN)                                                                                           \
+  {                                                                                                             \
+    const unsigned long long pa_ = reinterpret_cast<unsigned long long>(a.out) +                                \
+                                   (unsigned long long)(PN) * a.out_bstride * 4ull + (unsigned long long)(a.out_c0 >> 3) * OP16; \
+    const unsigned long long pb_ = (unsigned long long)(a.out_sstride >> 3) * OP16;                             \
+    const unsigned nrec_ = (unsigned)(a.Cout >> 3) * OP16;                                                      \
+    ers[0] = make_rsrc_e(pa_, nrec_);                                                                           \
+    ers[1] = make_rsrc_e(pa_ + pb_, nrec_);                                                                     \
+    ers[2] = make_rsrc_e(pa_ + 2 * pb_, nrec_);                                                                 \
+  }
+
     TILE_COORDS(k)
     TILE_SETUP()
     DMA_STAGE(0, 0)
     TILE_TABLES(0)
     unsigned g = 0, ti = 0;
-    int p1_n = 0, p1_cg = 0;                                   // the previous tile, whose statistics are still to be flushed
+    // finished tiles whose statistics are still to be flushed: p1 = previous tile, p2 = the one before.  With the
+    // deferred epilogue the partials of tile j are complete only after chunk 3 of tile j + 1.
+    int p1_n = 0, p1_cg = 0, p1_f0 = 0, p1_t0 = 0, p2_n = 0, p2_cg = 0;
+    const unsigned OP16 = (unsigned)a.Fout * (unsigned)Tp * 16u;               // bytes per output octet plane
+    __amdgpu_buffer_rsrc_t ers[3];
+    ers[0] = make_rsrc_e(reinterpret_cast<unsigned long long>(a.out), 0u);
+    ers[1] = ers[0]; ers[2] = ers[0];
+    f32x2_e es1[8], es2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { es1[i] = f32x2_e{0.f, 0.f}; es2[i] = f32x2_e{0.f, 0.f}; }
     for (;;) {
       bool more = false;
-      const int c_n = n, c_cg = cg;
+      const int c_n = n, c_cg = cg, c_f0 = f0, c_t0 = t0;
       for (int kc = 0; kc < nchunk; ++kc, ++g) {
+        STAMP(ti);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // chunk g has landed (hipcc does not count LDS-DMA loads)
+        STAMP(ti);
         __syncthreads();                                       // barrier g
-        if (kc == 0 && ti >= 1) TILE_STATS(p1_n, p1_cg, (ti + 1) & 1)
+        STAMP(ti);
+        if (kc == 0) {
+          if (!deferred && ti >= 1) TILE_STATS(p1_n, p1_cg, (ti + 1) & 1)
+          if (deferred && ti >= 2) TILE_STATS(p2_n, p2_cg, ti & 1)
+        }
         if (kc + 1 < nchunk) {
           DMA_STAGE(kc + 1, (g + 1) & 1)
         } else {
@@ -301,13 +392,36 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
             TILE_TABLES((ti + 1) & 1)
           }
         }
+        STAMP(ti);
+        if (deferred && ti >= 1 && kc < 4) {                   // row kc of the previous tile, behind the DMA issue
+          if (kc == 0) EPI_ROW(0) else if (kc == 1) EPI_ROW(1) else if (kc == 2) EPI_ROW(2) else EPI_ROW(3)
+          if (kc == 3) EPI_REDUCE((ti + 1) & 1)
+        }
       }
-      p1_n = c_n; p1_cg = c_cg;
+      p2_n = p1_n; p2_cg = p1_cg;
+      p1_n = c_n; p1_cg = c_cg; p1_f0 = c_f0; p1_t0 = c_t0;
+      if (deferred) EPI_SETUP(p1_n)
       ++ti;
       if (!more) break;
     }
+    if (deferred) {
+      // drain: the four rows of the last tile arrive one per barrier round (the consumers keep writing the mailbox)
+      __syncthreads();
+      if (ti >= 2) TILE_STATS(p2_n, p2_cg, ti & 1)
+      EPI_ROW(0)
+      __syncthreads();
+      EPI_ROW(1)
+      __syncthreads();
+      EPI_ROW(2)
+      __syncthreads();
+      EPI_ROW(3)
+      EPI_REDUCE((ti + 1) & 1)
+    }
     __syncthreads();                                           // final barrier: the last epilogue is done
     TILE_STATS(p1_n, p1_cg, (ti + 1) & 1)
+#undef EPI_ROW
+#undef EPI_REDUCE
+#undef EPI_SETUP
 #undef TILE_SETUP
 #undef DMA_STAGE
 #undef TILE_TABLES
@@ -316,6 +430,62 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
     // =============================================== consumers ===============================================
     TILE_COORDS(k)
     unsigned g = 0, ti = 0;
+    // mailbox write of one accumulator row: slot (row & 1), 4 x ds_write_b128 per lane
+#define HAND_ROW(ROW, SRC)                                                                                      \
+  {                                                                                                             \
+    float4* hq_ = s_hand + (((ROW) & 1) * 4 + wave) * (4 * 64) + lane;                                          \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                               \
+      hq_[q * 64] = make_float4((SRC)[4 * q + 0], (SRC)[4 * q + 1], (SRC)[4 * q + 2], (SRC)[4 * q + 3]);        \
+  }
+    if (deferred) {
+      f32x16 prev[3];                                          // rows 1..3 of the previous tile, until their chunk comes
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) prev[r][i] = 0.f;
+      for (;;) {
+        f32x16 acc[4];
+        const bool wave_live = (t0 + 32 * wave < T);
+        for (int kc = 0; kc < nchunk; ++kc, ++g) {
+          STAMP(ti);
+          __syncthreads();                                     // barrier g: stage g & 1 holds chunk g
+          STAMP(ti);
+          if (kc == 0) {
+            const float* tb = s_tab + (ti & 1) * (3 * FT * COP);
+            conv_acc_init_rows(acc, t0 + 32 * wave, T, lane, tb, tb + FT * COP, tb + 2 * FT * COP);
+          }
+          // row kc + 1 of the previous tile goes into the mailbox now; the producers read it behind the next barrier.
+          // (row 0 was written at the end of that tile; slot (kc + 1) & 1 was released by the barrier just passed)
+          if (ti >= 1) {
+            if (kc == 0) HAND_ROW(1, prev[0])
+            else if (kc == 1) HAND_ROW(2, prev[1])
+            else if (kc == 2) HAND_ROW(3, prev[2])
+          }
+          if (wave_live && !(a.dbg & 1)) {
+            const bf16x8* st = s_stage + (g & 1) * SN;
+            __builtin_amdgcn_s_setprio(1);
+            chunk_mfma6<NR, SF, TR2>(acc, st, st + 3 * XN, wave, half, l31);
+            __builtin_amdgcn_s_setprio(0);
+          }
+        }
+        HAND_ROW(0, acc[0])
+#pragma unroll
+        for (int r = 0; r < 3; ++r) prev[r] = acc[r + 1];
+        ++ti;
+        k += (unsigned)nslots;
+        if (k >= nk) break;
+        TILE_COORDS(k)
+      }
+      // drain (the producers post-process one row per barrier round)
+      __syncthreads();
+      HAND_ROW(1, prev[0])
+      __syncthreads();
+      HAND_ROW(2, prev[1])
+      __syncthreads();
+      HAND_ROW(3, prev[2])
+      __syncthreads();
+      __syncthreads();                                         // final barrier
+    } else {
     for (;;) {
       f32x16 acc[4];
       const bool wave_live = (t0 + 32 * wave < T);             // this consumer's frames exist (ragged last tile)
@@ -340,7 +510,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
       TILE_COORDS(k)
     }
     __syncthreads();                                           // final barrier
+    }
+#undef HAND_ROW
   }
+#undef STAMP
 #undef TILE_COORDS
 #endif
 }
@@ -424,7 +597,9 @@ __global__ __launch_bounds__(288) void conv_wprep6_k(const float* wf, const doub
 }
 
 static size_t x6_lds_bytes(int NR) {
-  return (size_t)(2 * (3 * NR * X6_TW + X6_WU)) * 16 + (size_t)(2 * 3 * FT * 32 + 2 * 4 * 32 * 2) * sizeof(float);
+  // two stages + epilogue tables + statistics partials (+ the 2-slot accumulator mailbox, not for the stride-2 mode)
+  return (size_t)(2 * (3 * NR * X6_TW + X6_WU)) * 16 + (size_t)(2 * 3 * FT * 32 + 2 * 4 * 32 * 2) * sizeof(float) +
+         (NR == 9 ? 0 : (size_t)2 * 4 * 4 * 64 * 16);
 }
 
 hipError_t conv_bf16x6_init() {
@@ -460,6 +635,14 @@ hipError_t launch_conv_bf16x6(const ConvArgs& a_in, int n_samples, hipStream_t s
     a.dbg = dbg;
   }
   a.dbg_buf = nullptr;
+  static int tl_env = -1, tl_done = 0;
+  static unsigned long long* tl_buf = nullptr;
+  if (tl_env < 0) { const char* e = getenv("MISONET_TIMELINE"); tl_env = e ? atoi(e) : 0; }
+  const bool do_tl = tl_env && tl_done < 2 && !a.tr2 && a.sf == 1 && a.Cin == tl_env && a.Fout == 63 && n_samples >= 8;
+  if (do_tl) {
+    if (!tl_buf && hipMalloc(reinterpret_cast<void**>(&tl_buf), 64 * 8) != hipSuccess) tl_buf = nullptr;
+    if (tl_buf) { (void)hipMemsetAsync(tl_buf, 0, 64 * 8, s); a.dbg_buf = tl_buf; }
+  }
   (void)conv_grid(a, n_samples, TT, FT, 1);                       // tile geometry: 4 rows x 128 frames
   static int g_cus = 0;
   if (!g_cus) {
@@ -478,6 +661,17 @@ hipError_t launch_conv_bf16x6(const ConvArgs& a_in, int n_samples, hipStream_t s
   if (mode == 0) hipLaunchKernelGGL((conv3x3_bf16x6<0>), pgrid, dim3(512), x6_lds_bytes(6), s, a, nslots);
   else if (mode == 1) hipLaunchKernelGGL((conv3x3_bf16x6<1>), pgrid, dim3(512), x6_lds_bytes(9), s, a, nslots);
   else hipLaunchKernelGGL((conv3x3_bf16x6<2>), pgrid, dim3(512), x6_lds_bytes(3), s, a, nslots);
+  if (do_tl && tl_buf) {
+    unsigned long long h[64];
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h, tl_buf, sizeof(h), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[timeline-x6] Cin=%d Fout=%d n=%d consumer(%llu):", a.Cin, a.Fout, n_samples, h[31]);
+    for (unsigned long long i = 0; i < h[31] && i < 30; ++i) fprintf(stderr, " %llu", h[i]);
+    fprintf(stderr, "\n[timeline-x6] producer(%llu):", h[63]);
+    for (unsigned long long i = 0; i < h[63] && i < 30; ++i) fprintf(stderr, " %llu", h[32 + i]);
+    fprintf(stderr, "\n");
+    ++tl_done;
+  }
   return hipGetLastError();
 }
 

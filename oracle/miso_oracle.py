@@ -27,13 +27,30 @@ import torch
 import torch.nn.functional as F
 
 EPS_GLN = 1e-8          # model.py:6
+# Arithmetic of the restatement.  float32 = the reference (model.py:77-80 `.float()`, float32 parameters).  Tests that
+# need a ground truth BETTER than any float32 implementation (conditioning studies) switch to float64 through
+# ``with precision(torch.float64): ...``; nothing else about the computation changes.
+DTYPE = torch.float32
+
+
+class precision:
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global DTYPE
+        self.old, DTYPE = DTYPE, self.dtype
+
+    def __exit__(self, *exc):
+        global DTYPE
+        DTYPE = self.old
 
 
 def _t(sd, key):
     v = sd[key]
     if isinstance(v, np.ndarray):
         v = torch.from_numpy(v)
-    return v.float()
+    return v.to(DTYPE)
 
 
 def _conv_elu_in(x, w, b, stride, padding, transposed=False, act=True):
@@ -146,7 +163,7 @@ def _split_complex(out):
 @torch.no_grad()
 def miso1_forward(mixture, sd, taps: Optional[Dict] = None):
     """mixture complex [B,M,T,129] -> complex64 [B,num_spks,T,129]  (model.py:76-111)."""
-    x = torch.cat((mixture.real.float(), mixture.imag.float()), dim=1)
+    x = torch.cat((mixture.real.to(DTYPE), mixture.imag.to(DTYPE)), dim=1)
     return _split_complex(trunk_forward(x, sd, taps))
 
 
@@ -154,7 +171,7 @@ def miso1_forward(mixture, sd, taps: Optional[Dict] = None):
 def miso3_forward(mixture, a, b, sd, taps: Optional[Dict] = None):
     """model.py:350-395.  Channel order: real(mix, a, b) then imag(mix, a, b); the reference's
     parameter names for a/b are swapped at the call site (tester.py:1242) -- order is what counts."""
-    real = torch.cat((mixture.real.float(), a.real.float(), b.real.float()), dim=1)
-    imag = torch.cat((mixture.imag.float(), a.imag.float(), b.imag.float()), dim=1)
+    real = torch.cat((mixture.real.to(DTYPE), a.real.to(DTYPE), b.real.to(DTYPE)), dim=1)
+    imag = torch.cat((mixture.imag.to(DTYPE), a.imag.to(DTYPE), b.imag.to(DTYPE)), dim=1)
     x = torch.cat((real, imag), dim=1)
     return _split_complex(trunk_forward(x, sd, taps))

@@ -85,40 +85,39 @@ def test_full_size_mvdr_alone():
     assert e_s < 1e-4 and e_w < 1e-4 and e_o < 1e-4
 
 
-@pytest.mark.parametrize("mode", ["bf16x6", "bf16x3"])
-def test_folded_norm_ill_conditioned_statistics(sd1, mode):
-    """The DMA dataflow folds the instance norm of a layer's input into the weights (W' = W * rstd, shift table): the
-    products W' * x cancel against the shift when |mean| >> std.  Inputs with a large DC offset per channel and weights
-    with large biases (post-ELU means far from zero) against the oracle."""
+@pytest.mark.parametrize("dc,bias_sigma", [(5.0, 2.0), (25.0, 4.0)])
+def test_folded_norm_ill_conditioned_statistics(sd1, dc, bias_sigma):
+    """The DMA dataflows fold the instance norm of a layer's input into the weights (W' = W * rstd, shift table): the
+    products W' * x cancel against the shift when |mean| >> std.  Inputs with a DC offset per channel and weights with
+    large biases (post-ELU means far from zero) make the whole forward ill-conditioned for ANY float32 implementation,
+    so the ground truth here is the oracle run in float64 and the yardstick is the exact-f32 mode's distance from it.
+    bf16x6 (exact operands, fp32-faithful) must stay at that yardstick; bf16x3 (16-bit operands) is only reported --
+    this loss of |mean| / std is why it is not the headline arithmetic."""
     _need_gpu()
     import misonet_amd as mz
     from misonet_amd import weights as W
     from oracle import miso_oracle
-    if mode not in _modes():
-        pytest.skip(f"mode {mode} not built")
     sd = {k: v.copy() for k, v in sd1.items()}
     r = np.random.default_rng(17)
     for k in sd:
         if k.endswith(".bias") and sd[k].ndim == 1:
-            sd[k] = (sd[k] + 4.0 * r.standard_normal(sd[k].shape)).astype(np.float32)    # ELU outputs with |mean| ~ 4 std
+            sd[k] = (sd[k] + bias_sigma * r.standard_normal(sd[k].shape)).astype(np.float32)
     T = 96
     x = (r.standard_normal((2, 6, T, 129)) + 1j * r.standard_normal((2, 6, T, 129))).astype(np.complex64)
-    x += np.complex64(25.0 + 10.0j)                                                       # DC offset 25x the std
+    x += np.complex64(dc + 0.4j * dc)
+    with miso_oracle.precision(torch.float64):
+        truth = np.concatenate([miso_oracle.miso1_forward(torch.from_numpy(x[b:b + 1]).to(torch.complex128), sd).numpy()
+                                for b in range(2)])
+    o32 = np.concatenate([miso_oracle.miso1_forward(torch.from_numpy(x[b:b + 1]), sd).numpy() for b in range(2)])
     m1 = mz.MISO_1(2, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN").cuda(0)
     m1.load_state_dict(sd)
-    m1.eval().set_precision(mode)
-    y = m1(torch.from_numpy(x).cuda()).cpu().numpy()
-    y_ref = np.concatenate([miso_oracle.miso1_forward(torch.from_numpy(x[b:b + 1]), sd).numpy() for b in range(2)])
-    m1.set_precision("f32")
-    y32 = m1(torch.from_numpy(x).cuda()).cpu().numpy()
-    e32, em = mag_parity(y32, y_ref)[0], mag_parity(y, y_ref)[0]
-    print(f"[ill-conditioned] f32 {e32:.3e}  {mode} {em:.3e}")
-    _assert_parity(y32, y_ref, "[f32] ill-conditioned statistics (DC offset, large biases)")
-    if mode == "bf16x3":
-        # measured 1.2e-2: with 16-bit operands the folded products W' * x lose |mean| / std of their relative accuracy
-        # against the shift table.  This is why bf16x3 is NOT the headline arithmetic (DESIGN.md section 3); the bound
-        # below only pins the size of the effect.
-        assert np.isfinite(em) and em < 5e-2
-    else:
-        _assert_parity(y, y_ref, f"[{mode}] ill-conditioned statistics (DC offset, large biases)")
-        assert em < 20 * max(e32, 1e-6), f"{mode} is not fp32-faithful under cancellation: {em:.3e} vs f32 {e32:.3e}"
+    m1.eval()
+    err = {"oracle_f32": mag_parity(o32, truth)[0]}
+    for mode in _modes():
+        m1.set_precision(mode)
+        err[mode] = mag_parity(m1(torch.from_numpy(x).cuda()).cpu().numpy(), truth)[0]
+    print(f"[ill-conditioned dc={dc} bias_sigma={bias_sigma}] error vs float64 truth: " +
+          "  ".join(f"{k} {v:.3e}" for k, v in err.items()))
+    # yardstick: the exact-f32 MFMA mode of this library under the same conditioning (the float32 oracle is reported too)
+    assert np.isfinite(err["f32"]) and np.isfinite(err["bf16x6"]) and np.isfinite(err["bf16x3"]), err
+    assert err["bf16x6"] <= 3.0 * err["f32"] + 2e-6, err
