@@ -59,13 +59,20 @@ int misonet_net_set_tensor(misonet_net* net, const char* key, const float* host_
 /* all tensors set -> repack into the kernel layouts and upload to the current device (synchronous) */
 int misonet_net_commit(misonet_net* net);
 
-/* arithmetic of the 3x3 convolutions (99.4 % of the FLOPs): 0 = exact float32 matrix cores
- * (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain; default), 1 = "bf16x3p": every product is evaluated as
- * w_hi*x_hi + w_hi*x_lo + w_lo*x_hi on the bf16 matrix cores with f32 accumulation (~1e-5 relative per layer) on
- * planar float32 activations, 2 = "bf16x3": the same arithmetic with the activations kept pre-split (bf16 hi/lo,
- * 8 channels per 16-byte unit) between the convolutions, the instance norm folded into per-sample weights and
- * LDS-DMA staging -- the fastest mode.  The choice is internal to the workspace: inputs, outputs and taps are the
- * same float32 / complex64 tensors in every mode. */
+/* arithmetic of the 3x3 convolutions (99.4 % of the FLOPs; the reference computes them in float32, model.py:77-80,
+ * 401-482):
+ *   0 "f32"     exact float32 matrix cores (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain); the default of a new handle;
+ *   3 "bf16x6"  fp32-FAITHFUL on the bf16 matrix cores: both operands are represented exactly as three bf16 pieces
+ *               (24 bits), the six leading partial products are accumulated in float32 (the dropped ones are < 2^-23
+ *               of a product, one float32 rounding); activations travel pre-split (oct3 layout: hi | mid | lo, 8 channels
+ *               per 16-byte unit), the instance norm is folded into per-sample weights, staging is LDS-DMA.  Same error
+ *               against the reference as mode 0 (2.3e-6 per forward) at 1.5-1.6 x its speed: what bench.py reports;
+ *   2 "bf16x3"  every product as w_hi*x_hi + w_hi*x_lo + w_lo*x_hi with 16-bit operands (2.4e-5 per forward, not
+ *               fp32-faithful; loses |mean|/std of its accuracy when a layer's input has |mean| >> std), same dataflow
+ *               with two parts -- the fastest mode;
+ *   1 "bf16x3p" the arithmetic of mode 2 on planar float32 activations (normalise-on-load staging).
+ * The choice is internal to the workspace (whose size depends on it: misonet_net_workspace_bytes must be asked again
+ * after a change): inputs, outputs and taps are the same float32 / complex64 tensors in every mode. */
 int misonet_net_set_precision(misonet_net* net, int mode);
 int misonet_net_get_precision(const misonet_net* net);
 

@@ -28,12 +28,7 @@
 //     A = [w_h | w_l] gives hl + lh.  27 MFMAs per (output row, chunk) = 9 taps x 6 terms x 8 channels / 16: no padding;
 //   * row reuse as in the bf16x3 kernel: an input fragment of staged row R serves the output rows f' with f' + kf = R,
 //     and the 18 weight fragments of a phase stay in registers: 48 LDS fragment reads per 108 MFMAs;
-//   * all layer types run 4-row tiles (the 9 staged rows of a stride-2 tile fit: 140 KB for two stages);
-//   * the tile epilogue (ELU, statistics, exact 3-way split, 16-byte stores: ~200 VALU instructions per row and lane)
-//     runs on the PRODUCER waves, which otherwise only issue 16 DMA instructions per chunk: a consumer hands the four
-//     accumulator rows of a finished tile over through a 2-slot LDS mailbox, one row per K-chunk of the NEXT tile
-//     (ds_write_b128 x 4), so its own instruction stream is MFMAs + operand reads only and the epilogue VALU work
-//     executes in the shadow of the matrix pipe on the same SIMD.
+//   * all layer types run 4-row tiles (the 9 staged rows of a stride-2 tile fit: 140 KB for two stages).
 #include "kernels.hpp"
 #include "conv_epilogue.hpp"
 #include "conv_bf16_core.hpp"
@@ -129,11 +124,19 @@ __device__ __forceinline__ void chunk_mfma6(f32x16 (&acc)[4], const bf16x8* sx, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// ONE persistent workgroup per CU, 8 waves: waves 0-3 = consumers (MFMAs + tile epilogue), waves 4-7 = producers (LDS-DMA
-// of the next chunk, epilogue tables of the next tile, float64 statistics atomics of the previous tile).  Workgroup b
-// belongs to XCD b & 7 and walks that XCD's own samples (n % 8 == xcd) tile by tile, row tile fastest.  One workgroup
-// barrier per K-chunk g: producers arrive when the DMA of chunk g has landed, consumers when the MFMAs of chunk g - 1
-// are done; chunks are numbered across tiles, so the first chunk of the next tile is in flight during the epilogue.
+// ONE persistent workgroup per CU, 8 waves: waves 0-3 = consumers (MFMAs + tile epilogue), waves 4-7 = producers (LDS-DMA,
+// epilogue tables of the coming tile, float64 statistics atomics of finished tiles).  Workgroup b belongs to XCD b & 7 and
+// walks that XCD's own samples (n % 8 == xcd) tile by tile, row tile fastest.  K-chunks are numbered across tiles; chunk
+// c lives in stage c & 1.  ONE workgroup barrier per chunk: barrier b separates chunk b - 1 from chunk b; producers
+// arrive at it when chunk b has landed, consumers when they are done reading chunk b - 1; behind it the producers put
+// chunk b + 1 into the stage that chunk b - 1 occupied (the first chunk of the next tile is in flight during an epilogue).
+//
+// Measured and NOT kept (git history): (i) a third stage with the first operands of chunk b
+// fetched during the last steps of chunk b - 1, so that the matrix pipe runs through the barrier -- 10 % SLOWER on the
+// same box: the producers' per-chunk loop (DMA issue ~2.8k cycles + landing + barrier) becomes the critical path, and
+// the consumers' 4.2k-cycle MFMA phase does not shrink because its length is set by the power limit, not by the operand
+// fetch; (ii) the tile epilogue on the producer waves through an LDS mailbox -- 4 % slower: a producer wave needs 3.3k
+// cycles per accumulator row behind its DMA issue.
 template <int MODE>
 __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int nslots) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (the LDS-DMA builtin has no host form)
@@ -141,15 +144,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
   constexpr int SF = MODE == 1 ? 2 : 1;
   constexpr bool TR2 = MODE == 2;
   constexpr int NR = MODE == 0 ? 6 : (MODE == 1 ? 9 : 3);      // staged input rows of a 4-row tile
+  constexpr int NS = 2;                                        // stages
   constexpr int XN = NR * X6_TW;                               // units per input part image
   constexpr int SN = 3 * XN + X6_WU;                           // units per stage: [x_h | x_m | x_l | w]
   constexpr int NXI = (XN + 255) / 256;
   constexpr int NWI = (X6_WU + 255) / 256;
   extern __shared__ __align__(16) unsigned char smem_b[];
-  bf16x8* s_stage = reinterpret_cast<bf16x8*>(smem_b);         // [2][SN]
-  float* s_tab = reinterpret_cast<float*>(s_stage + 2 * SN);   // [2 sets][bs | bl | br][FT][2][16]
-  float* s_red = s_tab + 2 * 3 * FT * COP;                     // [2 sets][4 waves][COP][2]
-  float4* s_hand = reinterpret_cast<float4*>(s_red + 2 * 4 * COP * 2);   // [2 slots][4 waves][4 quads][64 lanes] (MODE != 1)
+  bf16x8* s_stage = reinterpret_cast<bf16x8*>(smem_b);         // [NS][SN]
+  float* s_tab = reinterpret_cast<float*>(s_stage + NS * SN);  // [NS sets][bs | bl | br][FT][2][16] (written NS - 1 chunks ahead)
+  float* s_red = s_tab + NS * 3 * FT * COP;                    // [2 sets][4 waves][COP][2]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -159,11 +162,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
   const int half = lane >> 5, l31 = lane & 31;
   const int T = a.T, Tp = a.Tp, Fin = a.Fin, Cin = a.Cin;
   const int nchunk = Cin >> 3;
-  // deferred epilogue: the producers post-process row r of a finished tile during K-chunk r of the next one
-  const bool deferred = MODE != 1 && nchunk >= 4 && a.act && a.out_oct == 3 && !(a.dbg & 32);
 
-  // MISONET_TIMELINE=1: clock64() stamps of the third tile of workgroup 8 (consumer wave 0 -> slots 0.., producer wave 4
-  // -> slots 32..); experiments only
+  // MISONET_TIMELINE=<Cin>: clock64() stamps of the third tile of workgroup 8 (consumer wave 0 -> slots 0.., producer
+  // wave 4 -> slots 32..); experiments only
   unsigned long long* const tl = (a.dbg_buf && blockIdx.x == 8 && lane == 0 && (wave == 0 || wave == 4)) ? a.dbg_buf + (wave ? 32 : 0) : nullptr;
   int tl_i = 0;
   unsigned long long tl_base = 0;
@@ -172,8 +173,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
   const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
   const unsigned per = (unsigned)(a.ntx * a.nty * a.ncg);                    // tiles per sample
   const unsigned nk = (unsigned)((a.nsamp + 7 - (int)xcd) / 8) * per;        // tiles of this XCD's samples
-  unsigned k = slot;
-  if (k >= nk) return;
+  if (slot >= nk) return;
+  const unsigned ntile = (nk - slot + (unsigned)nslots - 1u) / (unsigned)nslots;   // tiles of this workgroup
+  const unsigned G = ntile * (unsigned)nchunk;                               // its chunks
 
   int t0, f0, n, cg;
 #define TILE_COORDS(K)                                                                                          \
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
     }                                                                                                           \
   }
 
-    // chunk KC of the current tile -> stage SB (xo walks one octet plane per chunk)
+    // chunk KC of the cursor's tile -> stage SB (xo walks one octet plane per chunk)
 #define DMA_STAGE(KC, SB)                                                                                       \
   {                                                                                                             \
     bf16x8* st_ = s_stage + (SB) * SN;                                                                          \
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
     }                                                                                                           \
   }
 
-    // epilogue tables of the current tile, set TS: producer wave rw builds output row f0 + rw, lane = output channel
+    // epilogue tables of the cursor's tile, set TS: producer wave rw builds output row f0 + rw, lane = output channel
 #define TILE_TABLES(TS)                                                                                         \
   {                                                                                                             \
     if (lane < COP) {                                                                                           \
@@ -276,231 +278,88 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
     }                                                                                                           \
   }
 
-    // float64 statistics of a finished tile (producer wave 0): sum of the four consumer partials per channel
-#define TILE_STATS(PN, PCG, RS)                                                                                 \
+    // float64 statistics of finished tile number J of this workgroup (producer wave 0): sum of the four consumer partials
+#define TILE_STATS(J)                                                                                           \
   {                                                                                                             \
     if (a.act && rw == 0) {                                                                                     \
-      const float* sr_ = s_red + (RS) * (4 * COP * 2);                                                          \
+      const unsigned kj_ = slot + (unsigned)(J) * (unsigned)nslots;                                             \
+      const unsigned grp_ = kj_ / per;                                                                          \
+      const unsigned tile_ = kj_ - grp_ * per;                                                                  \
+      const int pn_ = (int)(grp_ * 8u + xcd);                                                                   \
+      const int pcg_ = (int)((tile_ / (unsigned)a.nty) % (unsigned)a.ncg);                                      \
+      const float* sr_ = s_red + ((J) & 1) * (4 * COP * 2);                                                     \
       const int co_l = lane >> 1, which = lane & 1;                                                             \
-      const int co = (PCG) * COP + co_l;                                                                        \
+      const int co = pcg_ * COP + co_l;                                                                         \
       if (co < a.Cout) {                                                                                        \
         float tot = 0.f;                                                                                        \
         for (int w = 0; w < 4; ++w) tot += sr_[(w * COP + co_l) * 2 + which];                                   \
-        unsafeAtomicAdd(a.out_stats + ((long long)(PN) * a.out_sstride + a.out_c0 + co) * 2 + which, (double)tot); \
+        unsafeAtomicAdd(a.out_stats + ((long long)pn_ * a.out_sstride + a.out_c0 + co) * 2 + which, (double)tot); \
       }                                                                                                         \
     }                                                                                                           \
   }
 
-    // deferred epilogue of row ROW of the PREVIOUS tile (coordinates p1_*), read from mailbox slot ROW & 1
-#define EPI_ROW(ROW)                                                                                            \
+    // issue cursor: the next chunk to put in flight = chunk ci_kc of this workgroup's tile number ci_t
+    unsigned ci_g = 0, ci_t = 0;
+    int ci_kc = 0;
+#define ISSUE_NEXT()                                                                                            \
   {                                                                                                             \
-    const float4* hq_ = s_hand + (((ROW) & 1) * 4 + rw) * (4 * 64) + lane;                                      \
-    float v_[16];                                                                                               \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                             \
-      const float4 h_ = hq_[q * 64];                                                                            \
-      v_[4 * q + 0] = h_.x; v_[4 * q + 1] = h_.y; v_[4 * q + 2] = h_.z; v_[4 * q + 3] = h_.w;                   \
-    }                                                                                                           \
-    const int f_ = p1_f0 + (ROW);                                                                               \
-    const int t_ = p1_t0 + 32 * rw + l31;                                                                       \
-    const bool ok_ = f_ < a.Fout && t_ < T;                                                                     \
-    const float mf_ = ok_ ? 1.f : 0.f;                                                                          \
-    _Pragma("unroll") for (int i2 = 0; i2 < 8; ++i2) {                                                          \
-      f32x2_e x_ = {v_[2 * i2], v_[2 * i2 + 1]};                                                                \
-      f32x2_e e_ = x_ * f32x2_e{1.4426950408889634f, 1.4426950408889634f};                                      \
-      e_.x = __builtin_amdgcn_exp2f(e_.x);                                                                      \
-      e_.y = __builtin_amdgcn_exp2f(e_.y);                                                                      \
-      e_ = e_ - f32x2_e{1.f, 1.f};                                                                              \
-      x_.x = x_.x > 0.f ? x_.x : e_.x;                                                                          \
-      x_.y = x_.y > 0.f ? x_.y : e_.y;                                                                          \
-      v_[2 * i2] = x_.x; v_[2 * i2 + 1] = x_.y;                                                                 \
-      const f32x2_e vm_ = x_ * f32x2_e{mf_, mf_};                                                               \
-      es1[i2] = es1[i2] + vm_;                                                                                  \
-      es2[i2].x = fmaf(vm_.x, vm_.x, es2[i2].x);                                                                \
-      es2[i2].y = fmaf(vm_.y, vm_.y, es2[i2].y);                                                                \
-    }                                                                                                           \
-    const unsigned vo_ = (unsigned)(f_ * Tp + t_) * 16u + (unsigned)(half + (p1_cg * COP >> 3)) * OP16;         \
-    store_oct_row<3>(v_, ers, vo_, OP16, ok_ && (p1_cg * COP + (0 + half) * 8 < a.Cout),                        \
-                     ok_ && (p1_cg * COP + (2 + half) * 8 < a.Cout));                                           \
-  }
-    // statistics of the previous tile: this wave's partial sums -> s_red set RS
-#define EPI_REDUCE(RS)                                                                                          \
-  {                                                                                                             \
-    float f1_[16], f2_[16];                                                                                     \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                             \
-      f1_[2 * i] = es1[i].x; f1_[2 * i + 1] = es1[i].y; f2_[2 * i] = es2[i].x; f2_[2 * i + 1] = es2[i].y;       \
-      es1[i] = f32x2_e{0.f, 0.f}; es2[i] = f32x2_e{0.f, 0.f};                                                   \
-    }                                                                                                           \
-    const float x1_ = reduce16_halfwave(f1_, lane);                                                             \
-    const float x2_ = reduce16_halfwave(f2_, lane);                                                             \
-    if ((lane & 16) == 0) {                                                                                     \
-      const int q_ = lane & 15;                                                                                 \
-      const int co_l_ = (q_ & 3) + 8 * (q_ >> 2) + 4 * half;                                                    \
-      float* sr_ = s_red + (RS) * (4 * COP * 2) + rw * (COP * 2);                                               \
-      sr_[co_l_ * 2 + 0] = x1_;                                                                                 \
-      sr_[co_l_ * 2 + 1] = x2_;                                                                                 \
+    if (ci_g < G) {                                                                                             \
+      if (ci_kc == 0) {                                                                                         \
+        TILE_COORDS(slot + ci_t * (unsigned)nslots)                                                             \
+        TILE_SETUP()                                                                                            \
+        TILE_TABLES(ci_t % NS)                                                                                  \
+      }                                                                                                         \
+      if (!(a.dbg & 64)) DMA_STAGE(ci_kc, ci_g % NS)                                                            \
+      ++ci_g;                                                                                                   \
+      if (++ci_kc == nchunk) { ci_kc = 0; ++ci_t; }                                                             \
     }                                                                                                           \
   }
-    // output descriptors of the tile that becomes "previous"
-#define EPI_SETUP(PN)                                                                                           \
-  {                                                                                                             \
-    const unsigned long long pa_ = reinterpret_cast<unsigned long long>(a.out) +                                \
-                                   (unsigned long long)(PN) * a.out_bstride * 4ull + (unsigned long long)(a.out_c0 >> 3) * OP16; \
-    const unsigned long long pb_ = (unsigned long long)(a.out_sstride >> 3) * OP16;                             \
-    const unsigned nrec_ = (unsigned)(a.Cout >> 3) * OP16;                                                      \
-    ers[0] = make_rsrc_e(pa_, nrec_);                                                                           \
-    ers[1] = make_rsrc_e(pa_ + pb_, nrec_);                                                                     \
-    ers[2] = make_rsrc_e(pa_ + 2 * pb_, nrec_);                                                                 \
-  }
-
-    TILE_COORDS(k)
-    TILE_SETUP()
-    DMA_STAGE(0, 0)
-    TILE_TABLES(0)
-    unsigned g = 0, ti = 0;
-    // finished tiles whose statistics are still to be flushed: p1 = previous tile, p2 = the one before.  With the
-    // deferred epilogue the partials of tile j are complete only after chunk 3 of tile j + 1.
-    int p1_n = 0, p1_cg = 0, p1_f0 = 0, p1_t0 = 0, p2_n = 0, p2_cg = 0;
-    const unsigned OP16 = (unsigned)a.Fout * (unsigned)Tp * 16u;               // bytes per output octet plane
-    __amdgpu_buffer_rsrc_t ers[3];
-    ers[0] = make_rsrc_e(reinterpret_cast<unsigned long long>(a.out), 0u);
-    ers[1] = ers[0]; ers[2] = ers[0];
-    f32x2_e es1[8], es2[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { es1[i] = f32x2_e{0.f, 0.f}; es2[i] = f32x2_e{0.f, 0.f}; }
-    for (;;) {
-      bool more = false;
-      const int c_n = n, c_cg = cg, c_f0 = f0, c_t0 = t0;
-      for (int kc = 0; kc < nchunk; ++kc, ++g) {
-        STAMP(ti);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // chunk g has landed (hipcc does not count LDS-DMA loads)
-        STAMP(ti);
-        __syncthreads();                                       // barrier g
-        STAMP(ti);
-        if (kc == 0) {
-          if (!deferred && ti >= 1) TILE_STATS(p1_n, p1_cg, (ti + 1) & 1)
-          if (deferred && ti >= 2) TILE_STATS(p2_n, p2_cg, ti & 1)
-        }
-        if (kc + 1 < nchunk) {
-          DMA_STAGE(kc + 1, (g + 1) & 1)
-        } else {
-          k += (unsigned)nslots;
-          more = k < nk;
-          if (more) {
-            TILE_COORDS(k)
-            TILE_SETUP()
-            DMA_STAGE(0, (g + 1) & 1)
-            TILE_TABLES((ti + 1) & 1)
-          }
-        }
-        STAMP(ti);
-        if (deferred && ti >= 1 && kc < 4) {                   // row kc of the previous tile, behind the DMA issue
-          if (kc == 0) EPI_ROW(0) else if (kc == 1) EPI_ROW(1) else if (kc == 2) EPI_ROW(2) else EPI_ROW(3)
-          if (kc == 3) EPI_REDUCE((ti + 1) & 1)
-        }
-      }
-      p2_n = p1_n; p2_cg = p1_cg;
-      p1_n = c_n; p1_cg = c_cg; p1_f0 = c_f0; p1_t0 = c_t0;
-      if (deferred) EPI_SETUP(p1_n)
-      ++ti;
-      if (!more) break;
-    }
-    if (deferred) {
-      // drain: the four rows of the last tile arrive one per barrier round (the consumers keep writing the mailbox)
-      __syncthreads();
-      if (ti >= 2) TILE_STATS(p2_n, p2_cg, ti & 1)
-      EPI_ROW(0)
-      __syncthreads();
-      EPI_ROW(1)
-      __syncthreads();
-      EPI_ROW(2)
-      __syncthreads();
-      EPI_ROW(3)
-      EPI_REDUCE((ti + 1) & 1)
+    for (int i = 0; i < NS - 1; ++i) ISSUE_NEXT()
+    unsigned bt = 0;                                           // tile of chunk b - 1
+    int bkc = -1;                                              // its chunk index (-1 before the first barrier)
+    for (unsigned b = 0; b <= G; ++b) {
+      STAMP(bt);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // everything issued has landed (hipcc does not count LDS-DMA loads)
+      STAMP(bt);
+      __syncthreads();                                         // barrier b
+      STAMP(bt);
+      // the consumers finished the epilogue of tile bt - 1 before they entered the first chunk of tile bt
+      if (bkc == 0 && bt >= 1) TILE_STATS(bt - 1)
+      ISSUE_NEXT()                                             // chunk b + NS - 1
+      STAMP(bt);
+      if (bkc >= 0 && ++bkc == nchunk) { bkc = 0; ++bt; } else if (bkc < 0) bkc = 0;
     }
     __syncthreads();                                           // final barrier: the last epilogue is done
-    TILE_STATS(p1_n, p1_cg, (ti + 1) & 1)
-#undef EPI_ROW
-#undef EPI_REDUCE
-#undef EPI_SETUP
+    TILE_STATS(ntile - 1)
 #undef TILE_SETUP
 #undef DMA_STAGE
 #undef TILE_TABLES
 #undef TILE_STATS
+#undef ISSUE_NEXT
   } else {
     // =============================================== consumers ===============================================
+    unsigned k = slot;
     TILE_COORDS(k)
     unsigned g = 0, ti = 0;
-    // mailbox write of one accumulator row: slot (row & 1), 4 x ds_write_b128 per lane
-#define HAND_ROW(ROW, SRC)                                                                                      \
-  {                                                                                                             \
-    float4* hq_ = s_hand + (((ROW) & 1) * 4 + wave) * (4 * 64) + lane;                                          \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                               \
-      hq_[q * 64] = make_float4((SRC)[4 * q + 0], (SRC)[4 * q + 1], (SRC)[4 * q + 2], (SRC)[4 * q + 3]);        \
-  }
-    if (deferred) {
-      f32x16 prev[3];                                          // rows 1..3 of the previous tile, until their chunk comes
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) prev[r][i] = 0.f;
-      for (;;) {
-        f32x16 acc[4];
-        const bool wave_live = (t0 + 32 * wave < T);
-        for (int kc = 0; kc < nchunk; ++kc, ++g) {
-          STAMP(ti);
-          __syncthreads();                                     // barrier g: stage g & 1 holds chunk g
-          STAMP(ti);
-          if (kc == 0) {
-            const float* tb = s_tab + (ti & 1) * (3 * FT * COP);
-            conv_acc_init_rows(acc, t0 + 32 * wave, T, lane, tb, tb + FT * COP, tb + 2 * FT * COP);
-          }
-          // row kc + 1 of the previous tile goes into the mailbox now; the producers read it behind the next barrier.
-          // (row 0 was written at the end of that tile; slot (kc + 1) & 1 was released by the barrier just passed)
-          if (ti >= 1) {
-            if (kc == 0) HAND_ROW(1, prev[0])
-            else if (kc == 1) HAND_ROW(2, prev[1])
-            else if (kc == 2) HAND_ROW(3, prev[2])
-          }
-          if (wave_live && !(a.dbg & 1)) {
-            const bf16x8* st = s_stage + (g & 1) * SN;
-            __builtin_amdgcn_s_setprio(1);
-            chunk_mfma6<NR, SF, TR2>(acc, st, st + 3 * XN, wave, half, l31);
-            __builtin_amdgcn_s_setprio(0);
-          }
-        }
-        HAND_ROW(0, acc[0])
-#pragma unroll
-        for (int r = 0; r < 3; ++r) prev[r] = acc[r + 1];
-        ++ti;
-        k += (unsigned)nslots;
-        if (k >= nk) break;
-        TILE_COORDS(k)
-      }
-      // drain (the producers post-process one row per barrier round)
-      __syncthreads();
-      HAND_ROW(1, prev[0])
-      __syncthreads();
-      HAND_ROW(2, prev[1])
-      __syncthreads();
-      HAND_ROW(3, prev[2])
-      __syncthreads();
-      __syncthreads();                                         // final barrier
-    } else {
+    __syncthreads();                                           // barrier 0: chunk 0 has landed
     for (;;) {
       f32x16 acc[4];
-      const bool wave_live = (t0 + 32 * wave < T);             // this consumer's frames exist (ragged last tile)
+      const bool wave_live = (t0 + 32 * wave < T) && !(a.dbg & 1);   // this consumer's frames exist (ragged last tile)
+      {
+        const float* tb = s_tab + (ti % NS) * (3 * FT * COP);  // accumulators start at bias + folded shift
+        conv_acc_init_rows(acc, t0 + 32 * wave, T, lane, tb, tb + FT * COP, tb + 2 * FT * COP);
+      }
       for (int kc = 0; kc < nchunk; ++kc, ++g) {
-        __syncthreads();                                       // barrier g: stage g & 1 holds chunk g
-        if (kc == 0) {                                         // accumulators start at bias + folded shift (tables of this
-          const float* tb = s_tab + (ti & 1) * (3 * FT * COP); // tile: written by the producers before barrier g)
-          conv_acc_init_rows(acc, t0 + 32 * wave, T, lane, tb, tb + FT * COP, tb + 2 * FT * COP);
-        }
-        if (wave_live && !(a.dbg & 1)) {
-          const bf16x8* st = s_stage + (g & 1) * SN;
+        if (wave_live) {
+          const bf16x8* st = s_stage + (g % NS) * SN;
           __builtin_amdgcn_s_setprio(1);
           chunk_mfma6<NR, SF, TR2>(acc, st, st + 3 * XN, wave, half, l31);
           __builtin_amdgcn_s_setprio(0);
         }
+        STAMP(ti);
+        __syncthreads();                                       // barrier g + 1: done reading chunk g
+        STAMP(ti);
       }
       if (!(a.dbg & 4))
         conv_epilogue_rows_nb<3>(a, acc, n, cg, f0, t0 + 32 * wave, lane, s_red + (ti & 1) * (4 * COP * 2) + wave * (COP * 2), 4);
@@ -510,8 +369,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
       TILE_COORDS(k)
     }
     __syncthreads();                                           // final barrier
-    }
-#undef HAND_ROW
   }
 #undef STAMP
 #undef TILE_COORDS
@@ -597,19 +454,21 @@ __global__ __launch_bounds__(288) void conv_wprep6_k(const float* wf, const doub
 }
 
 static size_t x6_lds_bytes(int NR) {
-  // two stages + epilogue tables + statistics partials (+ the 2-slot accumulator mailbox, not for the stride-2 mode)
-  return (size_t)(2 * (3 * NR * X6_TW + X6_WU)) * 16 + (size_t)(2 * 3 * FT * 32 + 2 * 4 * 32 * 2) * sizeof(float) +
-         (NR == 9 ? 0 : (size_t)2 * 4 * 4 * 64 * 16);
+  const int ns = 2;                                  // two stages + epilogue tables + statistics partials
+  return (size_t)(ns * (3 * NR * X6_TW + X6_WU)) * 16 + (size_t)(ns * 3 * FT * 32 + 2 * 4 * 32 * 2) * sizeof(float);
+}
+
+template <int MODE>
+static hipError_t x6_set_attr() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6<MODE>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 hipError_t conv_bf16x6_init() {
   hipError_t e;
-  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6<0>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6<1>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6<2>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if ((e = x6_set_attr<0>()) != hipSuccess) return e;
+  if ((e = x6_set_attr<1>()) != hipSuccess) return e;
+  return x6_set_attr<2>();
 }
 
 long long conv_bf16x6_wps_bytes(int Cin, int Cout) {

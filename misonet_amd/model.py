@@ -101,6 +101,8 @@ class _Trunk:
         if mode not in self.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}")
         _lib.check(_lib.lib().misonet_net_set_precision(self._net, self.PRECISIONS[mode]))
+        if mode != self.precision:
+            self._ws.clear()           # the workspace layout (and size) depends on the arithmetic mode
         self.precision = mode
         return self
 

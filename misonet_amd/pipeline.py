@@ -116,12 +116,13 @@ class Enhancer:
         return x.to(torch.complex64).contiguous()
 
     def workspace(self, B, T):
-        ws = self._ws.get((B, T))
+        key = (B, T, self.model_sep.precision, self.model.precision)   # the layout depends on the arithmetic modes
+        ws = self._ws.get(key)
         if ws is None:
             self._ws.clear()
             n = _lib.lib().misonet_pipeline_workspace_bytes(self._pipe, B, T)
             ws = torch.empty(n, dtype=torch.uint8, device=self.device)
-            self._ws[(B, T)] = ws
+            self._ws[key] = ws
         return ws
 
     def enhance(self, mix: torch.Tensor, clean: Optional[torch.Tensor] = None, want_bf=False, want_miso1=False,
