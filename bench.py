@@ -44,13 +44,15 @@ PEAK_BF16_MFMA_TF = 2500.0      # dense bf16 matrix peak (spec)
 PEAK_HBM_TBS = 8.0
 ALGO_BYTES_PER_UTT = 6.23e9     # 8 forwards x 0.776 GB + 2 x 13.43 MB
 
-# arithmetic of the 3x3 convs: name -> (dominant kernel, bf16 MFMA products issued per algorithmic product, or 0 for
-# the f32 MFMA, fp32-faithful?)
+# arithmetic of the 3x3 convs: name -> (dominant kernel, 16-bit MFMA products issued per algorithmic product, or 0 for
+# the f32 MFMA, operands exact float32?, significant bits per operand)
 MODES = {
-    "f32":     ("conv3x3_mfma", 0, True),            # v_mfma_f32_32x32x2_f32: exact f32, bitwise an fmaf chain
-    "bf16x6":  ("conv3x3_bf16x6", 6, True),          # operands split EXACTLY into 3 bf16 pieces (24 bits), 6 leading terms
-    "bf16x3":  ("conv3x3_bf16x3_dma2", 3, False),    # 2 bf16 pieces (16 bits), 3 terms: inside 1e-3 but not fp32-faithful
-    "bf16x3p": ("conv3x3_bf16x3", 3, False),
+    "f32":     ("conv3x3_mfma", 0, True, 24),            # v_mfma_f32_32x32x2_f32: exact f32, bitwise an fmaf chain
+    "bf16x6":  ("conv3x3_bf16x6", 6, True, 24),          # operands split EXACTLY into 3 bf16 pieces, 6 leading terms
+    "f16x3":   ("conv3x3_bf16x3_dma2<F16>", 3, False, 22),   # 2 fp16 pieces (22 bits, "3xTF32"), 3 terms: measured at the
+                                                         # f32 mode's error level, but the operands are rounded
+    "bf16x3":  ("conv3x3_bf16x3_dma2", 3, False, 16),    # 2 bf16 pieces (16 bits), 3 terms: inside 1e-3, not fp32-faithful
+    "bf16x3p": ("conv3x3_bf16x3", 3, False, 16),
 }
 HEADLINE_PRECISION = "bf16x6"
 
@@ -138,7 +140,7 @@ def _traffic_entry(precision):
 
 def roofline_objects(precision, B, T, steps, dt_conv_ms, n_launch):
     """roofline of the dominant kernel (the 3x3 conv launches) for one precision mode."""
-    kernel, terms, _ = MODES[precision]
+    kernel, terms = MODES[precision][:2]
     fl1 = conv_flops_per_forward(2 * N_MIC, 2 * N_SPK, T)
     fl3 = conv_flops_per_forward(2 * (N_MIC + 2), 2, T)
     by1 = conv_bytes_per_forward(2 * N_MIC, 2 * N_SPK, T)
@@ -293,7 +295,7 @@ def main():
             roof["hbm_frac_pipeline"] = round(ALGO_BYTES_PER_UTT * (value / world) / (PEAK_HBM_TBS * 1e12), 4)
         alts = []
         if world == 1 and not args.no_alt:
-            for other in ("f32", "bf16x6", "bf16x3"):
+            for other in ("f32", "bf16x6", "f16x3", "bf16x3"):
                 if other == args.precision:
                     continue
                 try:
@@ -302,7 +304,8 @@ def main():
                 except ValueError:
                     continue
                 dt2, _, _ = run_steps(enh, mix, clean, out, args.steps, args.warmup, None, L, _lib, False)
-                a = {"dtype": other, "fp32_faithful": MODES[other][2], "value": round(B * args.steps / dt2, 3),
+                a = {"dtype": other, "fp32_faithful": MODES[other][2], "operand_bits": MODES[other][3],
+                     "value": round(B * args.steps / dt2, 3),
                      "unit": "utt/s", "steps": args.steps, "warmup": args.warmup}
                 if not args.no_profile:
                     k = max(1, min(args.steps, 3))
@@ -318,7 +321,8 @@ def main():
             "metric": "utterances/sec MISO1->MVDR->MISO3, 6-mic 16kHz 4s",
             "value": round(value, 3), "unit": "utt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.precision, "fp32_faithful": MODES[args.precision][2], "data": "synthetic",
+            "vs_baseline": None, "dtype": args.precision, "fp32_faithful": MODES[args.precision][2],
+            "operand_bits": MODES[args.precision][3], "data": "synthetic",
             "config": {"workload": "BASELINE configs[3]: synthetic 6-mic 16 kHz 4 s, full MISO1x6 -> align -> MVDRx2 -> MISO3x2",
                        "batch_per_gpu": B, "frames": T, "freq_bins": 129, "parallelism": f"utterance-shard x{world}"},
             "realtime_factor": round(value * (n / 16000.0), 2),

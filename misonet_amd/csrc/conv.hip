@@ -97,8 +97,8 @@ __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[NCO][4], const float* s
 // of chunk k and are normalised and written to LDS after it, so HBM/L2 latency hides under the matrix work.
 // Staging roles are division-free: thread (q = tid & 31, ci = tid >> 5) owns frames t0+4q..t0+4q+3 of channel ci
 // for every staged row; threads < 16*NR own the two halo frames t0-1 / t0+128 of one (row, channel).
-// OCTP = 3: the instantiations that write the bf16x6 oct layout (hi | mid | lo parts; the planar-input layers in front
-// of a dense block when the network runs in the bf16x6 mode).
+// OCTP = 3 / 4: the instantiations that write the bf16x6 (hi | mid | lo bf16 parts) / f16x3 (hi | lo fp16 parts) oct layout:
+// the planar-input layers in front of a dense block when the network runs in one of those modes.
 template <int NCO, int MODE, int OCTP = 0>
 __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0) ? 3 : 2)) void conv3x3_mfma(const ConvArgs a) {
   constexpr int COP = NCO * 32;
@@ -269,17 +269,24 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0) ? 3 : 2)
   }
 
   float* s_red = smem;   // [FT waves][COP][2]  (safe: the loop ends with a barrier after the last reads)
-  conv_epilogue<NCO, 4, OCTP>(a, acc, n, cg, f, t0, row_ok, lane, s_red + wave * (COP * 2));
+  conv_epilogue<NCO, 4, OCTP, true>(a, acc, n, cg, f, t0, row_ok, lane, s_red + wave * (COP * 2));
   if (a.act) {
     __syncthreads();
-    if (tid < COP * 2) {
-      const int co_l = tid >> 1, which = tid & 1;
+    if (tid < COP) {
+      // the tile's partials are moments about c = ELU(bias[co]) (conv_epilogue CENTRE): un-centre in float64
+      const int co_l = tid;
       const int co = cg * COP + co_l;
       if (co < a.Cout) {
-        float tot = 0.f;
+        float t1 = 0.f, t2 = 0.f;
+        int rows = 0;
         for (int w = 0; w < FT; ++w)
-          if (f0 + w < a.Fout) tot += s_red[(w * COP + co_l) * 2 + which];
-        unsafeAtomicAdd(a.out_stats + ((long long)n * a.out_sstride + a.out_c0 + co) * 2 + which, (double)tot);
+          if (f0 + w < a.Fout) { t1 += s_red[(w * COP + co_l) * 2]; t2 += s_red[(w * COP + co_l) * 2 + 1]; ++rows; }
+        const int frames = (T - t0) < TT ? (T - t0) : TT;
+        double sx, sxx;
+        stats_uncentre((double)t1, (double)t2, (double)elu_fast(a.bias[co]), (double)rows * (double)frames, sx, sxx);
+        double* o = a.out_stats + ((long long)n * a.out_sstride + a.out_c0 + co) * 2;
+        unsafeAtomicAdd(o, sx);
+        unsafeAtomicAdd(o + 1, sxx);
       }
     }
   }
@@ -310,7 +317,11 @@ hipError_t conv_init() {
   if ((e = set_lds_attr<1, 0, 3>()) != hipSuccess) return e;
   if ((e = set_lds_attr<1, 2, 3>()) != hipSuccess) return e;
   if ((e = set_lds_attr<2, 0, 3>()) != hipSuccess) return e;
-  return set_lds_attr<2, 2, 3>();
+  if ((e = set_lds_attr<2, 2, 3>()) != hipSuccess) return e;
+  if ((e = set_lds_attr<1, 0, 4>()) != hipSuccess) return e;
+  if ((e = set_lds_attr<1, 2, 4>()) != hipSuccess) return e;
+  if ((e = set_lds_attr<2, 0, 4>()) != hipSuccess) return e;
+  return set_lds_attr<2, 2, 4>();
 }
 
 int conv_xcd_env() {
@@ -327,11 +338,18 @@ hipError_t launch_conv(const ConvArgs& a_in, int n_samples, hipStream_t s) {
   if (a.NR != conv_rows(a.sf, a.tr2)) return hipErrorInvalidValue;
 #define MN_LAUNCH(NCO, MODE) hipLaunchKernelGGL((conv3x3_mfma<NCO, MODE>), grid, dim3(256), lds, s, a)
 #define MN_LAUNCH3(NCO, MODE) hipLaunchKernelGGL((conv3x3_mfma<NCO, MODE, 3>), grid, dim3(256), lds, s, a)
+#define MN_LAUNCH4(NCO, MODE) hipLaunchKernelGGL((conv3x3_mfma<NCO, MODE, 4>), grid, dim3(256), lds, s, a)
   if (a.out_oct) {
-    // planar float32 in, bf16x6 oct layout out: only the layer shapes that occur in front of a dense block
-    if (a.out_oct != 3 || mode == 1 || (a.Cout & 7) || (a.out_c0 & 7) || (a.out_sstride & 7)) return hipErrorInvalidValue;
-    if (a.cop == 32) { if (mode == 0) MN_LAUNCH3(1, 0); else MN_LAUNCH3(1, 2); }
-    else { if (mode == 0) MN_LAUNCH3(2, 0); else MN_LAUNCH3(2, 2); }
+    // planar float32 in, oct layout out (bf16x6: three bf16 pieces; f16x3: two fp16 pieces): only the layer shapes that
+    // occur in front of a dense block
+    if ((a.out_oct != 3 && a.out_oct != 4) || mode == 1 || (a.Cout & 7) || (a.out_c0 & 7) || (a.out_sstride & 7)) return hipErrorInvalidValue;
+    if (a.out_oct == 3) {
+      if (a.cop == 32) { if (mode == 0) MN_LAUNCH3(1, 0); else MN_LAUNCH3(1, 2); }
+      else { if (mode == 0) MN_LAUNCH3(2, 0); else MN_LAUNCH3(2, 2); }
+    } else {
+      if (a.cop == 32) { if (mode == 0) MN_LAUNCH4(1, 0); else MN_LAUNCH4(1, 2); }
+      else { if (mode == 0) MN_LAUNCH4(2, 0); else MN_LAUNCH4(2, 2); }
+    }
   } else if (a.cop == 32) {
     if (mode == 0) MN_LAUNCH(1, 0); else if (mode == 1) MN_LAUNCH(1, 1); else MN_LAUNCH(1, 2);
   } else {
@@ -339,6 +357,7 @@ hipError_t launch_conv(const ConvArgs& a_in, int n_samples, hipStream_t s) {
   }
 #undef MN_LAUNCH
 #undef MN_LAUNCH3
+#undef MN_LAUNCH4
   return hipGetLastError();
 }
 

@@ -50,10 +50,18 @@ __device__ __forceinline__ void chunk_load_a(bf16x8 (&ah)[9], bf16x8 (&al)[9], c
 
 struct NoIssue { __device__ __forceinline__ void operator()(int) const {} };
 
+// one 32x32x16 MFMA on 16-bit pieces: bf16 (bf16x3 mode) or fp16 (f16x3 mode); the LDS images are the same 16-byte units
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  if (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 // `issue(st)` is called once per step, between the step's operand reads and its MFMAs: the software-pipelined kernel
 // uses it to spread the LDS-DMA instructions of the NEXT chunk over the MFMA loop (a burst of 19 DMA instructions
 // costs a wave ~3k cycles of issue time; in the shadow of the matrix pipe it costs nothing).
-template <int NR, int SF, bool TR2, class Issue = NoIssue>
+template <int NR, int SF, bool TR2, bool F16 = false, class Issue = NoIssue>
 __device__ __forceinline__ void chunk_mfma_rows_a(f32x16 (&acc)[4], const bf16x8 (&ah)[9], const bf16x8 (&al)[9],
                                                   const bf16x8* s_xhi, const bf16x8* s_xlo, int wave, int half,
                                                   int l31, const Issue& issue = Issue()) {
@@ -82,9 +90,9 @@ __device__ __forceinline__ void chunk_mfma_rows_a(f32x16 (&acc)[4], const bf16x8
             const bool use = TR2 ? ((((fr + kf) & 1) == 0) && (((fr + kf) >> 1) == R)) : (SF * fr + kf == R);
             if (use) {
               const int tap = kt * 3 + kf;
-              if (term == 0) acc[fr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tap], bh[cur], acc[fr], 0, 0, 0);
-              else if (term == 1) acc[fr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tap], bl[cur], acc[fr], 0, 0, 0);
-              else acc[fr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tap], bh[cur], acc[fr], 0, 0, 0);
+              if (term == 0) acc[fr] = mfma16<F16>(al[tap], bh[cur], acc[fr]);
+              else if (term == 1) acc[fr] = mfma16<F16>(ah[tap], bl[cur], acc[fr]);
+              else acc[fr] = mfma16<F16>(ah[tap], bh[cur], acc[fr]);
             }
           }
         }
@@ -95,16 +103,16 @@ __device__ __forceinline__ void chunk_mfma_rows_a(f32x16 (&acc)[4], const bf16x8
   }
 }
 
-template <int NR, int SF, bool TR2>
+template <int NR, int SF, bool TR2, bool F16 = false>
 __device__ __forceinline__ void chunk_mfma_rows(f32x16 (&acc)[4], const bf16x8* s_xhi, const bf16x8* s_xlo,
                                                 const bf16x8* s_whi, const bf16x8* s_wlo, int wave, int half,
                                                 int l31) {
   bf16x8 ah[9], al[9];
   chunk_load_a(ah, al, s_whi, s_wlo, half, l31);
-  chunk_mfma_rows_a<NR, SF, TR2>(acc, ah, al, s_xhi, s_xlo, wave, half, l31);
+  chunk_mfma_rows_a<NR, SF, TR2, F16>(acc, ah, al, s_xhi, s_xlo, wave, half, l31);
 }
 
-template <int MODE>
+template <int MODE, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_dma(const ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (the LDS-DMA builtin has no host form)
   constexpr int COP = 32;
@@ -241,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_dma(const ConvArgs a) {
     STAMP();
     if (wave_live && !(a.dbg & 1)) {
       __builtin_amdgcn_s_setprio(1);
-      chunk_mfma_rows<NR, SF, TR2>(acc, s_xhi, s_xlo, s_whi, s_wlo, wave, half, l31);
+      chunk_mfma_rows<NR, SF, TR2, F16>(acc, s_xhi, s_xlo, s_whi, s_wlo, wave, half, l31);
       __builtin_amdgcn_s_setprio(0);
     }
     STAMP();
@@ -254,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_dma(const ConvArgs a) {
 
   // ---- epilogue (conv_epilogue.hpp) ----
   float* s_red = reinterpret_cast<float*>(smem_b);   // [4 waves][COP][2]
-  if (!(a.dbg & 4)) conv_epilogue_rows(a, acc, n, cg, f0, t0 + 32 * wave, lane, s_red + wave * (COP * 2), s_bs, s_bl, s_br);
+  if (!(a.dbg & 4)) conv_epilogue_rows<F16>(a, acc, n, cg, f0, t0 + 32 * wave, lane, s_red + wave * (COP * 2), s_bs, s_bl, s_br);
   STAMP();
   if (a.act) {
     __syncthreads();
@@ -295,7 +303,7 @@ __device__ __forceinline__ constexpr int mfma_last_r(int kf) {        // last st
 
 // `issue(st)` runs once per step behind the first MFMAs of the step: the deferred epilogue of the PREVIOUS tile is
 // spread over these slots, so its VALU work and stores execute in the shadow of the matrix pipe.
-template <int NR, int SF, bool TR2, class Issue = NoIssue>
+template <int NR, int SF, bool TR2, bool F16 = false, class Issue = NoIssue>
 __device__ __forceinline__ void chunk_mfma_rows_w(f32x16 (&acc)[4], const bf16x8* s_xhi, const bf16x8* s_xlo,
                                                   const bf16x8* s_whi, const bf16x8* s_wlo, int wave, int half,
                                                   int l31, const Issue& issue = Issue()) {
@@ -337,9 +345,9 @@ __device__ __forceinline__ void chunk_mfma_rows_w(f32x16 (&acc)[4], const bf16x8
 #pragma unroll
           for (int kf = 0; kf < 3; ++kf) {
             if (mfma_use<SF, TR2>(fr, kf, R)) {
-              if (term == 0) acc[fr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[kf], bh[cur], acc[fr], 0, 0, 0);
-              else if (term == 1) acc[fr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kf], bl[cur], acc[fr], 0, 0, 0);
-              else acc[fr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kf], bh[cur], acc[fr], 0, 0, 0);
+              if (term == 0) acc[fr] = mfma16<F16>(al[kf], bh[cur], acc[fr]);
+              else if (term == 1) acc[fr] = mfma16<F16>(ah[kf], bl[cur], acc[fr]);
+              else acc[fr] = mfma16<F16>(ah[kf], bh[cur], acc[fr]);
             }
           }
         }
@@ -363,7 +371,7 @@ __device__ __forceinline__ void chunk_mfma_rows_w(f32x16 (&acc)[4], const bf16x8
 //     of chunk g - 1 are done (stage (g+1)&1 free).  Behind it producers put chunk g + 1 in flight while consumers run
 //     the MFMAs of chunk g.  Chunks are numbered across tiles: the last chunk of a tile stages chunk 0 of the next one,
 //     so tile set-up and the first load latency hide behind the last MFMAs and the epilogue.
-template <int MODE>
+template <int MODE, bool F16 = false>
 __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, int nslots) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int COP = 32;
@@ -493,9 +501,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
       /* accumulator order: channel co = (i&3) + 8*(i>>2) + 4*h  ->  h = (co>>2)&1, i = (co&3) + 4*(co>>3) */    \
       const int slot_ = (rw * 2 + ((lane >> 2) & 1)) * 16 + (lane & 3) + 4 * (lane >> 3);                       \
       float* tb_ = s_tab + (TS) * (3 * FT * COP);                                                               \
-      tb_[slot_] = b3[0] + b3[1] + b3[2];                                                                       \
-      tb_[FT * COP + slot_] = b3[0];                                                                            \
-      tb_[2 * FT * COP + slot_] = b3[2];                                                                        \
+      const float wsc_ = F16 ? a.wscale : 1.f;   /* the accumulators START at these values: same scale as W' */     \
+      tb_[slot_] = (b3[0] + b3[1] + b3[2]) * wsc_;                                                              \
+      tb_[FT * COP + slot_] = b3[0] * wsc_;                                                                     \
+      tb_[2 * FT * COP + slot_] = b3[2] * wsc_;                                                                 \
     }                                                                                                           \
   }
 
@@ -576,6 +585,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
 #pragma unroll
       for (int i = 0; i < 8; ++i) { es.s1[i] = f32x2{0.f, 0.f}; es.s2[i] = f32x2{0.f, 0.f}; }
       es.okk0 = es.okk1 = false;
+      es.dsc = F16 ? a.descale : 1.f;
 #pragma unroll
       for (int i = 0; i < 2; ++i) { es.PH[i][0] = es.PH[i][1] = es.PL[i][0] = es.PL[i][1] = 0u; }
       __amdgpu_buffer_rsrc_t prs_h = make_rsrc_u(reinterpret_cast<unsigned long long>(a.out), 0u);
@@ -600,11 +610,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
           const bf16x8* st_ = s_stage + (g & 1) * SN;                                                           \
           auto hook = [&](int stp) {                                                                            \
             if ((ROW) >= 0)                                                                                     \
-              conv_epi_step<((ROW) >= 0 ? (ROW) : 0), 3 * NR>(stp, prev, es, prs_h, prs_l, OP16, lane); \
+              conv_epi_step<((ROW) >= 0 ? (ROW) : 0), 3 * NR, F16>(stp, prev, es, prs_h, prs_l, OP16, lane); \
           };                                                                                                    \
           if (wave_live && !(a.dbg & 1)) {                                                                      \
             __builtin_amdgcn_s_setprio(1);                                                                      \
-            chunk_mfma_rows_w<NR, SF, TR2>(acc, st_, st_ + XN, st_ + 2 * XN, st_ + 2 * XN + WN, wave, half, l31, hook); \
+            chunk_mfma_rows_w<NR, SF, TR2, F16>(acc, st_, st_ + XN, st_ + 2 * XN, st_ + 2 * XN + WN, wave, half, l31, hook); \
             __builtin_amdgcn_s_setprio(0);                                                                      \
           } else {                                                                                              \
             _Pragma("unroll") for (int stp = 0; stp < 3 * NR; ++stp) hook(stp);                                 \
@@ -633,11 +643,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
           prs_l = make_rsrc_u(pa + (unsigned long long)(a.out_sstride >> 3) * OP16, nrec);
           if (NDEF <= 2 && FTR > 2) {
 #pragma unroll
-            for (int stp = 0; stp < 3 * NR; ++stp) conv_epi_step<2, 3 * NR>(stp, acc, es, prs_h, prs_l, OP16, lane);
+            for (int stp = 0; stp < 3 * NR; ++stp) conv_epi_step<2, 3 * NR, F16>(stp, acc, es, prs_h, prs_l, OP16, lane);
           }
           if (NDEF <= 3 && FTR > 3) {
 #pragma unroll
-            for (int stp = 0; stp < 3 * NR; ++stp) conv_epi_step<3, 3 * NR>(stp, acc, es, prs_h, prs_l, OP16, lane);
+            for (int stp = 0; stp < 3 * NR; ++stp) conv_epi_step<3, 3 * NR, F16>(stp, acc, es, prs_h, prs_l, OP16, lane);
           }
 #pragma unroll
           for (int r4 = 0; r4 < NDEF; ++r4) prev[r4] = acc[r4];
@@ -651,9 +661,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
       {
         float* sred_prev = s_red + ((ti + 1) & 1) * (4 * COP * 2) + wave * (COP * 2);
 #pragma unroll
-        for (int stp = 0; stp < 3 * NR; ++stp) conv_epi_step<0, 3 * NR>(stp, prev, es, prs_h, prs_l, OP16, lane);
+        for (int stp = 0; stp < 3 * NR; ++stp) conv_epi_step<0, 3 * NR, F16>(stp, prev, es, prs_h, prs_l, OP16, lane);
 #pragma unroll
-        for (int stp = 0; stp < 3 * NR; ++stp) conv_epi_step<1, 3 * NR>(stp, prev, es, prs_h, prs_l, OP16, lane);
+        for (int stp = 0; stp < 3 * NR; ++stp) conv_epi_step<1, 3 * NR, F16>(stp, prev, es, prs_h, prs_l, OP16, lane);
         conv_epi_reduce(es, sred_prev, lane);
       }
 #undef RUN_CHUNK
@@ -681,13 +691,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
           if (wave_live && !(a.dbg & 1)) {
             const bf16x8* st = s_stage + (g & 1) * SN;
             __builtin_amdgcn_s_setprio(1);
-            chunk_mfma_rows_w<NR, SF, TR2>(acc, st, st + XN, st + 2 * XN, st + 2 * XN + WN, wave, half, l31);
+            chunk_mfma_rows_w<NR, SF, TR2, F16>(acc, st, st + XN, st + 2 * XN, st + 2 * XN + WN, wave, half, l31);
             __builtin_amdgcn_s_setprio(0);
           }
         }
         STAMP();
         if (!(a.dbg & 4))
-          conv_epilogue_rows_nb(a, acc, n, cg, f0, t0 + 32 * wave, lane, s_red + (ti & 1) * (4 * COP * 2) + wave * (COP * 2), FTR);
+          conv_epilogue_rows_nb<2, F16>(a, acc, n, cg, f0, t0 + 32 * wave, lane, s_red + (ti & 1) * (4 * COP * 2) + wave * (COP * 2), FTR);
         STAMP();
         if (stamp) a.dbg_buf[63] = si;
 #undef STAMP
@@ -710,10 +720,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
 //   btab : [n][ncg*32][9] float32                     = sum_ci wf[..ci..] * shift[n][ci]   (float64 accumulation)
 // One workgroup of 288 threads per (sample, group); thread p owns (tap, output channel) = (p / 32, p % 32) and walks the
 // input channels in a fixed order, so the table is deterministic.
+// F16 (f16x3 mode): the pieces are fp16 and carry the layer's power-of-two scale `wscale` (so that the lo pieces of small
+// weights stay in fp16's normal range); btab stays unscaled (the consumer scales the accumulator start values).
+template <bool F16>
 __global__ __launch_bounds__(288) void conv_wprep_k(const float* wf, const double* in_stats, int in_sstride, int in_c0,
                                                     int Cin, int ident_c, int Fin, int T, int nchunk, int ncg,
                                                     unsigned short* wps, long long wps_nstride_b, float* btab,
-                                                    long long btab_nstride) {
+                                                    long long btab_nstride, float wscale) {
   extern __shared__ float2 s_nrm[];                  // [nchunk*16] (scale, shift)
   const int n = blockIdx.x / ncg, cg = blockIdx.x - n * ncg;
   const int tid = threadIdx.x;
@@ -764,7 +777,7 @@ __global__ __launch_bounds__(288) void conv_wprep_k(const float* wf, const doubl
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const float2 m = s_nrm[kc * CKB + h * 8 + e];
-            ws[e] = wv[e] * m.x;
+            ws[e] = F16 ? wv[e] * m.x * wscale : wv[e] * m.x;
             bs = fmaf(wv[e], m.y, bs);
           }
           bsum += (double)bs;
@@ -772,7 +785,7 @@ __global__ __launch_bounds__(288) void conv_wprep_k(const float* wf, const doubl
 #pragma unroll
           for (int e2 = 0; e2 < 4; ++e2) {
             unsigned a_, b_;
-            split_pair_t(ws[2 * e2], ws[2 * e2 + 1], a_, b_);
+            split_pair_x<F16>(ws[2 * e2], ws[2 * e2 + 1], a_, b_);
             hi[e2] = a_; lo[e2] = b_;
           }
           u32x4_t* d = reinterpret_cast<u32x4_t*>(wdst + (long long)kc * (2 * 9 * 2 * 32 * 8));
@@ -793,31 +806,37 @@ static size_t dma_lds_bytes(int NR) {
   return (size_t)(2 * NR * 2 * TW + 2 * 9 * 2 * 32) * 16 + (size_t)(3 * FT * 32 + 32 * 9) * sizeof(float);
 }
 
-template <int MODE>
+template <int MODE, bool F16>
 static hipError_t dma_set_attr() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x3_dma<MODE>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x3_dma<MODE, F16>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x3_dma2<MODE, F16>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 hipError_t conv_bf16_dma_init() {
   hipError_t e;
-  if ((e = dma_set_attr<0>()) != hipSuccess) return e;
-  if ((e = dma_set_attr<1>()) != hipSuccess) return e;
-  if ((e = dma_set_attr<2>()) != hipSuccess) return e;
-  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x3_dma2<0>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x3_dma2<1>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x3_dma2<2>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if ((e = dma_set_attr<0, false>()) != hipSuccess) return e;
+  if ((e = dma_set_attr<1, false>()) != hipSuccess) return e;
+  if ((e = dma_set_attr<2, false>()) != hipSuccess) return e;
+  if ((e = dma_set_attr<0, true>()) != hipSuccess) return e;
+  if ((e = dma_set_attr<1, true>()) != hipSuccess) return e;
+  return dma_set_attr<2, true>();
 }
 
 hipError_t launch_conv_wprep(const ConvArgs& a, const float* wf, int n_samples, hipStream_t s) {
   const int nchunk = (a.Cin + CKB - 1) / CKB;
-  hipLaunchKernelGGL(conv_wprep_k, dim3(n_samples * a.ncg), dim3(288), (size_t)nchunk * CKB * sizeof(float2), s, wf,
-                     a.in_stats, a.in_sstride, a.in_c0, a.Cin, a.ident_c, a.Fin, a.T, nchunk, a.ncg,
-                     reinterpret_cast<unsigned short*>(const_cast<void*>(a.wps)), a.wps_nstride,
-                     const_cast<float*>(a.btab), a.btab_nstride);
+  if (a.in_oct == 4)
+    hipLaunchKernelGGL(conv_wprep_k<true>, dim3(n_samples * a.ncg), dim3(288), (size_t)nchunk * CKB * sizeof(float2), s, wf,
+                       a.in_stats, a.in_sstride, a.in_c0, a.Cin, a.ident_c, a.Fin, a.T, nchunk, a.ncg,
+                       reinterpret_cast<unsigned short*>(const_cast<void*>(a.wps)), a.wps_nstride,
+                       const_cast<float*>(a.btab), a.btab_nstride, a.wscale);
+  else
+    hipLaunchKernelGGL(conv_wprep_k<false>, dim3(n_samples * a.ncg), dim3(288), (size_t)nchunk * CKB * sizeof(float2), s, wf,
+                       a.in_stats, a.in_sstride, a.in_c0, a.Cin, a.ident_c, a.Fin, a.T, nchunk, a.ncg,
+                       reinterpret_cast<unsigned short*>(const_cast<void*>(a.wps)), a.wps_nstride,
+                       const_cast<float*>(a.btab), a.btab_nstride, 1.f);
   return hipGetLastError();
 }
 
@@ -825,6 +844,9 @@ hipError_t launch_conv_bf16_dma(const ConvArgs& a_in, int n_samples, hipStream_t
   ConvArgs a = a_in;
   if (!a.in_oct || !a.wps || a.cop != 32 || (a.Cin & 7) || (a.in_c0 & 7) || (a.in_sstride & 7)) return hipErrorInvalidValue;
   if (a.out_oct && ((a.Cout & 7) || (a.out_c0 & 7) || (a.out_sstride & 7))) return hipErrorInvalidValue;
+  if (a.in_oct != 1 && a.in_oct != 4) return hipErrorInvalidValue;
+  if (a.out_oct && a.out_oct != a.in_oct) return hipErrorInvalidValue;       // same piece format on both sides
+  const bool f16 = a.in_oct == 4;
   if (a.NR != conv_rows(a.sf, a.tr2)) return hipErrorInvalidValue;
   {
     static int dbg = -1;
@@ -871,12 +893,22 @@ hipError_t launch_conv_bf16_dma(const ConvArgs& a_in, int n_samples, hipStream_t
     if (nslots > nk_max) nslots = (int)nk_max;
     const dim3 pgrid((unsigned)(8 * nslots), 1, 1);
     const size_t lds2 = dma2_lds_bytes(mode == 1 ? 5 : a.NR);
-    if (mode == 0) hipLaunchKernelGGL((conv3x3_bf16x3_dma2<0>), pgrid, dim3(512), lds2, s, a, nslots);
-    else if (mode == 1) hipLaunchKernelGGL((conv3x3_bf16x3_dma2<1>), pgrid, dim3(512), lds2, s, a, nslots);
-    else hipLaunchKernelGGL((conv3x3_bf16x3_dma2<2>), pgrid, dim3(512), lds2, s, a, nslots);
-  } else if (mode == 0) hipLaunchKernelGGL((conv3x3_bf16x3_dma<0>), grid, dim3(256), lds, s, a);
-  else if (mode == 1) hipLaunchKernelGGL((conv3x3_bf16x3_dma<1>), grid, dim3(256), lds, s, a);
-  else hipLaunchKernelGGL((conv3x3_bf16x3_dma<2>), grid, dim3(256), lds, s, a);
+    if (f16) {
+      if (mode == 0) hipLaunchKernelGGL((conv3x3_bf16x3_dma2<0, true>), pgrid, dim3(512), lds2, s, a, nslots);
+      else if (mode == 1) hipLaunchKernelGGL((conv3x3_bf16x3_dma2<1, true>), pgrid, dim3(512), lds2, s, a, nslots);
+      else hipLaunchKernelGGL((conv3x3_bf16x3_dma2<2, true>), pgrid, dim3(512), lds2, s, a, nslots);
+    } else {
+      if (mode == 0) hipLaunchKernelGGL((conv3x3_bf16x3_dma2<0, false>), pgrid, dim3(512), lds2, s, a, nslots);
+      else if (mode == 1) hipLaunchKernelGGL((conv3x3_bf16x3_dma2<1, false>), pgrid, dim3(512), lds2, s, a, nslots);
+      else hipLaunchKernelGGL((conv3x3_bf16x3_dma2<2, false>), pgrid, dim3(512), lds2, s, a, nslots);
+    }
+  } else if (f16) {
+    if (mode == 0) hipLaunchKernelGGL((conv3x3_bf16x3_dma<0, true>), grid, dim3(256), lds, s, a);
+    else if (mode == 1) hipLaunchKernelGGL((conv3x3_bf16x3_dma<1, true>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((conv3x3_bf16x3_dma<2, true>), grid, dim3(256), lds, s, a);
+  } else if (mode == 0) hipLaunchKernelGGL((conv3x3_bf16x3_dma<0, false>), grid, dim3(256), lds, s, a);
+  else if (mode == 1) hipLaunchKernelGGL((conv3x3_bf16x3_dma<1, false>), grid, dim3(256), lds, s, a);
+  else hipLaunchKernelGGL((conv3x3_bf16x3_dma<2, false>), grid, dim3(256), lds, s, a);
   if (do_tl && tl_buf) {
     unsigned long long h[64];
     (void)hipStreamSynchronize(s);

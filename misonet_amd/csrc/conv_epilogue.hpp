@@ -103,6 +103,25 @@ __device__ __forceinline__ void split_pair_t(float x0, float x1, unsigned& hi, u
   lo = __builtin_bit_cast(unsigned, l);
 }
 
+// fp16 flavour (f16x3 mode): x = hi + lo + O(2^-22 |x|) for |x| in fp16's normal range (11-bit pieces; the MFMA keeps
+// fp16 subnormals, tools/micro/mfma_f16_denorm.hip, so smaller values degrade gracefully to an absolute 2^-25)
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair_h(float x0, float x1, unsigned& hi, unsigned& lo) {
+  f32x2_t x = {x0, x1};
+  const f16x2_t h = __builtin_convertvector(x, f16x2_t);
+  f32x2_t r;
+  r.x = x0 - (float)h.x;
+  r.y = x1 - (float)h.y;
+  const f16x2_t l = __builtin_convertvector(r, f16x2_t);
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+template <bool F16>
+__device__ __forceinline__ void split_pair_x(float x0, float x1, unsigned& hi, unsigned& lo) {
+  if (F16) split_pair_h(x0, x1, hi, lo);
+  else split_pair_t(x0, x1, hi, lo);
+}
+
 // two values -> three packed bf16 pairs with x = hi + mid + lo EXACTLY (bf16x6 mode): hi = rne(x), mid = rne(x - hi),
 // lo = x - hi - mid.  x - hi is exact in float32 and has at most 16 significant bits, x - hi - mid at most 8, so the
 // last conversion does not round (float32 has 24 significant bits = 3 x 8); bf16 has the exponent range of float32.
@@ -128,7 +147,7 @@ __device__ __forceinline__ void split3_pair_t(float x0, float x1, unsigned& hi, 
 // -> NP bf16 parts in the oct layout: part p of octet pair k is one 16-byte store per lane (lanes 0-31 store octet 2k,
 // lanes 32-63 octet 2k + 1, after a half-wave swap).  rs[p]: descriptor of part p; vo: byte offset of (row, frame) in
 // the plane of octet (group base + half); ok0 / ok1: this lane's octet of pair 0 / 1 exists and its frame is valid.
-template <int NP>
+template <int NP, bool F16 = false>
 __device__ __forceinline__ void store_oct_row(const float (&v)[16], const __amdgpu_buffer_rsrc_t (&rs)[3], unsigned vo,
                                               unsigned P16, bool ok0, bool ok1) {
   unsigned P[3][4][2];
@@ -138,8 +157,8 @@ __device__ __forceinline__ void store_oct_row(const float (&v)[16], const __amdg
       split3_pair_t(v[4 * o + 0], v[4 * o + 1], P[0][o][0], P[1][o][0], P[2][o][0]);
       split3_pair_t(v[4 * o + 2], v[4 * o + 3], P[0][o][1], P[1][o][1], P[2][o][1]);
     } else {
-      split_pair_t(v[4 * o + 0], v[4 * o + 1], P[0][o][0], P[1][o][0]);
-      split_pair_t(v[4 * o + 2], v[4 * o + 3], P[0][o][1], P[1][o][1]);
+      split_pair_x<F16>(v[4 * o + 0], v[4 * o + 1], P[0][o][0], P[1][o][0]);
+      split_pair_x<F16>(v[4 * o + 2], v[4 * o + 3], P[0][o][1], P[1][o][1]);
     }
   }
 #pragma unroll
@@ -170,14 +189,23 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_e(unsigned long long
                                            __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
 }
 
+// Tile partials of centred moments -> contribution to the global (sum x, sum x^2), in float64:
+//   sum x = t1 + cnt c ;  sum x^2 = t2 + 2 c t1 + cnt c^2     (t1 = sum (x - c), t2 = sum (x - c)^2 over cnt elements)
+__device__ __forceinline__ void stats_uncentre(double t1, double t2, double c, double cnt, double& sx, double& sxx) {
+  sx = t1 + cnt * c;
+  sxx = t2 + 2.0 * c * t1 + cnt * c * c;
+}
+
 // s_red: [COP][2] floats of THIS wave's row (the caller adds the rows of a tile).  COP = NCO * 32.
 // s_bias: optional LDS copy of this group's bias [COP].
 // s_b4:   optional LDS table [COP][4] = (bL, bC, bR, bL + bC + bR) of THIS wave's row: the bias plus the folded
 //         instance-norm shift of the DMA dataflow, split by time tap so that the first / last frame of the utterance
 //         (whose left / right taps fall into the zero padding) can drop their share.
 // OCTP:   0, or the number of bf16 parts of the oct-layout output path to compile: 2 (bf16x3: hi | lo) or 3 (bf16x6:
-//         hi | mid | lo); a.out_oct selects it at run time.
-template <int NCO, int NSEG, int OCTP, bool ACT>
+//         hi | mid | lo) or 4 (f16x3: fp16 hi | lo); a.out_oct selects it at run time.
+// CENTRE: accumulate the statistics of (x - c) with c = ELU(bias) of the channel (the exact mean of the pre-activation
+//         when the inputs are instance-normalised); the caller un-centres with stats_uncentre.
+template <int NCO, int NSEG, int OCTP, bool ACT, bool CENTRE = false>
 __device__ __forceinline__ void conv_epilogue_impl(const ConvArgs& a, f32x16_t (&acc)[NCO][NSEG], int n, int cg, int f,
                                                    int t0, bool row_ok, int lane, float* s_red,
                                                    const float* s_bias, const float* s_b4) {
@@ -196,7 +224,8 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvArgs& a, f32x16_t (
 
   if (OCTP && a.out_oct) {
     // ---- oct layout: per (octet, frame) one 16-byte unit in each of the OCTP parts ----
-    constexpr int NP = OCTP ? OCTP : 2;
+    constexpr int NP = OCTP == 3 ? 3 : 2;                                   // OCTP 2: bf16 hi|lo, 3: bf16 hi|mid|lo, 4: fp16 hi|lo
+    constexpr bool F16 = OCTP == 4;
     const unsigned P16 = (unsigned)a.Fout * (unsigned)Tp * 16u;             // bytes per octet plane
     const unsigned long long pa = reinterpret_cast<unsigned long long>(a.out) + (unsigned long long)n * a.out_bstride * 4ull +
                                   (unsigned long long)(a.out_c0 >> 3) * P16;
@@ -238,14 +267,15 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvArgs& a, f32x16_t (
           if (ACT) x = elu_fast(x);
           v[r] = x;
           const int kr = j * 32 + (r & 3) + 8 * (r >> 2);
-          const float vm = (unmasked || (tm[s] && (full_c || kr < cmax))) ? x : 0.f;
+          const float xd = (CENTRE && ACT) ? x - elu_fast(bs[r]) : x;
+          const float vm = (unmasked || (tm[s] && (full_c || kr < cmax))) ? xd : 0.f;
           s1[r] += vm;
           s2[r] = fmaf(vm, vm, s2[r]);
         }
         // this lane's octet (2k + half of group j) exists and its frame is inside the utterance
         const bool ok0 = !(a.dbg & 8) && (unmasked || (tm[s] && (cbase + j * 32 + (0 + half) * 8 < a.Cout)));
         const bool ok1 = !(a.dbg & 8) && (unmasked || (tm[s] && (cbase + j * 32 + (2 + half) * 8 < a.Cout)));
-        store_oct_row<NP>(v, rs, voff[s] + (unsigned)((cbase >> 3) + j * 4) * P16, P16, ok0, ok1);
+        store_oct_row<NP, F16>(v, rs, voff[s] + (unsigned)((cbase >> 3) + j * 4) * P16, P16, ok0, ok1);
       }
       if (ACT && !(a.dbg & 16)) {
         const float x1 = reduce16_halfwave(s1, lane);
@@ -299,14 +329,16 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvArgs& a, f32x16_t (
       const int kr = j * 32 + (r & 3) + 8 * (r >> 2);
       const unsigned coff = (unsigned)(cbase + kr) * P4;                      // uniform plane offset
       float a1 = 0.f, a2 = 0.f;
+      const float cr = (CENTRE && ACT) ? elu_fast(bs[r]) : 0.f;
       if (unmasked && !t_edge) {                                              // the common case: no masks at all
 #pragma unroll
         for (int s = 0; s < NSEG; ++s) {
           float v = acc[j][s][r] + bs[r];
           if (ACT) v = elu_fast(v);
           if (!(a.dbg & 8)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff[s] + coff, 0, 0);
-          a1 += v;
-          a2 = fmaf(v, v, a2);
+          const float vd = v - cr;
+          a1 += vd;
+          a2 = fmaf(vd, vd, a2);
         }
       } else {
         const bool cok = full_c || (kr < cmax);
@@ -317,7 +349,7 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvArgs& a, f32x16_t (
           if (t_edge) v -= (t == 0 ? bl[r] : 0.f) + (t == T - 1 ? br[r] : 0.f);
           if (ACT) v = elu_fast(v);
           if (!(a.dbg & 8)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff[s] + coff, 0, 0);
-          const float vm = (tm[s] && cok) ? v : 0.f;
+          const float vm = (tm[s] && cok) ? v - cr : 0.f;
           a1 += vm;
           a2 = fmaf(vm, vm, a2);
         }
@@ -340,12 +372,12 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvArgs& a, f32x16_t (
 
 // ACT (ELU + statistics) is a compile-time parameter of the implementation: a run-time test inside the unrolled element
 // loops turns into a branch per element and serialises the exp latency.
-template <int NCO, int NSEG = 4, int OCTP = 0>
+template <int NCO, int NSEG = 4, int OCTP = 0, bool CENTRE = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16_t (&acc)[NCO][NSEG], int n, int cg, int f,
                                               int t0, bool row_ok, int lane, float* s_red,
                                               const float* s_bias = nullptr, const float* s_b4 = nullptr) {
-  if (a.act) conv_epilogue_impl<NCO, NSEG, OCTP, true>(a, acc, n, cg, f, t0, row_ok, lane, s_red, s_bias, s_b4);
-  else conv_epilogue_impl<NCO, NSEG, OCTP, false>(a, acc, n, cg, f, t0, row_ok, lane, s_red, s_bias, s_b4);
+  if (a.act) conv_epilogue_impl<NCO, NSEG, OCTP, true, CENTRE>(a, acc, n, cg, f, t0, row_ok, lane, s_red, s_bias, s_b4);
+  else conv_epilogue_impl<NCO, NSEG, OCTP, false, CENTRE>(a, acc, n, cg, f, t0, row_ok, lane, s_red, s_bias, s_b4);
 }
 
 // Tile epilogue of the row-reuse mapping (conv_bf16_dma.hip): one wave owns 32 frames [tw, tw + 32) of FOUR output rows
@@ -358,7 +390,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16_t (&acc)
 // Channels >= Cout need no masking in the statistics: their weights and bias are zero-padded, so the value is
 // ELU(0) = 0 exactly.  Everything that depends only on the wave (tile edges) selects between a branch-free fast path
 // and a masked path; nothing is decided per element.
-template <bool MASKED, bool ACT>
+template <bool MASKED, bool ACT, bool F16 = false>
 __device__ __forceinline__ void conv_epilogue_rows_impl(const ConvArgs& a, f32x16_t (&acc)[4], int cg, int f0, int tw,
                                                         int lane, const float* s_bs, const float* s_bl,
                                                         const float* s_br, const __amdgpu_buffer_rsrc_t rs_h,
@@ -402,7 +434,7 @@ __device__ __forceinline__ void conv_epilogue_rows_impl(const ConvArgs& a, f32x1
     float v[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      float x = acc[r][i] + bs[i];
+      float x = (F16 ? acc[r][i] * a.descale : acc[r][i]) + bs[i];       // f16x3: the weights carry a power-of-two scale
       if (ACT) x = elu_fast(x);
       v[i] = x;
       const float vm = MASKED ? x * m : x;
@@ -411,29 +443,9 @@ __device__ __forceinline__ void conv_epilogue_rows_impl(const ConvArgs& a, f32x1
     }
     if (a.dbg & 8) continue;
     if (a.out_oct) {
-      unsigned H[4][2], L[4][2];
-#pragma unroll
-      for (int o = 0; o < 4; ++o) {
-        split_pair_t(v[4 * o + 0], v[4 * o + 1], H[o][0], L[o][0]);
-        split_pair_t(v[4 * o + 2], v[4 * o + 3], H[o][1], L[o][1]);
-      }
+      const __amdgpu_buffer_rsrc_t rs2[3] = {rs_h, rs_l, rs_l};
       const unsigned vo = (unsigned)(f * Tp + t) * 16u + (unsigned)half * P16 + (unsigned)(cbase >> 3) * P16;
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {                   // octet pair (2k, 2k+1): lanes 0-31 store 2k, lanes 32-63 store 2k+1
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-          auto rh = __builtin_amdgcn_permlane32_swap(H[2 * k][d], H[2 * k + 1][d], false, false);
-          H[2 * k][d] = rh[0]; H[2 * k + 1][d] = rh[1];
-          auto rl = __builtin_amdgcn_permlane32_swap(L[2 * k][d], L[2 * k + 1][d], false, false);
-          L[2 * k][d] = rl[0]; L[2 * k + 1][d] = rl[1];
-        }
-        const u32x4_t uh = {H[2 * k][0], H[2 * k][1], H[2 * k + 1][0], H[2 * k + 1][1]};
-        const u32x4_t ul = {L[2 * k][0], L[2 * k][1], L[2 * k + 1][0], L[2 * k + 1][1]};
-        if (ok && (k == 0 ? oct_ok0 : oct_ok1)) {
-          __builtin_amdgcn_raw_buffer_store_b128(uh, rs_h, vo + (unsigned)(2 * k) * P16, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(ul, rs_l, vo + (unsigned)(2 * k) * P16, 0, 0);
-        }
-      }
+      store_oct_row<2, F16>(v, rs2, vo, P16, ok && oct_ok0, ok && oct_ok1);
     } else {
       // planar: channel (i&3) + 8*(i>>2) + 4*half of the group; out-of-range channels fall outside num_records,
       // missing frames / rows get an out-of-range offset (4-byte stores: dropped by the hardware)
@@ -447,6 +459,7 @@ __device__ __forceinline__ void conv_epilogue_rows_impl(const ConvArgs& a, f32x1
   }
 }
 
+template <bool F16 = false>
 __device__ __forceinline__ void conv_epilogue_rows(const ConvArgs& a, f32x16_t (&acc)[4], int n, int cg, int f0, int tw,
                                                    int lane, float* s_red, const float* s_bs, const float* s_bl,
                                                    const float* s_br) {
@@ -483,10 +496,10 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvArgs& a, f32x16_t (
       reinterpret_cast<void*>(((unsigned long long)pb_hi << 32) | pb_lo), 0, nrec_s, 0x00020000);
 
   if (a.act) {
-    if (fast) conv_epilogue_rows_impl<false, true>(a, acc, cg, f0, tw, lane, s_bs, s_bl, s_br, rs_h, rs_l, s1, s2);
-    else conv_epilogue_rows_impl<true, true>(a, acc, cg, f0, tw, lane, s_bs, s_bl, s_br, rs_h, rs_l, s1, s2);
+    if (fast) conv_epilogue_rows_impl<false, true, F16>(a, acc, cg, f0, tw, lane, s_bs, s_bl, s_br, rs_h, rs_l, s1, s2);
+    else conv_epilogue_rows_impl<true, true, F16>(a, acc, cg, f0, tw, lane, s_bs, s_bl, s_br, rs_h, rs_l, s1, s2);
   } else {
-    conv_epilogue_rows_impl<true, false>(a, acc, cg, f0, tw, lane, s_bs, s_bl, s_br, rs_h, rs_l, s1, s2);
+    conv_epilogue_rows_impl<true, false, F16>(a, acc, cg, f0, tw, lane, s_bs, s_bl, s_br, rs_h, rs_l, s1, s2);
   }
 
   if (a.act && !(a.dbg & 16)) {
@@ -537,10 +550,15 @@ __device__ __forceinline__ void conv_acc_init_rows(f32x16_t (&acc)[4], int tw, i
   }
 }
 
-template <bool MASKED, bool ACT, int NP>
+// s_ctr (optional): 16 floats per half-wave in accumulator order, the CENTRE c of this tile's statistics per channel.
+// The partial sums are then of (x - c) and (x - c)^2; whoever adds the tile's partials to the global float64 moments
+// converts them back (stats_uncentre).  With c near the channel mean the float32 partials keep their accuracy when
+// |mean| >> std (one-pass E[x^2] - mean^2 from float32 partials otherwise loses mean^2 / var of it).
+template <bool MASKED, bool ACT, int NP, bool F16 = false>
 __device__ __forceinline__ void conv_epilogue_rows_nb_impl(const ConvArgs& a, f32x16_t (&acc)[4], int cg, int f0, int tw,
                                                            int lane, const __amdgpu_buffer_rsrc_t (&rs)[3],
-                                                           f32x2_e (&s1)[8], f32x2_e (&s2)[8], int rows) {
+                                                           f32x2_e (&s1)[8], f32x2_e (&s2)[8], int rows,
+                                                           const float* s_ctr = nullptr) {
   constexpr int COP = 32;
   const int half = lane >> 5, l31 = lane & 31;
   const int T = a.T, Tp = a.Tp;
@@ -552,6 +570,18 @@ __device__ __forceinline__ void conv_epilogue_rows_nb_impl(const ConvArgs& a, f3
   const bool oct_ok1 = cbase + (2 + half) * 8 < a.Cout;
   const f32x2_e kl2e = {1.4426950408889634f, 1.4426950408889634f};
   const f32x2_e kone = {1.f, 1.f};
+  f32x2_e ctr[8];
+#pragma unroll
+  for (int i2 = 0; i2 < 8; ++i2) ctr[i2] = f32x2_e{0.f, 0.f};
+  if (s_ctr) {
+    const float4* pc = reinterpret_cast<const float4*>(s_ctr + half * 16);
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const float4 q = pc[q4];
+      ctr[2 * q4] = f32x2_e{q.x, q.y};
+      ctr[2 * q4 + 1] = f32x2_e{q.z, q.w};
+    }
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int f = f0 + r;
@@ -562,6 +592,7 @@ __device__ __forceinline__ void conv_epilogue_rows_nb_impl(const ConvArgs& a, f3
 #pragma unroll
     for (int i2 = 0; i2 < 8; ++i2) {
       f32x2_e x = {acc[r][2 * i2], acc[r][2 * i2 + 1]};
+      if (F16) x = x * f32x2_e{a.descale, a.descale};      // f16x3: the weights carry a power-of-two scale
       if (ACT) {                                   // compile-time: a run-time test here becomes a branch per pair and
                                                    // serialises the exp latency of the eight pairs
         f32x2_e e = x * kl2e;
@@ -572,7 +603,8 @@ __device__ __forceinline__ void conv_epilogue_rows_nb_impl(const ConvArgs& a, f3
         x.y = x.y > 0.f ? x.y : e.y;
       }
       v[2 * i2] = x.x; v[2 * i2 + 1] = x.y;
-      const f32x2_e vm = MASKED ? x * m2 : x;
+      const f32x2_e xd = x - ctr[i2];
+      const f32x2_e vm = MASKED ? xd * m2 : xd;
       s1[i2] = s1[i2] + vm;
       s2[i2].x = fmaf(vm.x, vm.x, s2[i2].x);
       s2[i2].y = fmaf(vm.y, vm.y, s2[i2].y);
@@ -580,7 +612,7 @@ __device__ __forceinline__ void conv_epilogue_rows_nb_impl(const ConvArgs& a, f3
     if (a.dbg & 8) continue;
     if (a.out_oct) {
       const unsigned vo = (unsigned)(f * Tp + t) * 16u + (unsigned)half * P16 + (unsigned)(cbase >> 3) * P16;
-      store_oct_row<NP>(v, rs, vo, P16, ok && oct_ok0, ok && oct_ok1);
+      store_oct_row<NP, F16>(v, rs, vo, P16, ok && oct_ok0, ok && oct_ok1);
     } else {
       const unsigned vo = ok ? ((unsigned)(f * Tp + t) * 4u + (unsigned)(4 * half) * P4) : 0x80000000u;
 #pragma unroll
@@ -593,9 +625,9 @@ __device__ __forceinline__ void conv_epilogue_rows_nb_impl(const ConvArgs& a, f3
 }
 
 // rows: output rows of the tile (4, or 2 for the stride-2 layers of the bf16x3 kernel); NP: bf16 parts of an oct output
-template <int NP = 2>
+template <int NP = 2, bool F16 = false>
 __device__ __forceinline__ void conv_epilogue_rows_nb(const ConvArgs& a, f32x16_t (&acc)[4], int n, int cg, int f0, int tw,
-                                                      int lane, float* s_red, int rows = 4) {
+                                                      int lane, float* s_red, int rows = 4, const float* s_ctr = nullptr) {
   const int half = lane >> 5;
   const int T = a.T, Tp = a.Tp;
   const bool fast = (tw + 32 <= T) && (f0 + 4 <= a.Fout) && rows == 4;      // uniform: all 32 frames and 4 rows exist
@@ -621,10 +653,10 @@ __device__ __forceinline__ void conv_epilogue_rows_nb(const ConvArgs& a, f32x16_
   }
 
   if (a.act) {
-    if (fast) conv_epilogue_rows_nb_impl<false, true, NP>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows);
-    else conv_epilogue_rows_nb_impl<true, true, NP>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows);
+    if (fast) conv_epilogue_rows_nb_impl<false, true, NP, F16>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows, s_ctr);
+    else conv_epilogue_rows_nb_impl<true, true, NP, F16>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows, s_ctr);
   } else {
-    conv_epilogue_rows_nb_impl<true, false, NP>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows);
+    conv_epilogue_rows_nb_impl<true, false, NP, F16>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows);
   }
 
   if (a.act && !(a.dbg & 16)) {
@@ -659,9 +691,10 @@ struct EpiState {
   unsigned prow_b;          // bytes per output row (Tp * 16)
   unsigned PH[2][2], PL[2][2];
   bool okk0, okk1;          // this lane's octet of pair 0 / 1 exists (Cout)
+  float dsc;                // f16x3: 2^-k of the layer's weight scale (1 otherwise)
 };
 
-template <int ROW, int NSTEP>
+template <int ROW, int NSTEP, bool F16 = false>
 __device__ __forceinline__ void conv_epi_step(int st, f32x16_t (&prev)[4], EpiState& e, const __amdgpu_buffer_rsrc_t rs_h,
                                               const __amdgpu_buffer_rsrc_t rs_l, unsigned P16, int lane) {
   constexpr int NPIECE = 12;
@@ -673,6 +706,7 @@ __device__ __forceinline__ void conv_epi_step(int st, f32x16_t (&prev)[4], EpiSt
     const int q = st * PP + pi;
     if (q < 8) {
       f32x2_e x = {prev[ROW][2 * q], prev[ROW][2 * q + 1]};
+      if (F16) x = x * f32x2_e{e.dsc, e.dsc};
       f32x2_e ex = x * kl2e;
       ex.x = __builtin_amdgcn_exp2f(ex.x);
       ex.y = __builtin_amdgcn_exp2f(ex.y);
@@ -690,10 +724,10 @@ __device__ __forceinline__ void conv_epi_step(int st, f32x16_t (&prev)[4], EpiSt
       e.s2[q].y = fmaf(vm.y, vm.y, e.s2[q].y);
     } else if (q == 8 || q == 10) {
       const int b = (q == 8) ? 0 : 8;
-      split_pair_t(prev[ROW][b + 0], prev[ROW][b + 1], e.PH[0][0], e.PL[0][0]);
-      split_pair_t(prev[ROW][b + 2], prev[ROW][b + 3], e.PH[0][1], e.PL[0][1]);
-      split_pair_t(prev[ROW][b + 4], prev[ROW][b + 5], e.PH[1][0], e.PL[1][0]);
-      split_pair_t(prev[ROW][b + 6], prev[ROW][b + 7], e.PH[1][1], e.PL[1][1]);
+      split_pair_x<F16>(prev[ROW][b + 0], prev[ROW][b + 1], e.PH[0][0], e.PL[0][0]);
+      split_pair_x<F16>(prev[ROW][b + 2], prev[ROW][b + 3], e.PH[0][1], e.PL[0][1]);
+      split_pair_x<F16>(prev[ROW][b + 4], prev[ROW][b + 5], e.PH[1][0], e.PL[1][0]);
+      split_pair_x<F16>(prev[ROW][b + 6], prev[ROW][b + 7], e.PH[1][1], e.PL[1][1]);
     } else if (q == 9 || q == 11) {
       const int k = (q == 9) ? 0 : 1;
 #pragma unroll

@@ -47,7 +47,9 @@ struct ConvArgs {
   // "oct" activation layout of the bf16x3 DMA dataflow (conv_bf16_dma.hip): per sample [hi | lo] halves, each
   // [c/8][f][Tp][8] bf16 (8 channels of one frame = one 16-byte unit), values RAW (bias + ELU, no instance norm).
   int in_oct, out_oct;      // layout of the input / output buffer: 0 planar float32, 1 oct (bf16x3: hi | lo halves),
-                            // 3 oct3 (bf16x6, conv_bf16x6.hip: hi | mid | lo parts, 6 bytes per element)
+                            // 3 oct3 (bf16x6, conv_bf16x6.hip: hi | mid | lo parts, 6 bytes per element),
+                            // 4 oct with fp16 pieces (f16x3)
+  float wscale, descale;    // f16x3: power-of-two scale 2^k carried by the folded weights and its inverse (1, 1 otherwise)
   const void* wps;          // per-sample weights with the instance norm of the input folded in (conv_wprep), LDS image order
   long long wps_nstride;    // bytes between samples (0: one image shared by all samples)
   const float* btab;        // [n][ncg*32][9] border-aware shift table: sum_ci W[co][ci][tap] * shift[ci], or nullptr
@@ -99,7 +101,7 @@ hipError_t conv_init();                      // dynamic-LDS attributes
 hipError_t launch_conv_bf16(const ConvArgs& a, int n_samples, hipStream_t s);   // conv_bf16.hip (needs a.w16)
 hipError_t conv_bf16_init();
 hipError_t launch_conv_bf16_dma(const ConvArgs& a, int n_samples, hipStream_t s);   // conv_bf16_dma.hip (oct input)
-hipError_t launch_conv_wprep(const ConvArgs& a, const float* wf, int n_samples, hipStream_t s);
+hipError_t launch_conv_wprep(const ConvArgs& a, const float* wf, int n_samples, hipStream_t s);   // a.in_oct == 4: fp16 pieces
 hipError_t conv_bf16_dma_init();
 // bf16x6 (fp32-faithful) DMA dataflow, conv_bf16x6.hip: oct3 input, oct3 or planar output
 hipError_t launch_conv_bf16x6(const ConvArgs& a, int n_samples, hipStream_t s);

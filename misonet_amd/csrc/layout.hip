@@ -85,8 +85,8 @@ __global__ __launch_bounds__(256) void unpack_k(const float* src, int Cbuf, int 
   if (nan_flag && bad) atomicOr(nan_flag, 1);
 }
 
-// oct = 2 / 3: the source buffer is in the oct layout of the bf16x3 / bf16x6 DMA dataflow (kernels.hpp), value = the sum
-// of its bf16 parts (exact for three parts)
+// oct = 2 / 3 / 4: the source buffer is in the oct layout of the bf16x3 / bf16x6 / f16x3 DMA dataflow (kernels.hpp), value =
+// the sum of its pieces (exact for three bf16 parts)
 __global__ __launch_bounds__(256) void export_k(const float* src, long long src_bstride, int c0, int C, int Fq, int T,
                                                 int Tp, const double* stats, int sstride, int ident_c, float* dst,
                                                 int oct) {
@@ -113,8 +113,14 @@ __global__ __launch_bounds__(256) void export_k(const float* src, long long src_
     for (int f = fr; f < Fq; f += 8)
       if (tl < nt) {
         const long long e = (((long long)(ch >> 3) * Fq + f) * Tp + t0 + tl) * 8 + (ch & 7);
-        float v = __uint_as_float((unsigned)hb[e] << 16) + __uint_as_float((unsigned)hb[half_e + e] << 16);
-        if (oct == 3) v += __uint_as_float((unsigned)hb[2 * half_e + e] << 16);
+        float v;
+        if (oct == 4) {                                                       // fp16 pieces (f16x3)
+          const _Float16* hh = reinterpret_cast<const _Float16*>(hb);
+          v = (float)hh[e] + (float)hh[half_e + e];
+        } else {
+          v = __uint_as_float((unsigned)hb[e] << 16) + __uint_as_float((unsigned)hb[half_e + e] << 16);
+          if (oct == 3) v += __uint_as_float((unsigned)hb[2 * half_e + e] << 16);
+        }
         s_v[f][tl] = (v - mean) * rstd;
       }
   } else {

@@ -4,6 +4,8 @@
 #include "../../include/misonet.h"
 
 #include <math.h>
+#include <cmath>
+#include <algorithm>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -103,6 +105,7 @@ struct ConvL {
   long long w16_off = 0;            // offset (floats) of the bf16 hi/lo packed weights
   long long wf_off = 0;             // offset (floats) of the float32 weights in bf16-image order (conv_wprep_k source)
   long long wf6_off = 0;            // offset (floats) of the float32 weights [cg][chunk of 8][tap][32][8] (conv_wprep6_k source)
+  float wscale = 1.f;               // f16x3: power of two that brings max |W| of the layer to [32, 64)
 };
 
 struct TcnHalf { int dw, prelu, gamma, beta, pw; long long o_dw, o_prelu, o_gamma, o_beta, o_pw; };
@@ -132,7 +135,8 @@ struct misonet_net {
   std::vector<Tap> taps;
   float* w_dev = nullptr;
   bool committed = false;
-  int precision = 0;             // 0: exact f32 MFMA, 1: bf16x3 planar, 2: bf16x3 DMA dataflow, 3: bf16x6 DMA dataflow
+  int precision = 0;             // 0: exact f32 MFMA, 1: bf16x3 planar, 2: bf16x3 DMA dataflow, 3: bf16x6 DMA dataflow,
+                                 // 4: f16x3 DMA dataflow
 };
 
 static int find_tensor(const misonet_net* n, const std::string& name) {
@@ -293,9 +297,9 @@ static long long align_up(long long x, long long a) { return (x + a - 1) / a * a
 // in the oct layout (2 bf16 parts = the bytes of float32, or 3 parts = 6 bytes per element); the network input/output,
 // the F <= 3 bottleneck buffers and the TCN stay planar float32.  Returns the ConvArgs::in_oct / out_oct code.
 static inline int buf_oct(const misonet_net* n, int b) {
-  if (n->precision != 2 && n->precision != 3) return 0;
+  if (n->precision < 2) return 0;
   const bool o = (b >= B_E0 && b <= B_E4) || (b >= B_D2 && b <= B_D6) || (b >= B_X2 && b <= B_X6);
-  return o ? (n->precision == 3 ? 3 : 1) : 0;
+  return o ? (n->precision == 3 ? 3 : (n->precision == 4 ? 4 : 1)) : 0;
 }
 // floats per sample of buffer b (an oct3 buffer holds 1.5 floats per element; C is a multiple of 8 there)
 static inline long long bstride(const misonet_net* n, const Layout& L, int b) {
@@ -375,8 +379,10 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
   a.out_stats += (long long)n0 * a.out_sstride * 2;
   a.in_oct = buf_oct(n, c.in_buf);
   a.out_oct = buf_oct(n, c.out_buf);
-  // bf16x6: the planar-input layers (network input, F <= 3 bottleneck) run on the exact f32 kernel
-  if (n->precision == 3 && !a.in_oct) a.w16 = nullptr;
+  // bf16x6 / f16x3: the planar-input layers (network input, F <= 3 bottleneck) run on the exact f32 kernel
+  if (n->precision >= 3 && !a.in_oct) a.w16 = nullptr;
+  a.wscale = a.descale = 1.f;
+  if (a.in_oct == 4) { a.wscale = c.wscale; a.descale = 1.f / c.wscale; }
   if (a.w16 || a.in_oct) { a.cop = 32; a.ncg = (c.Cout + 31) / 32; }
   static int sync_dbg = -1;                 // MISONET_SYNC_DEBUG=1: name every conv launch and wait for it (fault hunting)
   if (sync_dbg < 0) { const char* e = getenv("MISONET_SYNC_DEBUG"); sync_dbg = e ? atoi(e) : 0; }
@@ -587,8 +593,15 @@ static inline float bf16_to_f32(unsigned short h) {
 }
 
 // bf16x3 path: [cg][chunk of 16 ci][hi|lo][tap][octet h][COP][8] bf16 (conv_bf16.hip)
-static void pack_conv_bf16(const misonet_net* n, const ConvL& c, std::vector<float>& arena) {
+static void pack_conv_bf16(const misonet_net* n, ConvL& c, std::vector<float>& arena) {
   const std::vector<float>& W = n->tensors[c.wt].host;
+  {
+    // f16x3: a static power of two per layer brings max |W| to [32, 64): with rstd in [2^-6, 2^9] the folded weights
+    // W * rstd stay below fp16's 65504 and the lo pieces of all but negligible weights stay normal
+    float m = 0.f;
+    for (float v : W) m = std::max(m, fabsf(v));
+    c.wscale = (m > 0.f && std::isfinite(m)) ? exp2f(floorf(log2f(64.f / m))) : 1.f;
+  }
   const int nchunk = (c.Cin + 15) / 16;
   const int COP = 32;                       // the bf16x3 kernels always work on 32-channel output groups
   const int ncg16 = (c.Cout + 31) / 32;
@@ -667,8 +680,8 @@ int misonet_net_commit(misonet_net* n) {
       tb.h[h].o_pw = take(128 * 128);
     }
   std::vector<float> arena((size_t)off, 0.f);
-  for (const ConvL& c : n->enc) { pack_conv(n, c, arena); pack_conv_bf16(n, c, arena); pack_conv_wf6(n, c, arena); }
-  for (const ConvL& c : n->dec) { pack_conv(n, c, arena); pack_conv_bf16(n, c, arena); pack_conv_wf6(n, c, arena); }
+  for (ConvL& c : n->enc) { pack_conv(n, c, arena); pack_conv_bf16(n, c, arena); pack_conv_wf6(n, c, arena); }
+  for (ConvL& c : n->dec) { pack_conv(n, c, arena); pack_conv_bf16(n, c, arena); pack_conv_wf6(n, c, arena); }
   for (const TcnBlock& tb : n->tcn)
     for (int h = 0; h < 2; ++h) {
       const TcnHalf& H = tb.h[h];
@@ -693,8 +706,8 @@ int misonet_net_commit(misonet_net* n) {
 
 int misonet_net_set_precision(misonet_net* n, int mode) {
   if (!n) return fail(MISONET_EINVAL, "null argument");
-  if (mode < 0 || mode > 3)
-    return fail(MISONET_EINVAL, "precision mode must be 0 (f32), 1 (bf16x3, planar), 2 (bf16x3, DMA dataflow) or 3 (bf16x6)");
+  if (mode < 0 || mode > 4)
+    return fail(MISONET_EINVAL, "precision mode must be 0 (f32), 1 (bf16x3, planar), 2 (bf16x3, DMA dataflow), 3 (bf16x6) or 4 (f16x3)");
   n->precision = mode;
   return MISONET_OK;
 }
@@ -757,7 +770,7 @@ int misonet_net_tap(misonet_net* n, const char* name, const void* ws, int B, int
       void* w = const_cast<void*>(ws);
       HIPCHK(launch_export(buf_ptr(L, w, t.buf), bstride(n, L, t.buf), t.c0, t.C, n->bufs[t.buf].F, T, L.Tp,
                            t.normalised ? stats_ptr(L, w, t.buf) : nullptr, n->bufs[t.buf].C, 0, dst, B,
-                           reinterpret_cast<hipStream_t>(stream), buf_oct(n, t.buf) == 3 ? 3 : (buf_oct(n, t.buf) ? 2 : 0)));
+                           reinterpret_cast<hipStream_t>(stream), buf_oct(n, t.buf) >= 3 ? buf_oct(n, t.buf) : (buf_oct(n, t.buf) ? 2 : 0)));
       return MISONET_OK;
     }
   return fail(MISONET_EINVAL, "unknown tap '%s'", name);

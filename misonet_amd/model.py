@@ -89,12 +89,14 @@ class _Trunk:
         self.training = False
         return self
 
-    PRECISIONS = {"f32": 0, "bf16x3p": 1, "bf16x3": 2, "bf16x6": 3}
+    PRECISIONS = {"f32": 0, "bf16x3p": 1, "bf16x3": 2, "bf16x6": 3, "f16x3": 4}
 
     def set_precision(self, mode: str):
         """Arithmetic of the 3x3 convolutions: "f32" (exact float32 matrix cores, default), "bf16x6" (fp32-faithful:
         both operands split EXACTLY into three bf16 pieces, the six leading partial products on the bf16 matrix cores
-        with f32 accumulation -- same accuracy class as "f32" at 2.67x its matrix rate, conv_bf16x6.hip), "bf16x3" (three-term bf16
+        with f32 accumulation -- same accuracy class as "f32" at 2.67x its matrix rate, conv_bf16x6.hip), "f16x3"
+        (operands rounded to two fp16 pieces = 22 bits, three terms, f32 accumulation: the "3xTF32" scheme; measured at the
+        f32 mode's error level, at the cost of "bf16x3"; activations must stay inside fp16's range), "bf16x3" (three-term bf16
         split on the bf16 matrix cores, f32 accumulation, ~1e-5 relative per layer; activations travel pre-split in the
         oct layout and are staged by LDS-DMA, conv_bf16_dma.hip) or "bf16x3p" (same arithmetic on planar float32
         activations with normalise-on-load staging, conv_bf16.hip)."""

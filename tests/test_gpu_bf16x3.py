@@ -1,5 +1,6 @@
 """GPU parity of the split-bf16 precision modes -- "bf16x6" (fp32-faithful: exact 3-way split, six terms,
-conv_bf16x6.hip), "bf16x3" / "bf16x3p" (2-way split, three terms, conv_bf16_dma.hip / conv_bf16.hip) -- against the same
+conv_bf16x6.hip), "f16x3" (two fp16 pieces, three terms), "bf16x3" / "bf16x3p" (two bf16 pieces, three terms; conv_bf16_dma.hip /
+conv_bf16.hip) -- against the same
 goldens / oracle and the same 1e-3 tolerance as the exact-f32 mode.  (Test names say bf16x3 for history; every test
 runs once per mode.)  tests/test_gpu_bf16x6.py holds bf16x6 to the f32 mode's own error level on top of this."""
 import numpy as np
@@ -14,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 # "bf16x3": oct-layout activations, instance norm folded into per-sample weights, LDS-DMA staging (conv_bf16_dma.hip);
 # "bf16x3p": planar float32 activations, normalise-on-load staging (conv_bf16.hip)
-@pytest.fixture(scope="module", params=["bf16x6", "bf16x3", "bf16x3p"])
+@pytest.fixture(scope="module", params=["bf16x6", "f16x3", "bf16x3", "bf16x3p"])
 def nets_bf(request, sd1, sd3):
     _need_gpu()
     PREC = request.param

@@ -20,7 +20,7 @@ def pair(sd1, sd3):
     import misonet_amd as mz
     from misonet_amd import weights as W
     nets = {}
-    for mode in ("f32", "bf16x6"):
+    for mode in ("f32", "bf16x6", "f16x3"):
         m1 = mz.MISO_1(2, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN").cuda(0)
         m1.load_state_dict(sd1)
         m3 = mz.MISO_3(1, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN").cuda(0)
@@ -121,3 +121,27 @@ def test_bf16x6_batch_invariance(pair):
     yb = m1(xb).cpu().numpy()
     assert rel_l2(yb[8], y1[0]) < 1e-6
     assert rel_l2(yb[0], y1[0]) < 1e-6
+
+
+def test_f16x3_is_at_the_f32_error_level(pair, sd1):
+    """"f16x3" rounds the operands to two fp16 pieces (22 bits, the "3xTF32" scheme) -- so it is NOT labelled fp32-faithful
+    -- but its error against the oracle sits at the f32 mode's own level: operand rounding at 2^-22 is below the noise of
+    float32 accumulation over K = 216 ... 1728 terms.  Measured here for every stage of a forward, ragged shapes and the
+    full-size forward, next to f32 and bf16x6."""
+    from oracle import miso_oracle
+    m32, m6, mh = pair["f32"][0], pair["bf16x6"][0], pair["f16x3"][0]
+    cases = [("T=32 golden", torch.from_numpy(golden("g1_miso1_T32.npz")["x"]), golden("g1_miso1_T32.npz")["y"])]
+    r = np.random.default_rng(1603)
+    for B, T in ((2, 130), (1, 257)):
+        x = (r.standard_normal((B, 6, T, 129)) + 1j * r.standard_normal((B, 6, T, 129))).astype(np.complex64)
+        ref = np.concatenate([miso_oracle.miso1_forward(torch.from_numpy(x[b:b + 1]), sd1).numpy() for b in range(B)])
+        cases.append((f"B={B} T={T}", torch.from_numpy(x), ref))
+    mx, _ = _utt_inputs(1, 1001)
+    cases.append(("T=1001", torch.from_numpy(mx[None]), miso_oracle.miso1_forward(torch.from_numpy(mx[None]), sd1).numpy()))
+    for what, x, ref in cases:
+        xd = x.cuda()
+        e32 = mag_parity(m32(xd).cpu().numpy(), ref)[0]
+        e6 = mag_parity(m6(xd).cpu().numpy(), ref)[0]
+        eh = mag_parity(mh(xd).cpu().numpy(), ref)[0]
+        print(f"[f16x3] {what}: vs oracle  f32 {e32:.3e}  bf16x6 {e6:.3e}  f16x3 {eh:.3e}")
+        assert np.isfinite(eh) and eh <= 2.0 * e32 + 2e-6, what
