@@ -162,17 +162,22 @@ def roofline_objects(precision, B, T, steps, dt_conv_ms, n_launch):
               # engine clock seen in the PMC pass (the peaks below are the guide's 2.4 GHz figures; under the bf16 MFMA
               # load the part is power-limited)
               "clock_ghz_observed_pmc": tj.get("clock_ghz_observed") if tj else None}
-    mfma_peak = PEAK_BF16_MFMA_TF if terms else PEAK_F32_MFMA_TF
+    # peak of the arithmetic: the guide's dense MFMA peak of the instruction the mode issues, divided by the number of
+    # MFMA products the mode spends per algorithmic product (1 for the f32 MFMA; 6 / 3 for the split modes on the
+    # 2.5 PF bf16 / fp16 MFMA) -- i.e. the rate the mode would reach with the matrix pipe 100 % busy on useful work
+    raw_peak = PEAK_BF16_MFMA_TF if terms else PEAK_F32_MFMA_TF
+    mfma_peak = round(raw_peak / terms, 1) if terms else raw_peak
     r_mfma = dict(common, bound="mfma", achieved=round(ach_tf, 3), peak=mfma_peak, unit="TFLOP/s",
                   frac=round(ach_tf / mfma_peak, 4))
     if terms:
-        r_mfma["bf16_products_per_product"] = terms
+        r_mfma["peak_basis"] = f"{raw_peak:.0f} TF/s dense 16-bit MFMA peak / {terms} MFMA products per algorithmic product"
+        r_mfma["mfma_products_per_product"] = terms
         r_mfma["issued_tflops"] = round(terms * ach_tf, 1)
-        r_mfma["frac_issued"] = round(terms * ach_tf / mfma_peak, 4)
+        r_mfma["frac_of_raw_16bit_peak"] = round(ach_tf / raw_peak, 4)
     r_hbm = dict(common, bound="hbm", achieved=round(ach_tb * 1e3, 1), peak=PEAK_HBM_TBS * 1e3, unit="GB/s",
                  frac=round(ach_tb / PEAK_HBM_TBS, 4))
     # binding roofline: arithmetic intensity of the layer vs the ridge of the mode's effective matrix peak
-    eff_peak = mfma_peak / terms if terms else mfma_peak
+    eff_peak = mfma_peak
     ai = flops_step / bytes_step
     binding = r_mfma if ai >= eff_peak * 1e12 / (PEAK_HBM_TBS * 1e12) else r_hbm
     return binding, (r_hbm if binding is r_mfma else r_mfma)
