@@ -198,6 +198,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
     const unsigned long long part_b = (unsigned long long)(a.in_sstride >> 3) * P16;   // bytes between the parts
     const unsigned wbytes = (unsigned)nchunk * (unsigned)X6_WU * 16u;        // one (sample, group) weight image set
     const unsigned wo = (unsigned)(tid & 255) * 16u;
+    const int btab_parts = nchunk >= 8 ? 4 : (nchunk >= 4 ? 2 : 1);          // conv_bf16x6_btab_parts
     __amdgpu_buffer_rsrc_t rs_x0, rs_x1, rs_x2, rs_w;
     unsigned xo[NXI];
 
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
       float b3[3] = {0.f, 0.f, 0.f};                                                                            \
       if (a.btab) {                                                                                             \
         const float* bt_ = a.btab + (long long)n * a.btab_nstride + (long long)(cg * COP + lane) * 9;           \
+        const long long pst_ = (long long)a.ncg * COP * 9;          /* floats between the shares of the table */  \
         _Pragma("unroll") for (int kf = 0; kf < 3; ++kf) {                                                      \
           bool ok_;                                                                                             \
           if (TR2) {                                                                                            \
@@ -265,7 +267,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
             ok_ = fi_ >= 0 && fi_ < Fin;                                                                        \
           }                                                                                                     \
           _Pragma("unroll") for (int kt = 0; kt < 3; ++kt) {                                                    \
-            const float v_ = bt_[kt * 3 + kf];                                                                  \
+            float v_ = bt_[kt * 3 + kf];                                                                        \
+            for (int p_ = 1; p_ < btab_parts; ++p_) v_ += bt_[p_ * pst_ + kt * 3 + kf];                          \
             b3[kt] += ok_ ? v_ : 0.f;                                                                           \
           }                                                                                                     \
         }                                                                                                       \
@@ -398,16 +401,22 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
 //   wf   : [ncg][nchunk][9 taps][32 co][8 ci] float32 (zero padded), shared by all samples; tap = kt * 3 + kf
 //   wps  : [n][ncg][nchunk][X6_WU] 16-byte units: unit ((kf*3 + p)*2 + kt)*32 + co for kt < 2, X6_WPAIR + (kf*3 + p)*32 + co
 //          for kt = 2, each = the 8 channels of the chunk of part p of  wf * rstd[n][ci]
-//   btab : [n][ncg*32][9] float32 = sum_ci wf[..ci..] * (-mean * rstd)[n][ci]   (float64 accumulation, fixed order)
+//   btab : [n][nparts][ncg*32][9] float32, share p = sum over the chunks of part p of wf[..ci..] * (-mean * rstd)[n][ci]
+//          (float64 accumulation, fixed order)
 // One workgroup of 288 threads per (sample, group); thread = (tap, output channel).
 __global__ __launch_bounds__(288) void conv_wprep6_k(const float* wf, const double* in_stats, int in_sstride, int in_c0,
                                                      int Cin, int ident_c, int Fin, int T, int nchunk, int ncg,
                                                      u32x4_t* wps, long long wps_nstride_b, float* btab,
-                                                     long long btab_nstride) {
+                                                     long long btab_nstride, int nparts) {
   extern __shared__ float2 s_nrm[];                  // [nchunk*8] (scale, shift)
   const int n = blockIdx.x / ncg, cg = blockIdx.x - n * ncg;
   const int tid = threadIdx.x;
-  for (int c = tid; c < nchunk * 8; c += 288) {
+  // blockIdx.y = part: this workgroup folds the chunks [kc_lo, kc_hi) and writes ITS share of the shift table; the conv
+  // kernel adds the nparts shares in a fixed order (the launch is latency-bound: 4 x the workgroups, 1/4 of the loop)
+  const int per_part = (nchunk + nparts - 1) / nparts;
+  const int kc_lo = blockIdx.y * per_part;
+  const int kc_hi = (kc_lo + per_part) < nchunk ? (kc_lo + per_part) : nchunk;
+  for (int c = kc_lo * 8 + tid; c < kc_hi * 8; c += 288) {
     float mean = 0.f, rstd = (c < Cin) ? 1.f : 0.f;
     if (c >= ident_c && c < Cin) {
       const double* st = in_stats + ((long long)n * in_sstride + in_c0 + c) * 2;
@@ -430,11 +439,11 @@ __global__ __launch_bounds__(288) void conv_wprep6_k(const float* wf, const doub
   const int ustep = kt < 2 ? 2 * 32 : 32;            // units between the parts
   double bsum = 0.0;
   constexpr int U = 4;                               // chunks per batch: the loads of a batch are issued together
-  for (int kc0 = 0; kc0 < nchunk; kc0 += U) {
+  for (int kc0 = kc_lo; kc0 < kc_hi; kc0 += U) {
     float4 wl[U][2];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int kc = (kc0 + u < nchunk) ? kc0 + u : nchunk - 1;
+      const int kc = (kc0 + u < kc_hi) ? kc0 + u : kc_hi - 1;
       const float4* src = reinterpret_cast<const float4*>(wsrc + (long long)kc * (9 * 32 * 8));
       wl[u][0] = src[0];
       wl[u][1] = src[1];
@@ -442,7 +451,7 @@ __global__ __launch_bounds__(288) void conv_wprep6_k(const float* wf, const doub
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int kc = kc0 + u;
-      if (kc < nchunk) {
+      if (kc < kc_hi) {
         const float4 w0 = wl[u][0], w1 = wl[u][1];
         const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
         float ws[8];
@@ -468,7 +477,7 @@ __global__ __launch_bounds__(288) void conv_wprep6_k(const float* wf, const doub
       }
     }
   }
-  btab[(long long)n * btab_nstride + (long long)(cg * 32 + co) * 9 + tap] = (float)bsum;
+  btab[(long long)n * btab_nstride + ((long long)blockIdx.y * ncg * 32 + cg * 32 + co) * 9 + tap] = (float)bsum;
 }
 
 static size_t x6_lds_bytes(int NR) {
@@ -493,12 +502,18 @@ long long conv_bf16x6_wps_bytes(int Cin, int Cout) {
   return (long long)((Cout + 31) / 32) * (Cin / 8) * X6_WU * 16;
 }
 
+int conv_bf16x6_btab_parts(int Cin) {                // shares of the shift table (= workgroups per (sample, group))
+  const int nchunk = Cin >> 3;
+  return nchunk >= 8 ? 4 : (nchunk >= 4 ? 2 : 1);
+}
+
 hipError_t launch_conv_wprep6(const ConvArgs& a, const float* wf, int n_samples, hipStream_t s) {
   const int nchunk = a.Cin >> 3;
-  hipLaunchKernelGGL(conv_wprep6_k, dim3(n_samples * a.ncg), dim3(288), (size_t)nchunk * 8 * sizeof(float2), s, wf,
+  const int nparts = conv_bf16x6_btab_parts(a.Cin);
+  hipLaunchKernelGGL(conv_wprep6_k, dim3(n_samples * a.ncg, nparts), dim3(288), (size_t)nchunk * 8 * sizeof(float2), s, wf,
                      a.in_stats, a.in_sstride, a.in_c0, a.Cin, a.ident_c, a.Fin, a.T, nchunk, a.ncg,
                      reinterpret_cast<u32x4_t*>(const_cast<void*>(a.wps)), a.wps_nstride, const_cast<float*>(a.btab),
-                     a.btab_nstride);
+                     a.btab_nstride, nparts);
   return hipGetLastError();
 }
 

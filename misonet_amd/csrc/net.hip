@@ -338,7 +338,7 @@ static Layout make_layout(const misonet_net* n, int N, int T) {
   L.wps_base = align_up(L.data_base + d * 4, 256);
   L.wps_nstride = wmax;
   L.btab_base = align_up(L.wps_base + wmax * N, 256);
-  L.btab_nstride = cmax * 9;
+  L.btab_nstride = cmax * 9 * 4;                    // up to 4 shares of the shift table (conv_wprep6_k)
   L.total_bytes = L.btab_base + L.btab_nstride * 4 * N;
   return L;
 }
