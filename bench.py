@@ -321,7 +321,9 @@ def main():
             m3.set_precision(args.precision)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(sd1, sd3, T)
+            enh.enhance(mix, clean, check_nan=False, out=out)            # the headline mode's result for the checker
+            torch.cuda.synchronize()
+            cpu = cpu_baseline(sd1, sd3, T, out[:4].cpu().numpy())
         line = {
             "metric": "utterances/sec MISO1->MVDR->MISO3, 6-mic 16kHz 4s",
             "value": round(value, 3), "unit": "utt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -332,6 +334,7 @@ def main():
                        "batch_per_gpu": B, "frames": T, "freq_bins": 129, "parallelism": f"utterance-shard x{world}"},
             "realtime_factor": round(value * (n / 16000.0), 2),
             "rccl_ranks": rccl_ranks, "per_rank_utt_per_s": [round(v, 3) for v in per_rank],
+            "parity": (cpu or {}).pop("parity_of_headline", None) if cpu else None,
             "roofline": roof, "roofline_other": roof2, "alt_precision": alts, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
@@ -360,7 +363,7 @@ def _physical_cores():
     return os.cpu_count() or 1
 
 
-def cpu_baseline(sd1, sd3, T):
+def cpu_baseline(sd1, sd3, T, gpu_out=None):
     """The oracle (kind "port": our stock-torch-CPU/NumPy restatement of the reference path, B = 1 per call as in
     tester.py:846-975) on this host's cores.  Bounded sample: one forward warm-up, one
     utterance at each of a ladder of thread counts (8 ... physical cores), then 3 different utterances end to end at
@@ -379,11 +382,15 @@ def cpu_baseline(sd1, sd3, T):
         clean = np.stack([pipeline_oracle.stft_chunk(s0)[0], pipeline_oracle.stft_chunk(s1)[0]])
         return mix, clean
 
+    ref_out = {}                                     # utterance -> the oracle's enhanced spectrograms (the checker)
+
     def timed(u, stages=None):
         mix, clean = utt(u)
         t0 = time.perf_counter()
-        pipeline_oracle.enhance_utterance(mix, clean, sd1, sd3, ref_ch=0, timings=stages)
-        return time.perf_counter() - t0
+        r = pipeline_oracle.enhance_utterance(mix, clean, sd1, sd3, ref_ch=0, timings=stages)
+        dt = time.perf_counter() - t0
+        ref_out[u] = r["out"]
+        return dt
 
     # B = 1 convolutions do not scale to a whole 2-socket host (128 threads were 5x SLOWER than 8 on the EPYC 9575F box):
     # probe a ladder of thread counts on one utterance each and quote the best one, stating every probe
@@ -408,7 +415,18 @@ def cpu_baseline(sd1, sd3, T):
             break
     med = float(np.median(times))
     stage_med = {k: round(float(np.median([s[k] for s in stages if k in s])), 3) for k in stages[0]}
-    return {"value": round(1.0 / med, 4), "unit": "utt/s", "cores": best, "kind": "port",
+    parity = None
+    if gpu_out is not None:
+        # the utterances the oracle just processed are utterances 0..3 of the GPU batch: the oracle as the CHECKER of the
+        # number on this line (rel-L2 of the complex-spectrogram magnitudes, the north_star's parity metric)
+        errs = {}
+        for u, ref in ref_out.items():
+            if u < gpu_out.shape[0]:
+                g = np.abs(gpu_out[u])
+                errs[str(u)] = float(np.linalg.norm(g - np.abs(ref)) / np.linalg.norm(np.abs(ref)))
+        parity = {"rel_l2_magnitudes_vs_oracle_by_utterance": {k: float(f"{v:.3e}") for k, v in errs.items()},
+                  "worst": float(f"{max(errs.values()):.3e}") if errs else None, "tolerance": 1e-3}
+    return {"parity_of_headline": parity, "value": round(1.0 / med, 4), "unit": "utt/s", "cores": best, "kind": "port",
             "host_logical_cpus": logical, "host_physical_cores": physical, "usable_cpus": usable,
             "utt_per_s_by_threads": {str(c): round(1.0 / t, 4) for c, t in probes.items()},
             "stage_seconds_median": stage_med,

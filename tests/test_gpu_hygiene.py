@@ -107,3 +107,26 @@ def test_device_handling(sd1, sd3):
     with pytest.raises(RuntimeError):
         enh.separate(x.cpu())
     assert y0.shape == (1, 2, 8, 129)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x6", "f16x3", "bf16x3"])
+def test_non_default_geometry(mode):
+    """A geometry other than config/NN_BSS.yml's: 4 microphones, 3 speakers, bottleneck channels
+    (16,24,40,32,48,64,128) -- output groups of 16/24/40/48 channels, 2-chunk layers, a dense block that grows to 200
+    channels -- against the oracle (which derives every shape from the state_dict).  The constructor arguments are the
+    reference's (model.py:9); en/de lists must mirror each other (model.py:35,99)."""
+    _need_gpu()
+    import misonet_amd as mz
+    from misonet_amd import weights as W
+    from oracle import miso_oracle
+    en, de = (16, 24, 40, 32, 48, 64, 128), (128, 64, 48, 32, 40, 24, 16)
+    sd = W.make_state_dict(W.tensor_spec(8, 6, en, de), seed=5)
+    m = mz.MISO_1(3, 4, 7, list(en), list(de), "IN").cuda(0)
+    m.load_state_dict(sd)
+    m.eval().set_precision(mode)
+    r = np.random.default_rng(41)
+    x = (r.standard_normal((2, 4, 70, 129)) + 1j * r.standard_normal((2, 4, 70, 129))).astype(np.complex64)
+    y = m(torch.from_numpy(x).cuda()).cpu().numpy()
+    ref = np.concatenate([miso_oracle.miso1_forward(torch.from_numpy(x[b:b + 1]), sd).numpy() for b in range(2)])
+    assert y.shape == (2, 3, 70, 129)
+    _assert_parity(y, ref, f"[{mode}] non-default geometry (4 mics, 3 speakers, en={en})")
