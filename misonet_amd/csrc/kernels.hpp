@@ -112,7 +112,8 @@ long long conv_bf16x6_wps_bytes(int Cin, int Cout);   // per-sample folded-weigh
 // ---- TCN (reference model.py:486-632) -----------------------------------------------------------------------------
 // x0 = IN2d(raw) materialised as the residual stream + its per-(n,c) statistics
 hipError_t launch_tcn_prepare(const float* raw, long long raw_bstride, int raw_c0, const double* raw_stats, int raw_sstride,
-                              float* x, double* x_stats, int C, int T, int Tp, int n_samples, hipStream_t s);
+                              float* x, double* x_stats, int C, int T, int Tp, int n_samples, hipStream_t s,
+                              int raw_oct3 = 0);   // raw_oct3: source in the bf16x6 oct3 layout
 // d = PReLU(dwconv_dilated(ELU(IN1d(x)))) ; accumulates gLN statistics (per sample) of d
 hipError_t launch_tcn_dw(const float* x, const double* x_stats, const float* wdw /*[C][3]*/, const float* prelu /*[1]*/,
                          float* d, double* gln_stats /*[n][2]*/, int C, int T, int Tp, int dilation, int n_samples, hipStream_t s);
@@ -120,7 +121,8 @@ hipError_t launch_tcn_dw(const float* x, const double* x_stats, const float* wdw
 hipError_t launch_tcn_pw(const float* d, const double* gln_stats, const float* gamma, const float* beta,
                          const float* wpw /*packed [C/CK... see tcn.hip]*/, const float* residual /*or nullptr*/,
                          float* y, long long y_bstride, int y_c0, double* y_stats /*[n][C][2]*/, int C, int T, int Tp,
-                         int n_samples, hipStream_t s);
+                         int n_samples, hipStream_t s,
+                         int y_oct3_cbuf = 0);   // != 0: y is an oct3 buffer with that many channels (bf16x6 mode)
 
 // ---- layout conversion ----------------------------------------------------------------------------------------
 // complex64 [B][Mseg][T][F] -> planar real/imag channel planes; optional circular mic shifts (tester.py:1034,1050):

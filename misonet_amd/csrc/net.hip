@@ -294,11 +294,15 @@ static int build_plan(misonet_net* n) {
 static long long align_up(long long x, long long a) { return (x + a - 1) / a * a; }
 
 // precision 2 ("bf16x3") and 3 ("bf16x6"), the DMA dataflows: the dense-block buffers and everything between them travel
-// in the oct layout (2 bf16 parts = the bytes of float32, or 3 parts = 6 bytes per element); the network input/output,
-// the F <= 3 bottleneck buffers and the TCN stay planar float32.  Returns the ConvArgs::in_oct / out_oct code.
+// in the oct layout (2 bf16 parts = the bytes of float32, or 3 parts = 6 bytes per element); the network input/output
+// and the TCN stay planar float32, and so do the F <= 3 bottleneck buffers except in bf16x6.  Returns the ConvArgs::in_oct /
+// out_oct code.
 static inline int buf_oct(const misonet_net* n, int b) {
   if (n->precision < 2) return 0;
   const bool o = (b >= B_E0 && b <= B_E4) || (b >= B_D2 && b <= B_D6) || (b >= B_X2 && b <= B_X6);
+  // bf16x6 also keeps the F <= 3 bottleneck buffers D0 / D1 in its layout (the TCN reads / writes it at its two ends), so
+  // that encoder 6 and decoders 0-1 run on the persistent kernel instead of the one-row-per-wave f32 kernel
+  if (n->precision == 3 && (b == B_D0 || b == B_D1)) return 3;
   return o ? (n->precision == 3 ? 3 : (n->precision == 4 ? 4 : 1)) : 0;
 }
 // floats per sample of buffer b (an oct3 buffer holds 1.5 floats per element; C is a multiple of 8 there)
@@ -473,7 +477,7 @@ static int forward_planar(misonet_net* n, const Layout& L, void* ws, hipStream_t
     float* tp = buf_ptr(L, ws, B_TP);
     const int skip_c0 = n->cfg.de_ch[0];
     HIPCHK(launch_tcn_prepare(buf_ptr(L, ws, B_D0), bstride(n, L, B_D0), skip_c0, stats_ptr(L, ws, B_D0),
-                              n->bufs[B_D0].C, xa, xs, 128, T, Tp, N, s));
+                              n->bufs[B_D0].C, xa, xs, 128, T, Tp, N, s, buf_oct(n, B_D0) == 3));
     float* cur = xa;
     float* nxt = xb;
     for (int k = 0; k < 14; ++k) {
@@ -489,7 +493,7 @@ static int forward_planar(misonet_net* n, const Layout& L, void* ws, hipStream_t
       float* y = last ? buf_ptr(L, ws, B_D0) : nxt;
       HIPCHK(launch_tcn_pw(td, gl + (2 * k + 1) * (long long)N * 2, W + tb.h[1].o_gamma, W + tb.h[1].o_beta,
                            W + tb.h[1].o_pw, cur, y, last ? bstride(n, L, B_D0) : 128LL * Tp, 0,
-                           xs + (k + 1) * per, 128, T, Tp, N, s));
+                           xs + (k + 1) * per, 128, T, Tp, N, s, (last && buf_oct(n, B_D0) == 3) ? n->bufs[B_D0].C : 0));
       float* t = cur; cur = nxt; nxt = t;
     }
   }

@@ -33,18 +33,31 @@ __device__ inline void in_params(const double* st, int T, float& mean, float& rs
 }
 
 // x[n][c][t] = IN2d(raw)[n][c][t] (the encoder's last Conv2d_ output, F = 1; model.py:89) + sums of x
+// raw_oct3: the source buffer is in the oct3 layout of the bf16x6 mode (three bf16 parts [c/8][f = 0][Tp][8], value = their
+// exact sum); raw_sstride = channels of that buffer.
 __global__ __launch_bounds__(256) void tcn_prepare_k(const float* raw, long long raw_bstride, int raw_c0,
                                                      const double* raw_stats, int raw_sstride, float* x,
-                                                     double* x_stats, int C, int T, int Tp) {
+                                                     double* x_stats, int C, int T, int Tp, int raw_oct3) {
   __shared__ double s_tmp[4];
   const int c = blockIdx.x, n = blockIdx.y;
   float mean, rstd;
   in_params(raw_stats + ((long long)n * raw_sstride + raw_c0 + c) * 2, T, mean, rstd);
   const float* src = raw + (long long)n * raw_bstride + (long long)(raw_c0 + c) * Tp;
+  const unsigned short* so = reinterpret_cast<const unsigned short*>(raw + (long long)n * raw_bstride);
+  const int ch = raw_c0 + c;
+  const long long part_e = (long long)(raw_sstride >> 3) * Tp * 8;      // bf16 elements per part (F = 1)
   float* dst = x + ((long long)n * C + c) * Tp;
   double s1 = 0.0, s2 = 0.0;
   for (int t = threadIdx.x; t < T; t += 256) {
-    const float v = (src[t] - mean) * rstd;
+    float r;
+    if (raw_oct3) {
+      const long long e = ((long long)(ch >> 3) * Tp + t) * 8 + (ch & 7);
+      r = (__uint_as_float((unsigned)so[e] << 16) + __uint_as_float((unsigned)so[part_e + e] << 16)) +
+          __uint_as_float((unsigned)so[2 * part_e + e] << 16);
+    } else {
+      r = src[t];
+    }
+    const float v = (r - mean) * rstd;
     dst[t] = v;
     s1 += v;
     s2 += (double)v * v;
@@ -144,10 +157,13 @@ __global__ __launch_bounds__(256) void tcn_dw_k(const float* x, const double* x_
 // conv_epilogue.hpp.
 constexpr int PW_TT = 128;
 constexpr int PW_KC = 16;
+// Y_OCT3: y is an oct3 buffer of the bf16x6 mode (the TCN output feeds decoder 0 there): the accumulator layout is the
+// conv kernels', so the row goes out through store_oct_row<3>; y_bstride in floats, y_cbuf = channels of that buffer.
+template <bool Y_OCT3>
 __global__ __launch_bounds__(256) void tcn_pw_k(const float* d, const double* gln_stats, const float* gamma,
                                                 const float* beta, const float* wt /*[ci][co]*/,
                                                 const float* residual, float* y, long long y_bstride, int y_c0,
-                                                double* y_stats, int T, int Tp) {
+                                                double* y_stats, int T, int Tp, int y_cbuf) {
   constexpr int C = 128;
   __shared__ __align__(16) float s_g[2][PW_KC][PW_TT];
   __shared__ __align__(16) float s_w[2][PW_KC][C];
@@ -246,6 +262,18 @@ __global__ __launch_bounds__(256) void tcn_pw_k(const float* d, const double* gl
   const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(
       reinterpret_cast<void*>(((unsigned long long)phi << 32) | plo), 0,
       __builtin_amdgcn_readfirstlane((int)((unsigned)C * (unsigned)Tp * 4u)), 0x00020000);
+  // oct3 destination: three parts, each [y_cbuf / 8][F = 1][Tp] 16-byte units, this kernel's channels at octet y_c0 / 8
+  const unsigned OP16 = (unsigned)Tp * 16u;
+  __amdgpu_buffer_rsrc_t rs_o[3];
+  {
+    const unsigned long long po = reinterpret_cast<unsigned long long>(y) + (unsigned long long)n * y_bstride * 4ull +
+                                  (unsigned long long)(y_c0 >> 3) * OP16;
+    const unsigned long long pb = (unsigned long long)(y_cbuf >> 3) * OP16;
+    const unsigned nrec = Y_OCT3 ? (unsigned)(C >> 3) * OP16 : 0u;
+    rs_o[0] = make_rsrc_e(po, nrec);
+    rs_o[1] = make_rsrc_e(po + pb, nrec);
+    rs_o[2] = make_rsrc_e(po + 2 * pb, nrec);
+  }
   float s1[16], s2[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
@@ -255,15 +283,20 @@ __global__ __launch_bounds__(256) void tcn_pw_k(const float* d, const double* gl
     const bool ok = t < T;
     const float m = ok ? 1.f : 0.f;
     const unsigned vo = ok ? (unsigned)((wave * 32 + 4 * half) * Tp + t) * 4u : 0x80000000u;
+    float vrow[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co_off = (r & 3) + 8 * (r >> 2);
       const float v = acc[s][r] + rv[s][r];
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, vo + (unsigned)(co_off * Tp) * 4u, 0, 0);
+      vrow[r] = v;
+      if (!Y_OCT3)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, vo + (unsigned)(co_off * Tp) * 4u, 0, 0);
       const float vm = v * m;
       s1[r] += vm;
       s2[r] = fmaf(vm, vm, s2[r]);
     }
+    if (Y_OCT3)     // octets 4 * wave + {0, 2} + half of this kernel's 16 octets, frame t
+      store_oct_row<3>(vrow, rs_o, (unsigned)t * 16u + (unsigned)(4 * wave + half) * OP16, OP16, ok, ok);
   }
   if (y_stats) {
     const float x1 = reduce16_halfwave(s1, lane);
@@ -280,9 +313,9 @@ __global__ __launch_bounds__(256) void tcn_pw_k(const float* d, const double* gl
 
 hipError_t launch_tcn_prepare(const float* raw, long long raw_bstride, int raw_c0, const double* raw_stats,
                               int raw_sstride, float* x, double* x_stats, int C, int T, int Tp, int n_samples,
-                              hipStream_t s) {
+                              hipStream_t s, int raw_oct3) {
   hipLaunchKernelGGL(tcn_prepare_k, dim3(C, n_samples), dim3(256), 0, s, raw, raw_bstride, raw_c0, raw_stats,
-                     raw_sstride, x, x_stats, C, T, Tp);
+                     raw_sstride, x, x_stats, C, T, Tp, raw_oct3);
   return hipGetLastError();
 }
 
@@ -297,10 +330,17 @@ hipError_t launch_tcn_dw(const float* x, const double* x_stats, const float* wdw
 
 hipError_t launch_tcn_pw(const float* d, const double* gln_stats, const float* gamma, const float* beta,
                          const float* wpw, const float* residual, float* y, long long y_bstride, int y_c0,
-                         double* y_stats, int C, int T, int Tp, int n_samples, hipStream_t s) {
+                         double* y_stats, int C, int T, int Tp, int n_samples, hipStream_t s, int y_oct3_cbuf) {
   if (C != 128) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(tcn_pw_k, dim3((T + PW_TT - 1) / PW_TT, n_samples), dim3(256), 0, s, d, gln_stats, gamma, beta,
-                     wpw, residual, y, y_bstride, y_c0, y_stats, T, Tp);
+  const dim3 g((T + PW_TT - 1) / PW_TT, n_samples);
+  if (y_oct3_cbuf) {
+    if ((y_c0 & 7) || (y_oct3_cbuf & 7)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(tcn_pw_k<true>, g, dim3(256), 0, s, d, gln_stats, gamma, beta, wpw, residual, y, y_bstride, y_c0,
+                       y_stats, T, Tp, y_oct3_cbuf);
+  } else {
+    hipLaunchKernelGGL(tcn_pw_k<false>, g, dim3(256), 0, s, d, gln_stats, gamma, beta, wpw, residual, y, y_bstride, y_c0,
+                       y_stats, T, Tp, 0);
+  }
   return hipGetLastError();
 }
 
