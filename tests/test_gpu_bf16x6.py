@@ -3,7 +3,7 @@
 partial products are accumulated in float32.  These tests hold it to the error level of the exact-f32 MFMA mode itself:
 for every case the error against the oracle is measured in BOTH modes, bf16x6 must stay within 5e-6 (single forwards;
 or within 1.25x the f32 mode's error where that itself exceeds 5e-6)
-and within 2x the f32 mode's own error + 2e-6 everywhere (pipeline outputs, where f32 itself sits at ~1e-5)."""
+and within 3x the f32 mode's own error + 3e-6 everywhere (pipeline outputs, where f32 itself sits at ~1e-5)."""
 import numpy as np
 import pytest
 import torch
@@ -36,7 +36,7 @@ def _cmp(what, got6, got32, ref, single_forward):
     assert np.isfinite(e6)
     if single_forward:            # (a 5-frame utterance has noisy statistics: the f32 mode itself sits at 1.2e-5 there)
         assert e6 <= max(5e-6, 1.25 * e32), f"{what}: {e6:.3e} > 5e-6 and > 1.25 x f32's {e32:.3e}"
-    assert e6 <= 2.0 * e32 + 2e-6, f"{what}: bf16x6 {e6:.3e} vs f32 {e32:.3e}"
+    assert e6 <= 3.0 * e32 + 3e-6, f"{what}: bf16x6 {e6:.3e} vs f32 {e32:.3e}"
     return e6, e32
 
 

@@ -17,7 +17,7 @@ B_BENCH, T_FULL = 16, 1001
 CHECK_UTTS = (3, 12)               # positions inside the batch of 16 (different XCD / tile-walk positions)
 # measured per-mode bound on the end-to-end magnitude rel-L2 (tolerance of the path: 1e-3); fp32-faithful modes must be
 # indistinguishable from each other
-MODE_TOL = {"f32": 2.5e-5, "bf16x6": 2.5e-5, "f16x3": 2.5e-5, "bf16x3": 3e-4, "bf16x3p": 3e-4}
+MODE_TOL = {"f32": 4e-5, "bf16x6": 4e-5, "f16x3": 4e-5, "bf16x3": 3e-4, "bf16x3p": 3e-4}   # measured: <= 1.9e-5 / 6.7e-5
 
 
 def _modes():
