@@ -124,25 +124,6 @@ hipError_t launch_tcn_pw(const float* d, const double* gln_stats, const float* g
                          int n_samples, hipStream_t s,
                          int y_oct3_cbuf = 0);   // != 0: y is an oct3 buffer with that many channels (bf16x6 mode)
 
-// fused TemporalBlock half (tcn.hip): see TcnFuseArgs there
-struct TcnFuseArgs {
-  const float* s0; const float* s1; float* u_out;      // [n][128][Tp]
-  const double* xs_in;       // [n][128][2]: sums (u, u^2) of s0 as a residual stream (modes 0, 1)
-  const double* ps_in;       // [n][128][3]: sums (P, P^2, x P) of the tensor in s1 (mode 1) / in s0 (mode 2)
-  const double* gl_in;       // [n][2]: gLN sums (d, d^2) of the conv that produced that tensor
-  const float* Bv; const float* Gv;    // [128]: W beta and W gamma 1 of that conv (mode 1)
-  double* xs_out;            // [n][128][2]: sums of u (mode 1; written by the tile-0 workgroup of every sample)
-  int mode;                  // 0: u = s0 with sums xs_in; 1: u = s0 + r s1 + c (block input from the previous block);
-                             // 2: u = s0 = P1 of this block (instance norm through the sums of P1)
-  const float* wdw; const float* prelu; const float* wg;    // this conv: depth-wise [128][3], PReLU slope, (W gamma) [ci][co]
-  float* P; double* gl_out; double* ps_out;                   // raw output + its sums
-  const float* xres;         // mode 2: the block input x (for sum x P), else nullptr
-  int T, Tp, dil;
-};
-hipError_t launch_tcn_fused(const TcnFuseArgs& a, int n_samples, hipStream_t s);
-hipError_t launch_tcn_finish(const float* x, const float* P, const double* gl, const float* Bv, const float* Gv, float* y,
-                             long long y_bstride, int y_cbuf, int oct3, int T, int Tp, int n_samples, hipStream_t s);
-
 // ---- layout conversion ----------------------------------------------------------------------------------------
 // complex64 [B][Mseg][T][F] -> planar real/imag channel planes; optional circular mic shifts (tester.py:1034,1050):
 // destination sample n = b*nshift + k receives source channel (m + k) % Mseg at destination channel m.

@@ -108,11 +108,7 @@ struct ConvL {
   float wscale = 1.f;               // f16x3: power of two that brings max |W| of the layer to [32, 64)
 };
 
-struct TcnHalf {
-  int dw, prelu, gamma, beta, pw;
-  long long o_dw, o_prelu, o_gamma, o_beta, o_pw;
-  long long o_wg, o_B, o_G;      // fused path: (W gamma) [ci][co], W beta [co], W gamma 1 [co]
-};
+struct TcnHalf { int dw, prelu, gamma, beta, pw; long long o_dw, o_prelu, o_gamma, o_beta, o_pw; };
 struct TcnBlock { int dilation; TcnHalf h[2]; };
 
 struct Tap { std::string name; int buf, c0, C; bool normalised; };
@@ -121,7 +117,7 @@ struct Layout {
   int N, T, Tp;
   long long data_off[NBUF];      // floats
   long long stats_off[NBUF];     // doubles
-  long long tcn_xs, tcn_ps, tcn_gln;   // doubles: [15][N*128*2], [28][N*128*3], [28][N*2]
+  long long tcn_xs, tcn_ps, tcn_gln;   // doubles: [15][N*128*2], [14][N*128*2], [28][N*2]
   long long stats_doubles;
   long long data_base;           // bytes from ws start to the float arena
   long long wps_base, wps_nstride;   // bytes: per-sample folded weights of the layer in flight (DMA dataflow)
@@ -324,7 +320,7 @@ static Layout make_layout(const misonet_net* n, int N, int T) {
     so += (long long)N * n->bufs[b].C * 2;
   }
   L.tcn_xs = so;  so += 15LL * N * 128 * 2;
-  L.tcn_ps = so;  so += 28LL * N * 128 * 3;     // per DS conv: sums (P, P^2, x P) of its raw output (fused path)
+  L.tcn_ps = so;  so += 14LL * N * 128 * 2;
   L.tcn_gln = so; so += 28LL * N * 2;
   L.stats_doubles = so;
   L.data_base = align_up(256 + so * 8, 256);
@@ -484,54 +480,14 @@ static int forward_planar(misonet_net* n, const Layout& L, void* ws, hipStream_t
                               n->bufs[B_D0].C, xa, xs, 128, T, Tp, N, s, buf_oct(n, B_D0) == 3));
     float* cur = xa;
     float* nxt = xb;
-    static int tcn_old = -1;                       // MISONET_TCN_UNFUSED=1: the 4-launch blocks (A/B experiments)
-    if (tcn_old < 0) { const char* e = getenv("MISONET_TCN_UNFUSED"); tcn_old = e ? atoi(e) : 0; }
-    const float* W = n->w_dev;
-    if (!tcn_old) {
-      // fused path: one launch per DepthwiseSeparableConv, norms applied late (tcn.hip: tcn_fused_k)
-      const long long per3 = (long long)N * 128 * 3;
-      for (int k = 0; k < 14; ++k) {
-        const TcnBlock& tb = n->tcn[k];
-        TcnFuseArgs fa;
-        // first half: input = the block input (materialised on the way for k > 0)
-        fa.s0 = cur; fa.s1 = k ? tp : nullptr; fa.u_out = k ? nxt : nullptr;
-        fa.xs_in = xs + (k ? k - 1 : 0) * per;
-        fa.ps_in = k ? ps + (2 * (k - 1) + 1) * per3 : nullptr;
-        fa.gl_in = k ? gl + (2 * (k - 1) + 1) * (long long)N * 2 : nullptr;
-        fa.Bv = k ? W + n->tcn[k - 1].h[1].o_B : nullptr;
-        fa.Gv = k ? W + n->tcn[k - 1].h[1].o_G : nullptr;
-        fa.xs_out = xs + k * per;
-        fa.mode = k ? 1 : 0;
-        fa.wdw = W + tb.h[0].o_dw; fa.prelu = W + tb.h[0].o_prelu; fa.wg = W + tb.h[0].o_wg;
-        fa.P = td; fa.gl_out = gl + (2 * k) * (long long)N * 2; fa.ps_out = ps + (2 * k) * per3;
-        fa.xres = nullptr;
-        fa.T = T; fa.Tp = Tp; fa.dil = tb.dilation;
-        HIPCHK(launch_tcn_fused(fa, N, s));
-        if (k) { float* t = cur; cur = nxt; nxt = t; }           // cur = this block's input x_k
-        // second half: input = P1 of this block, residual stream x_k only for the cross sums
-        fa.s0 = td; fa.s1 = nullptr; fa.u_out = nullptr;
-        fa.xs_in = nullptr;
-        fa.ps_in = ps + (2 * k) * per3;
-        fa.gl_in = gl + (2 * k) * (long long)N * 2;
-        fa.Bv = fa.Gv = nullptr; fa.xs_out = nullptr;
-        fa.mode = 2;
-        fa.wdw = W + tb.h[1].o_dw; fa.prelu = W + tb.h[1].o_prelu; fa.wg = W + tb.h[1].o_wg;
-        fa.P = tp; fa.gl_out = gl + (2 * k + 1) * (long long)N * 2; fa.ps_out = ps + (2 * k + 1) * per3;
-        fa.xres = cur;
-        HIPCHK(launch_tcn_fused(fa, N, s));
-      }
-      const bool o3 = buf_oct(n, B_D0) == 3;
-      HIPCHK(launch_tcn_finish(cur, tp, gl + 27LL * N * 2, W + n->tcn[13].h[1].o_B, W + n->tcn[13].h[1].o_G,
-                               buf_ptr(L, ws, B_D0), bstride(n, L, B_D0), n->bufs[B_D0].C, o3 ? 1 : 0, T, Tp, N, s));
-    } else {
-    double* ps2 = ps;                              // the unfused kernels keep (sum, sum^2) per channel: stride 2
     for (int k = 0; k < 14; ++k) {
       const TcnBlock& tb = n->tcn[k];
+      const float* W = n->w_dev;
       HIPCHK(launch_tcn_dw(cur, xs + k * per, W + tb.h[0].o_dw, W + tb.h[0].o_prelu, td, gl + (2 * k) * (long long)N * 2,
                            128, T, Tp, tb.dilation, N, s));
       HIPCHK(launch_tcn_pw(td, gl + (2 * k) * (long long)N * 2, W + tb.h[0].o_gamma, W + tb.h[0].o_beta, W + tb.h[0].o_pw,
-                           nullptr, tp, 128LL * Tp, 0, ps2 + k * per, 128, T, Tp, N, s));
-      HIPCHK(launch_tcn_dw(tp, ps2 + k * per, W + tb.h[1].o_dw, W + tb.h[1].o_prelu, td,
+                           nullptr, tp, 128LL * Tp, 0, ps + k * per, 128, T, Tp, N, s));
+      HIPCHK(launch_tcn_dw(tp, ps + k * per, W + tb.h[1].o_dw, W + tb.h[1].o_prelu, td,
                            gl + (2 * k + 1) * (long long)N * 2, 128, T, Tp, tb.dilation, N, s));
       const bool last = (k == 13);
       float* y = last ? buf_ptr(L, ws, B_D0) : nxt;
@@ -539,7 +495,6 @@ static int forward_planar(misonet_net* n, const Layout& L, void* ws, hipStream_t
                            W + tb.h[1].o_pw, cur, y, last ? bstride(n, L, B_D0) : 128LL * Tp, 0,
                            xs + (k + 1) * per, 128, T, Tp, N, s, (last && buf_oct(n, B_D0) == 3) ? n->bufs[B_D0].C : 0));
       float* t = cur; cur = nxt; nxt = t;
-    }
     }
   }
   { int r = run_stack(n->dec); if (r) return r; }
@@ -727,9 +682,6 @@ int misonet_net_commit(misonet_net* n) {
       tb.h[h].o_gamma = take(128);
       tb.h[h].o_beta = take(128);
       tb.h[h].o_pw = take(128 * 128);
-      tb.h[h].o_wg = take(128 * 128);
-      tb.h[h].o_B = take(128);
-      tb.h[h].o_G = take(128);
     }
   std::vector<float> arena((size_t)off, 0.f);
   for (ConvL& c : n->enc) { pack_conv(n, c, arena); pack_conv_bf16(n, c, arena); pack_conv_wf6(n, c, arena); }
@@ -744,20 +696,6 @@ int misonet_net_commit(misonet_net* n) {
       const std::vector<float>& P = n->tensors[H.pw].host;     // [co][ci][1] -> [ci][co]
       for (int co = 0; co < 128; ++co)
         for (int ci = 0; ci < 128; ++ci) arena[H.o_pw + (long long)ci * 128 + co] = P[(long long)co * 128 + ci];
-      // fused path (tcn_fused_k): gLN's affine part goes through the linear point-wise conv
-      const std::vector<float>& Gm = n->tensors[H.gamma].host;
-      const std::vector<float>& Bt = n->tensors[H.beta].host;
-      for (int co = 0; co < 128; ++co) {
-        double sb = 0.0, sgm = 0.0;
-        for (int ci = 0; ci < 128; ++ci) {
-          const float wg = P[(long long)co * 128 + ci] * Gm[ci];
-          arena[H.o_wg + (long long)ci * 128 + co] = wg;
-          sb += (double)P[(long long)co * 128 + ci] * (double)Bt[ci];
-          sgm += (double)wg;
-        }
-        arena[H.o_B + co] = (float)sb;
-        arena[H.o_G + co] = (float)sgm;
-      }
     }
   if (n->w_dev) { (void)hipFree(n->w_dev); n->w_dev = nullptr; }
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&n->w_dev), arena.size() * sizeof(float)));

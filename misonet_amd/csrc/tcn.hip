@@ -311,306 +311,6 @@ __global__ __launch_bounds__(256) void tcn_pw_k(const float* d, const double* gl
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Fused TemporalBlock half: ONE launch per DepthwiseSeparableConv (model.py:553-567) instead of two, 30 launches per
-// TCN instead of 57.  The global norms that separate the stages are applied LATE, by algebra:
-//   * gLN is affine per sample and the point-wise conv is linear, so  pw(gLN(d)) = r P + c  with
-//         P[co][t] = sum_ci (W[co][ci] gamma[ci]) d[ci][t],   r = rstd_gLN(d),   c[co] = (W beta)[co] - r mean_gLN(d) (W gamma 1)[co]:
-//     the kernel computes P from the RAW d while it accumulates the gLN sums of d; whoever reads P next applies (r, c);
-//   * the instance norm of y = r P + c needs only the per-channel sums of P:  (y - mean y) = r (P - mean P)  (c cancels);
-//   * the block output x' = x + r2 P2 + c2 is materialised by the FIRST kernel of the next block while it stages its
-//     input (and by tcn_finish_k after the last block); its instance-norm sums follow from the sums of x, P2 and x P2.
-// Source of a kernel:  u[c][t] = s0[c][t] + rr s1[c][t] + cc[c]  (s1 optional),  a = ELU((u - mu[c]) rho[c]),
-// d = PReLU(dwconv_dilated(a)),  P = (W gamma) d.   All sums in float64.
-
-template <int H>
-__global__ __launch_bounds__(256) void tcn_fused_k(const TcnFuseArgs a) {
-  constexpr int C = 128;
-  constexpr int W = PW_TT + 2 * H;                   // staged frames per channel: [t0 - H, t0 + 128 + H)
-  constexpr int W4 = W / 4;
-  constexpr int NU = (PW_KC * W4 + 255) / 256;       // float4 units per thread and chunk
-  __shared__ __align__(16) float s_a[PW_KC][W];
-  __shared__ __align__(16) float s_g[2][PW_KC][PW_TT];
-  __shared__ __align__(16) float s_w[2][PW_KC][C];
-  __shared__ float4 s_par[C];                        // (rho, rr, cc, mu)
-  __shared__ double s_tmp[4][2];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int half = lane >> 5, l31 = lane & 31;
-  const int t0 = blockIdx.x * PW_TT, n = blockIdx.y;
-  const int T = a.T, Tp = a.Tp, dil = a.dil;
-  const double cntT = (double)T;
-
-  // ---- per-channel parameters of the source (every workgroup recomputes them from the float64 sums) ----
-  if (tid < C) {
-    const int c = tid;
-    double rr = 0.0, cc = 0.0, mu, var;
-    bool direct = true;
-    if (a.mode == 0) {
-      const double* st = a.xs_in + ((long long)n * C + c) * 2;
-      mu = st[0] / cntT;
-      var = st[1] / cntT - mu * mu;
-    } else {
-      const double gcnt = (double)C * cntT;
-      const double gm = a.gl_in[(long long)n * 2] / gcnt;
-      double gv = a.gl_in[(long long)n * 2 + 1] / gcnt - gm * gm;
-      gv = gv > 0.0 ? gv : 0.0;
-      const double r = 1.0 / sqrt(gv + (double)GLN_EPS);
-      const double* ps = a.ps_in + ((long long)n * C + c) * 3;
-      if (a.mode == 1) {
-        rr = r;
-        cc = (double)a.Bv[c] - r * gm * (double)a.Gv[c];
-        const double* st = a.xs_in + ((long long)n * C + c) * 2;
-        const double su = st[0] + r * ps[0] + cntT * cc;
-        const double suu = st[1] + r * r * ps[1] + cntT * cc * cc + 2.0 * r * ps[2] + 2.0 * cc * st[0] + 2.0 * r * cc * ps[0];
-        mu = su / cntT;
-        var = suu / cntT - mu * mu;
-        if (blockIdx.x == 0) {
-          double* o = a.xs_out + ((long long)n * C + c) * 2;
-          o[0] = su; o[1] = suu;
-        }
-      } else {
-        // y = r P + c:  (y - mean y) rstd_y = (P - mean P) * r / sqrt(r^2 var P + eps)
-        mu = ps[0] / cntT;
-        const double vp = ps[1] / cntT - mu * mu;
-        var = r * r * (vp > 0.0 ? vp : 0.0);
-        var = var > 0.0 ? var : 0.0;
-        s_par[c] = make_float4((float)(r / sqrt(var + (double)IN_EPS)), 0.f, 0.f, (float)mu);
-        direct = false;
-      }
-    }
-    if (direct) {
-      var = var > 0.0 ? var : 0.0;
-      s_par[c] = make_float4((float)(1.0 / sqrt(var + (double)IN_EPS)), (float)rr, (float)cc, (float)mu);
-    }
-  }
-  const float slope = a.prelu[0];
-  const float* s0n = a.s0 + (long long)n * C * Tp;
-  const float* s1n = a.s1 ? a.s1 + (long long)n * C * Tp : nullptr;
-  float* uon = a.u_out ? a.u_out + (long long)n * C * Tp : nullptr;
-
-  f32x16 acc[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
-
-  // staging roles.  Source units: unit u = tid + 256 i -> (row = u / W4, col4 = u % W4), frames t0 - H + 4 col4 ..
-  // d / weight roles as tcn_pw_k: thread (q = tid & 31 -> frames 4q..4q+3, g = tid >> 5 -> channels g, g + 8 of the chunk)
-  const int sq = tid & 31, sg = tid >> 5;
-  float4 v0[NU], v1[NU], wi[2];
-#define FU_ISSUE(K0)                                                                                             \
-  _Pragma("unroll") for (int i = 0; i < NU; ++i) {                                                               \
-    const int u_ = tid + 256 * i;                                                                                \
-    const int row_ = u_ / W4, c4_ = u_ - row_ * W4;                                                              \
-    const int tg_ = t0 - H + 4 * c4_;                                                                            \
-    const bool ld_ = (u_ < PW_KC * W4) && tg_ >= 0 && tg_ < Tp;                                                  \
-    const long long o_ = (long long)((K0) + (row_ < PW_KC ? row_ : 0)) * Tp + (tg_ >= 0 ? tg_ : 0);              \
-    v0[i] = ld_ ? *reinterpret_cast<const float4*>(s0n + o_) : make_float4(0.f, 0.f, 0.f, 0.f);                  \
-    v1[i] = (ld_ && s1n) ? *reinterpret_cast<const float4*>(s1n + o_) : make_float4(0.f, 0.f, 0.f, 0.f);         \
-  }                                                                                                              \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                  \
-    wi[i] = *reinterpret_cast<const float4*>(a.wg + (long long)((K0) + sg + 8 * i) * C + 4 * sq);
-  // a = ELU(IN(u)) into s_a (zero outside [0, T): Conv1d pads the ELU output); the block input u goes out on the way
-#define FU_COMMIT_A(K0)                                                                                          \
-  _Pragma("unroll") for (int i = 0; i < NU; ++i) {                                                               \
-    const int u_ = tid + 256 * i;                                                                                \
-    if (u_ < PW_KC * W4) {                                                                                       \
-      const int row_ = u_ / W4, c4_ = u_ - row_ * W4;                                                            \
-      const int tg_ = t0 - H + 4 * c4_;                                                                          \
-      const float4 p_ = s_par[(K0) + row_];                                                                      \
-      float4 uu_;                                                                                                \
-      uu_.x = fmaf(p_.y, v1[i].x, v0[i].x) + p_.z; uu_.y = fmaf(p_.y, v1[i].y, v0[i].y) + p_.z;                  \
-      uu_.z = fmaf(p_.y, v1[i].z, v0[i].z) + p_.z; uu_.w = fmaf(p_.y, v1[i].w, v0[i].w) + p_.z;                  \
-      if (uon && c4_ >= H / 4 && c4_ < H / 4 + PW_TT / 4 && tg_ < Tp)                                            \
-        *reinterpret_cast<float4*>(uon + (long long)((K0) + row_) * Tp + tg_) = uu_;                             \
-      float4 o_;                                                                                                 \
-      o_.x = (tg_ + 0 >= 0 && tg_ + 0 < T) ? elu_fast((uu_.x - p_.w) * p_.x) : 0.f;                              \
-      o_.y = (tg_ + 1 >= 0 && tg_ + 1 < T) ? elu_fast((uu_.y - p_.w) * p_.x) : 0.f;                              \
-      o_.z = (tg_ + 2 >= 0 && tg_ + 2 < T) ? elu_fast((uu_.z - p_.w) * p_.x) : 0.f;                              \
-      o_.w = (tg_ + 3 >= 0 && tg_ + 3 < T) ? elu_fast((uu_.w - p_.w) * p_.x) : 0.f;                              \
-      *reinterpret_cast<float4*>(&s_a[row_][4 * c4_]) = o_;                                                      \
-    }                                                                                                            \
-  }
-  // d = PReLU(dwconv(a)) of this thread's (2 channels x 4 frames) into s_g[BUF], weights into s_w[BUF]; gLN partials
-#define FU_COMMIT_D(K0, BUF)                                                                                     \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
-    const int cl_ = sg + 8 * i;                                                                                  \
-    const int c_ = (K0) + cl_;                                                                                   \
-    const float w0_ = a.wdw[c_ * 3 + 0], w1_ = a.wdw[c_ * 3 + 1], w2_ = a.wdw[c_ * 3 + 2];                       \
-    float dd_[4];                                                                                                \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                              \
-      const int ix_ = H + 4 * sq + j;                                                                            \
-      float x_ = w1_ * s_a[cl_][ix_];                                                                            \
-      x_ = fmaf(w0_, s_a[cl_][ix_ - dil], x_);                                                                   \
-      x_ = fmaf(w2_, s_a[cl_][ix_ + dil], x_);                                                                   \
-      x_ = x_ > 0.f ? x_ : slope * x_;                                                                           \
-      x_ = (t0 + 4 * sq + j < T) ? x_ : 0.f;                                                                     \
-      dd_[j] = x_;                                                                                               \
-      g1 += x_; g2 = fmaf(x_, x_, g2);                                                                           \
-    }                                                                                                            \
-    *reinterpret_cast<float4*>(&s_g[BUF][cl_][4 * sq]) = make_float4(dd_[0], dd_[1], dd_[2], dd_[3]);            \
-    *reinterpret_cast<float4*>(&s_w[BUF][cl_][4 * sq]) = wi[i];                                                  \
-  }
-
-  float g1 = 0.f, g2 = 0.f;
-  double G1 = 0.0, G2 = 0.0;
-  __syncthreads();                                   // s_par
-  FU_ISSUE(0)
-  FU_COMMIT_A(0)
-  __syncthreads();
-  FU_COMMIT_D(0, 0)
-  __syncthreads();
-#pragma unroll 1
-  for (int kc = 0; kc < C / PW_KC; ++kc) {
-    const int buf = kc & 1;
-    const bool more = kc + 1 < C / PW_KC;
-    if (more) { FU_ISSUE((kc + 1) * PW_KC) }
-#pragma unroll
-    for (int kk = 0; kk < PW_KC; kk += 2) {
-      const float av = s_w[buf][kk + half][wave * 32 + l31];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const float bv = s_g[buf][kk + half][s * 32 + l31];
-        acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[s], 0, 0, 0);
-      }
-    }
-    if (more) {
-      FU_COMMIT_A((kc + 1) * PW_KC)                  // s_a is not read by the MFMAs
-      __syncthreads();
-      FU_COMMIT_D((kc + 1) * PW_KC, buf ^ 1)
-      G1 += (double)g1; G2 += (double)g2; g1 = 0.f; g2 = 0.f;
-      __syncthreads();
-    }
-  }
-  G1 += (double)g1; G2 += (double)g2;
-#undef FU_ISSUE
-#undef FU_COMMIT_A
-#undef FU_COMMIT_D
-
-  // ---- gLN sums of d: one float64 atomic pair per workgroup ----
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    G1 += __shfl_xor(G1, m, 64);
-    G2 += __shfl_xor(G2, m, 64);
-  }
-  if (lane == 0) { s_tmp[wave][0] = G1; s_tmp[wave][1] = G2; }
-  __syncthreads();
-  if (tid < 2)
-    unsafeAtomicAdd(a.gl_out + (long long)n * 2 + tid, s_tmp[0][tid] + s_tmp[1][tid] + s_tmp[2][tid] + s_tmp[3][tid]);
-
-  // ---- epilogue: raw P out; sums of P, P^2 and (mode 2) x P per output channel ----
-  float xv[4][16];
-  {
-    const float* xn = a.xres ? a.xres + (long long)n * C * Tp : s0n;
-    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc_e(reinterpret_cast<unsigned long long>(xn),
-                                                    a.xres ? (unsigned)C * (unsigned)Tp * 4u : 0u);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int t = t0 + s * 32 + l31;
-      const unsigned vo = (t < T) ? (unsigned)((wave * 32 + 4 * half) * Tp + t) * 4u : 0x80000000u;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co_off = (r & 3) + 8 * (r >> 2);
-        xv[s][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, vo + (unsigned)(co_off * Tp) * 4u, 0, 0));
-      }
-    }
-  }
-  const __amdgpu_buffer_rsrc_t rs_p = make_rsrc_e(reinterpret_cast<unsigned long long>(a.P + (long long)n * C * Tp),
-                                                  (unsigned)C * (unsigned)Tp * 4u);
-  float s1[16], s2[16], s3[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; s3[r] = 0.f; }
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const int t = t0 + s * 32 + l31;
-    const bool ok = t < T;
-    const unsigned vo = ok ? (unsigned)((wave * 32 + 4 * half) * Tp + t) * 4u : 0x80000000u;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co_off = (r & 3) + 8 * (r >> 2);
-      const float v = acc[s][r];
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_p, vo + (unsigned)(co_off * Tp) * 4u, 0, 0);
-      const float vm = ok ? v : 0.f;
-      s1[r] += vm;
-      s2[r] = fmaf(vm, vm, s2[r]);
-      s3[r] = fmaf(vm, xv[s][r], s3[r]);             // out-of-range loads return 0
-    }
-  }
-  {
-    const float x1 = reduce16_halfwave(s1, lane);
-    const float x2 = reduce16_halfwave(s2, lane);
-    const float x3 = a.xres ? reduce16_halfwave(s3, lane) : 0.f;
-    if ((lane & 16) == 0) {
-      const int q = lane & 15;
-      const int co = wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
-      double* o = a.ps_out + ((long long)n * C + co) * 3;
-      unsafeAtomicAdd(o + 0, (double)x1);
-      unsafeAtomicAdd(o + 1, (double)x2);
-      if (a.xres) unsafeAtomicAdd(o + 2, (double)x3);
-    }
-  }
-}
-
-// TCN output = x + r P2 + c of the last block (tcn_fused_k's late norms), written as the decoder's first 128 channels:
-// planar float32 rows, or the oct3 layout of the bf16x6 mode (y_cbuf = channels of that buffer).  One thread per
-// (octet, frame).
-__global__ __launch_bounds__(256) void tcn_finish_k(const float* x, const float* P, const double* gl, const float* Bv,
-                                                    const float* Gv, float* y, long long y_bstride, int y_cbuf, int oct3,
-                                                    int T, int Tp) {
-  constexpr int C = 128;
-  const int t = blockIdx.x * 256 + threadIdx.x, o = blockIdx.y, n = blockIdx.z;
-  const double gcnt = (double)C * (double)T;
-  const double gm = gl[(long long)n * 2] / gcnt;
-  double gv = gl[(long long)n * 2 + 1] / gcnt - gm * gm;
-  gv = gv > 0.0 ? gv : 0.0;
-  const double r = 1.0 / sqrt(gv + (double)GLN_EPS);
-  if (t >= T) return;
-  float v[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int c = o * 8 + e;
-    const long long i = ((long long)n * C + c) * Tp + t;
-    const float cc = (float)((double)Bv[c] - r * gm * (double)Gv[c]);
-    v[e] = fmaf((float)r, P[i], x[i]) + cc;
-  }
-  if (oct3) {
-    u32x4_t ph, pm, pl;
-#pragma unroll
-    for (int e2 = 0; e2 < 4; ++e2) {
-      unsigned a_, b_, c_;
-      split3_pair_t(v[2 * e2], v[2 * e2 + 1], a_, b_, c_);
-      ph[e2] = a_; pm[e2] = b_; pl[e2] = c_;
-    }
-    u32x4_t* d = reinterpret_cast<u32x4_t*>(y + (long long)n * y_bstride) + (long long)o * Tp + t;
-    const long long part_u = (long long)(y_cbuf >> 3) * Tp;
-    d[0] = ph; d[part_u] = pm; d[2 * part_u] = pl;
-  } else {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) y[(long long)n * y_bstride + (long long)(o * 8 + e) * Tp + t] = v[e];
-  }
-}
-
-hipError_t launch_tcn_fused(const TcnFuseArgs& a, int n_samples, hipStream_t s) {
-  const dim3 g((a.T + PW_TT - 1) / PW_TT, n_samples);
-  const int H = a.dil <= 4 ? 4 : a.dil;
-  switch (H) {
-    case 4: hipLaunchKernelGGL(tcn_fused_k<4>, g, dim3(256), 0, s, a); break;
-    case 8: hipLaunchKernelGGL(tcn_fused_k<8>, g, dim3(256), 0, s, a); break;
-    case 16: hipLaunchKernelGGL(tcn_fused_k<16>, g, dim3(256), 0, s, a); break;
-    case 32: hipLaunchKernelGGL(tcn_fused_k<32>, g, dim3(256), 0, s, a); break;
-    case 64: hipLaunchKernelGGL(tcn_fused_k<64>, g, dim3(256), 0, s, a); break;
-    default: return hipErrorInvalidValue;
-  }
-  return hipGetLastError();
-}
-
-hipError_t launch_tcn_finish(const float* x, const float* P, const double* gl, const float* Bv, const float* Gv, float* y,
-                             long long y_bstride, int y_cbuf, int oct3, int T, int Tp, int n_samples, hipStream_t s) {
-  hipLaunchKernelGGL(tcn_finish_k, dim3((T + 255) / 256, 16, n_samples), dim3(256), 0, s, x, P, gl, Bv, Gv, y, y_bstride,
-                     y_cbuf, oct3, T, Tp);
-  return hipGetLastError();
-}
-
 hipError_t launch_tcn_prepare(const float* raw, long long raw_bstride, int raw_c0, const double* raw_stats,
                               int raw_sstride, float* x, double* x_stats, int C, int T, int Tp, int n_samples,
                               hipStream_t s, int raw_oct3) {
