@@ -130,3 +130,22 @@ def test_non_default_geometry(mode):
     ref = np.concatenate([miso_oracle.miso1_forward(torch.from_numpy(x[b:b + 1]), sd).numpy() for b in range(2)])
     assert y.shape == (2, 3, 70, 129)
     _assert_parity(y, ref, f"[{mode}] non-default geometry (4 mics, 3 speakers, en={en})")
+
+
+def test_f16x3_overflow_fails_loudly(sd1):
+    """f16x3 keeps activations as fp16 pieces: values beyond 65504 overflow.  That must surface as the library's NaN
+    error (FloatingPointError), never as a silently wrong spectrogram; the float32-range modes take the same input."""
+    _need_gpu()
+    import misonet_amd as mz
+    from misonet_amd import weights as W
+    m = mz.MISO_1(2, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN").cuda(0)
+    m.load_state_dict(sd1)
+    m.eval()
+    r = np.random.default_rng(8)
+    x = (1e6 * (r.standard_normal((1, 6, 40, 129)) + 1j * r.standard_normal((1, 6, 40, 129)))).astype(np.complex64)
+    xd = torch.from_numpy(x).cuda()
+    y6 = m.set_precision("bf16x6")(xd).cpu().numpy()
+    y32 = m.set_precision("f32")(xd).cpu().numpy()
+    assert np.isfinite(y6).all() and rel_l2(y6, y32) < 1e-4
+    with pytest.raises(FloatingPointError):
+        m.set_precision("f16x3")(xd)
