@@ -4,6 +4,7 @@ Host-side mirror of the reference call surface:
   MISO_1, MISO_3            (reference model.py:8-111, 282-395)
   Apply_Beamforming         (reference tester.py:1071-1136)
   Enhancer                  (reference tester.py:846-975, the Tester_Enhance hot loop, kept on-device)
+  tester.Tester_Enhance     (reference tester.py:798-975: the harness class itself, same constructor / test / inference)
 The compute lives in csrc/ (libmisonet_hip.so); importing a compute symbol without the built
 library raises -- there is no CPU fallback.
 """

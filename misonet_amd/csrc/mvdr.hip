@@ -148,63 +148,82 @@ __global__ __launch_bounds__(256) void mvdr_scm_eig(const MvdrArgs a, double* ws
     s_V[i][j][1] = 0.0;
   }
   __syncthreads();
-  // cyclic complex Jacobi on the Hermitian s_A; eigenvectors accumulate in the columns of s_V.  The workgroup is one wave:
-  // lane k < M owns index k of the three M-long update loops of a rotation (columns of A, columns of V, rows of A), every
-  // lane recomputes the rotation itself from the same LDS values, so control flow stays uniform and each matrix element
-  // sees exactly the arithmetic of the sequential algorithm.
+  // Complex Jacobi on the Hermitian s_A with a PARALLEL (round-robin) ordering; eigenvectors accumulate in the columns of
+  // s_V.  A sweep is ME - 1 rounds of M / 2 DISJOINT pivot pairs; disjoint rotations commute, so a round applies
+  // A <- R^H A R with R = R_1 R_2 .. in three phases separated by barriers: (0) every lane of pair j computes that
+  // pair's rotation from the untouched matrix, (1) lane (j, k) updates row k of the columns (p_j, q_j) of A and V,
+  // (2) lane (j, k) updates column k of the rows (p_j, q_j) of A.  M (M - 1) / 2 rotations of a sweep cost ME - 1 round
+  // latencies instead of M (M - 1) / 2: the 6 x 6 problem was ~280 of the kernel's 320 us of dependent float64 work.
   {
+    constexpr int ME = (M + 1) & ~1;                       // players of the tournament (a dummy when M is odd)
+    constexpr int NPR = ME / 2;                            // pairs per round
+    const int pj = tid / M, pk = tid - pj * M;             // this lane's pair slot and index (valid when pj < NPR)
     double scale = 0.0;
     for (int i = 0; i < M; ++i) scale += fabs(s_A[i][i][0]);
     for (int sweep = 0; sweep < 16; ++sweep) {
       double off = 0.0;
       for (int p = 0; p < M; ++p)
         for (int q = p + 1; q < M; ++q) off += s_A[p][q][0] * s_A[p][q][0] + s_A[p][q][1] * s_A[p][q][1];
-      if (off <= 1e-30 * scale * scale || off == 0.0) break;
-      for (int p = 0; p < M; ++p)
-        for (int q = p + 1; q < M; ++q) {
+      if (off <= 1e-28 * scale * scale || off == 0.0) break;    // uniform: every lane reads the same elements
+      for (int rd = 0; rd < ME - 1; ++rd) {
+        // circle method: slot 0 pairs the fixed player ME - 1 with rd, slot i pairs (rd + i) with (rd - i) modulo ME - 1
+        int p = 0, q = 0;
+        bool act = pj < NPR;
+        if (act) {
+          if (pj == 0) { p = rd; q = ME - 1; }
+          else { p = (rd + pj) % (ME - 1); q = (rd - pj + (ME - 1)) % (ME - 1); }
+          if (p > q) { const int t = p; p = q; q = t; }
+          act = q < M;                                     // the dummy player sits out
+        }
+        cd Rpp = {1.0, 0.0}, Rpq = {0.0, 0.0}, Rqp = {0.0, 0.0}, Rqq = {1.0, 0.0};
+        if (act) {
           const cd apq = {s_A[p][q][0], s_A[p][q][1]};
           const double g = sqrt(cabs2(apq));
-          if (g <= 1e-300) continue;                       // uniform: every lane reads the same element
-          const double app = s_A[p][p][0], aqq = s_A[q][q][0];
-          const double tau = (aqq - app) / (2.0 * g);
-          const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-          const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = tt * cs;
-          const cd ph = {apq.re / g, apq.im / g};        // e^{i phi}
-          // R restricted to (p,q): Rpp = c, Rpq = s, Rqp = -s e^{-i phi}, Rqq = c e^{-i phi}
-          const cd Rpp = {cs, 0.0}, Rpq = {sn, 0.0};
-          const cd Rqp = {-sn * ph.re, sn * ph.im}, Rqq = {cs * ph.re, -cs * ph.im};
-          __syncthreads();                                 // every lane has read the pivot before anyone overwrites it
-          if (tid < M) {                                   // A <- A R (columns p, q), V <- V R: row k = tid
-            const int k = tid;
-            const cd akp = {s_A[k][p][0], s_A[k][p][1]}, akq = {s_A[k][q][0], s_A[k][q][1]};
-            const cd np_ = cadd(cmul(akp, Rpp), cmul(akq, Rqp));
-            const cd nq_ = cadd(cmul(akp, Rpq), cmul(akq, Rqq));
-            s_A[k][p][0] = np_.re; s_A[k][p][1] = np_.im;
-            s_A[k][q][0] = nq_.re; s_A[k][q][1] = nq_.im;
-            const cd vkp = {s_V[k][p][0], s_V[k][p][1]}, vkq = {s_V[k][q][0], s_V[k][q][1]};
-            const cd vp_ = cadd(cmul(vkp, Rpp), cmul(vkq, Rqp));
-            const cd vq_ = cadd(cmul(vkp, Rpq), cmul(vkq, Rqq));
-            s_V[k][p][0] = vp_.re; s_V[k][p][1] = vp_.im;
-            s_V[k][q][0] = vq_.re; s_V[k][q][1] = vq_.im;
+          if (g > 1e-300) {
+            const double app = s_A[p][p][0], aqq = s_A[q][q][0];
+            const double tau = (aqq - app) / (2.0 * g);
+            const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+            const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = tt * cs;
+            const cd ph = {apq.re / g, apq.im / g};        // e^{i phi}
+            // R restricted to (p,q): Rpp = c, Rpq = s, Rqp = -s e^{-i phi}, Rqq = c e^{-i phi}
+            Rpp = {cs, 0.0}; Rpq = {sn, 0.0};
+            Rqp = {-sn * ph.re, sn * ph.im}; Rqq = {cs * ph.re, -cs * ph.im};
+          } else {
+            act = false;
           }
-          __syncthreads();
-          if (tid < M) {                                   // A <- R^H A (rows p, q): column k = tid
-            const int k = tid;
-            const cd apk = {s_A[p][k][0], s_A[p][k][1]}, aqk = {s_A[q][k][0], s_A[q][k][1]};
-            const cd np_ = cadd(cmul(cconj(Rpp), apk), cmul(cconj(Rqp), aqk));
-            const cd nq_ = cadd(cmul(cconj(Rpq), apk), cmul(cconj(Rqq), aqk));
-            s_A[p][k][0] = np_.re; s_A[p][k][1] = np_.im;
-            s_A[q][k][0] = nq_.re; s_A[q][k][1] = nq_.im;
-          }
-          __syncthreads();
-          if (tid == 0) {
-            s_A[p][q][0] = s_A[p][q][1] = 0.0;
-            s_A[q][p][0] = s_A[q][p][1] = 0.0;
-            s_A[p][p][1] = 0.0;
-            s_A[q][q][1] = 0.0;
-          }
-          __syncthreads();
         }
+        __syncthreads();                                   // every lane has read its pivot before anyone overwrites it
+        if (act) {                                         // A <- A R (columns p, q), V <- V R: row k = pk
+          const int k = pk;
+          const cd akp = {s_A[k][p][0], s_A[k][p][1]}, akq = {s_A[k][q][0], s_A[k][q][1]};
+          const cd np_ = cadd(cmul(akp, Rpp), cmul(akq, Rqp));
+          const cd nq_ = cadd(cmul(akp, Rpq), cmul(akq, Rqq));
+          s_A[k][p][0] = np_.re; s_A[k][p][1] = np_.im;
+          s_A[k][q][0] = nq_.re; s_A[k][q][1] = nq_.im;
+          const cd vkp = {s_V[k][p][0], s_V[k][p][1]}, vkq = {s_V[k][q][0], s_V[k][q][1]};
+          const cd vp_ = cadd(cmul(vkp, Rpp), cmul(vkq, Rqp));
+          const cd vq_ = cadd(cmul(vkp, Rpq), cmul(vkq, Rqq));
+          s_V[k][p][0] = vp_.re; s_V[k][p][1] = vp_.im;
+          s_V[k][q][0] = vq_.re; s_V[k][q][1] = vq_.im;
+        }
+        __syncthreads();
+        if (act) {                                         // A <- R^H A (rows p, q): column k = pk
+          const int k = pk;
+          const cd apk = {s_A[p][k][0], s_A[p][k][1]}, aqk = {s_A[q][k][0], s_A[q][k][1]};
+          const cd np_ = cadd(cmul(cconj(Rpp), apk), cmul(cconj(Rqp), aqk));
+          const cd nq_ = cadd(cmul(cconj(Rpq), apk), cmul(cconj(Rqq), aqk));
+          s_A[p][k][0] = np_.re; s_A[p][k][1] = np_.im;
+          s_A[q][k][0] = nq_.re; s_A[q][k][1] = nq_.im;
+        }
+        __syncthreads();
+        if (act && pk == 0) {
+          s_A[p][q][0] = s_A[p][q][1] = 0.0;
+          s_A[q][p][0] = s_A[q][p][1] = 0.0;
+          s_A[p][p][1] = 0.0;
+          s_A[q][q][1] = 0.0;
+        }
+        __syncthreads();
+      }
     }
   }
   if (tid == 0) {
@@ -238,22 +257,28 @@ __global__ __launch_bounds__(256) void mvdr_solve(int B, int S, int F, double ep
   const double* d0 = ws + ws_steer0(B, S, F, M) + base * (M * 2);
   for (int i = tid; i < F * M * 2; i += blockDim.x) s_d[i] = d0[i];
   __syncthreads();
-  if (tid == 0) {
+  // sequential-in-f phase correction (tester.py:1161-1167): bin f is rotated by the phase of <d[f], d_corrected[f-1]>.
+  // The dependence from bin to bin is kept exactly; inside a bin lane m < M owns microphone m (the M products and the M
+  // rotations run on M lanes, the sum over m is a butterfly over 8 lanes with zeros in the unused ones).
+  if (tid < 8) {
+    const int m = tid;
+    const bool live = m < M;
+    cd prv = live ? cd{s_d[m * 2], s_d[m * 2 + 1]} : cd{0.0, 0.0};
     for (int f = 1; f < F; ++f) {
-      cd z = {0.0, 0.0};
-      for (int m = 0; m < M; ++m) {
-        const cd cur = {s_d[(f * M + m) * 2], s_d[(f * M + m) * 2 + 1]};
-        const cd prv = {s_d[((f - 1) * M + m) * 2], s_d[((f - 1) * M + m) * 2 + 1]};
-        z = cadd(z, cmulc(cur, prv));
+      const cd cur = live ? cd{s_d[(f * M + m) * 2], s_d[(f * M + m) * 2 + 1]} : cd{0.0, 0.0};
+      cd z = cmulc(cur, prv);
+#pragma unroll
+      for (int w = 4; w >= 1; w >>= 1) {
+        z.re += __shfl_xor(z.re, w, 8);
+        z.im += __shfl_xor(z.im, w, 8);
       }
       const double az = sqrt(cabs2(z));
       cd rot = {1.0, 0.0};                                // exp(-j angle(z)); angle(0) = 0
       if (az > 0.0) rot = {z.re / az, -z.im / az};
-      for (int m = 0; m < M; ++m) {
-        const cd cur = {s_d[(f * M + m) * 2], s_d[(f * M + m) * 2 + 1]};
-        const cd r = cmul(cur, rot);
-        s_d[(f * M + m) * 2] = r.re;
-        s_d[(f * M + m) * 2 + 1] = r.im;
+      prv = cmul(cur, rot);
+      if (live) {
+        s_d[(f * M + m) * 2] = prv.re;
+        s_d[(f * M + m) * 2 + 1] = prv.im;
       }
     }
   }

@@ -284,3 +284,32 @@ def test_inference_loader_two_splits(nets, sd1, sd3, tmp_path):
         assert d.max() <= 1
         v, fs = S.read_wav_pcm24(str(tmp_path / f"rec_{s}.wav"))
         assert fs == 16000 and np.array_equal(v[:, 0], wav[s].astype(np.int32) << 8)
+
+
+def test_tester_enhance_class_drop_in(nets, sd1, sd3, tmp_path):
+    """misonet_amd.tester.Tester_Enhance: the reference's harness class (tester.py:798-975) with the arguments run.py:272-274
+    passes; test() writes cv_dev93/ and test_eval92/ like the reference (tester.py:833,841)."""
+    from misonet_amd.tester import Tester_Enhance
+    from misonet_amd import stft as S
+    from oracle import pipeline_oracle
+    m1, m3 = nets
+    frames = 40
+    mx, cl = _utt_inputs(5, frames)
+    s0 = np.broadcast_to(cl[0][None], (6,) + cl[0].shape)        # loaders carry all mics; only ref_ch is read (tester.py:889)
+    s1 = np.broadcast_to(cl[1][None], (6,) + cl[1].shape)
+    item = ({"0": torch.from_numpy(mx)[None]}, {"0": torch.from_numpy(s0.copy())[None]},
+            {"0": torch.from_numpy(s1.copy())[None]}, [0], ["utt5"])
+    tst = Tester_Enhance("SMS_WSJ", "MISO3", [item], [item], m1, m3, 6, 0, 2, (frames - 1) * 64 / 16000, str(tmp_path), 0, True,
+                         fs=16000, window="hann", length=256, overlap=192)
+    res = tst.test()
+    ref = pipeline_oracle.enhance_utterance(mx, cl, sd1, sd3, ref_ch=0)
+    for sub in ("cv_dev93", "test_eval92"):
+        wav = res[sub]["utt5"]
+        for s in range(2):
+            want = pipeline_oracle.istft_int16(ref["out"][s])
+            assert np.abs(wav[s].astype(np.int32) - want.astype(np.int32)).max() <= 1
+            v, fs = S.read_wav_pcm24(str(tmp_path / sub / f"utt5_{s}.wav"))
+            assert fs == 16000 and np.array_equal(v[:, 0], wav[s].astype(np.int32) << 8)
+    with pytest.raises(ValueError):
+        Tester_Enhance("SMS_WSJ", "MISO3", [], [], m1, m3, 6, 0, 2, 4.0, str(tmp_path), 0, True,
+                       fs=16000, window="hann", length=512, overlap=384)
