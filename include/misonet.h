@@ -69,7 +69,7 @@ int misonet_net_commit(misonet_net* net);
  *               against the reference as mode 0 (2.3e-6 per forward) at 1.5-1.6 x its speed: what bench.py reports;
  *   4 "f16x3"   operands rounded to two fp16 pieces (22 bits; the weights carry a per-layer power-of-two scale), three
  *               terms, float32 accumulation: measured at or below mode 0's error on well-conditioned data (1.9e-6 per
- *               forward) at mode 2's cost, but 10 x mode 0 under |mean| >> std and limited to fp16's range;
+ *               forward) at mode 2's cost, but 2.4 x mode 0 under |mean| >> std and limited to fp16's range;
  *   2 "bf16x3"  every product as w_hi*x_hi + w_hi*x_lo + w_lo*x_hi with 16-bit operands (2.4e-5 per forward, not
  *               fp32-faithful; loses |mean|/std of its accuracy when a layer's input has |mean| >> std), same dataflow
  *               with two parts -- the fastest mode;

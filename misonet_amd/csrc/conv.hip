@@ -272,21 +272,14 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0) ? 3 : 2)
   conv_epilogue<NCO, 4, OCTP, true>(a, acc, n, cg, f, t0, row_ok, lane, s_red + wave * (COP * 2));
   if (a.act) {
     __syncthreads();
-    if (tid < COP) {
-      // the tile's partials are moments about c = ELU(bias[co]) (conv_epilogue CENTRE): un-centre in float64
-      const int co_l = tid;
+    if (tid < COP * 2) {
+      const int co_l = tid >> 1, which = tid & 1;
       const int co = cg * COP + co_l;
       if (co < a.Cout) {
-        float t1 = 0.f, t2 = 0.f;
-        int rows = 0;
+        float tot = 0.f;
         for (int w = 0; w < FT; ++w)
-          if (f0 + w < a.Fout) { t1 += s_red[(w * COP + co_l) * 2]; t2 += s_red[(w * COP + co_l) * 2 + 1]; ++rows; }
-        const int frames = (T - t0) < TT ? (T - t0) : TT;
-        double sx, sxx;
-        stats_uncentre((double)t1, (double)t2, (double)elu_fast(a.bias[co]), (double)rows * (double)frames, sx, sxx);
-        double* o = a.out_stats + ((long long)n * a.out_sstride + a.out_c0 + co) * 2;
-        unsafeAtomicAdd(o, sx);
-        unsafeAtomicAdd(o + 1, sxx);
+          if (f0 + w < a.Fout) tot += s_red[(w * COP + co_l) * 2 + which];
+        unsafeAtomicAdd(a.out_stats + ((long long)n * a.out_sstride + a.out_c0 + co) * 2 + which, (double)tot);
       }
     }
   }

@@ -389,6 +389,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
   bf16x8* s_stage = reinterpret_cast<bf16x8*>(smem_b);         // [2][SN]
   float* s_tab = reinterpret_cast<float*>(s_stage + 2 * SN);   // [2 sets][bs | bl | br][FT][2][16]
   float* s_red = s_tab + 2 * 3 * FT * COP;                     // [2 sets][4 waves][COP][2]
+  float* s_ctr = s_red + 2 * 4 * COP * 2;                      // [4 sets][2 half-waves][16]: ELU(bias), the centre the
+                                                               // activations are stored about (conv_epilogue.hpp)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -475,7 +477,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
   }
 
     // epilogue tables of the current tile, set TS: producer wave rw builds output row f0 + rw, lane = output channel
-#define TILE_TABLES(TS)                                                                                         \
+#define TILE_TABLES(TS, CS)                                                                                     \
   {                                                                                                             \
     if (lane < COP) {                                                                                           \
       const int f_ = f0 + rw;                                                                                   \
@@ -505,6 +507,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
       tb_[slot_] = (b3[0] + b3[1] + b3[2]) * wsc_;                                                              \
       tb_[FT * COP + slot_] = b3[0] * wsc_;                                                                     \
       tb_[2 * FT * COP + slot_] = b3[2] * wsc_;                                                                 \
+      if (rw == 0) s_ctr[(CS) * COP + slot_] = a.act ? elu_fast(a.bias[cg * COP + lane]) : 0.f;                 \
     }                                                                                                           \
   }
 
@@ -526,7 +529,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
     TILE_COORDS(k)
     TILE_SETUP()
     DMA_STAGE(0, 0)
-    TILE_TABLES(0)
+    TILE_TABLES(0, 0)
     unsigned g = 0, ti = 0;
     // finished tiles whose statistics are still to be flushed: p1 = previous tile, p2 = the one before.  With the
     // deferred epilogue the partials of tile j are complete only after chunk 1 of tile j + 1.
@@ -550,7 +553,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
             TILE_COORDS(k)
             TILE_SETUP()
             DMA_STAGE(0, (g + 1) & 1)
-            TILE_TABLES((ti + 1) & 1)
+            TILE_TABLES((ti + 1) & 1, (ti + 1) & 3)
           }
         }
       }
@@ -586,6 +589,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
       for (int i = 0; i < 8; ++i) { es.s1[i] = f32x2{0.f, 0.f}; es.s2[i] = f32x2{0.f, 0.f}; }
       es.okk0 = es.okk1 = false;
       es.dsc = F16 ? a.descale : 1.f;
+      es.ctr = s_ctr;
 #pragma unroll
       for (int i = 0; i < 2; ++i) { es.PH[i][0] = es.PH[i][1] = es.PL[i][0] = es.PL[i][1] = 0u; }
       __amdgpu_buffer_rsrc_t prs_h = make_rsrc_u(reinterpret_cast<unsigned long long>(a.out), 0u);
@@ -636,6 +640,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
           es.pvo0 = (unsigned)(f0 * Tp + t) * 16u + (unsigned)(half + (cbase >> 3)) * OP16;
           es.okk0 = cbase + (0 + half) * 8 < a.Cout;
           es.okk1 = cbase + (2 + half) * 8 < a.Cout;
+          es.ctr = s_ctr + (ti & 3) * COP;
           const unsigned long long pa = reinterpret_cast<unsigned long long>(a.out) +
                                         (unsigned long long)n * a.out_bstride * 4ull + (unsigned long long)(a.out_c0 >> 3) * OP16;
           const unsigned nrec = (unsigned)(a.Cout >> 3) * OP16;
@@ -697,7 +702,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
         }
         STAMP();
         if (!(a.dbg & 4))
-          conv_epilogue_rows_nb<2, F16>(a, acc, n, cg, f0, t0 + 32 * wave, lane, s_red + (ti & 1) * (4 * COP * 2) + wave * (COP * 2), FTR);
+          conv_epilogue_rows_nb<2, F16>(a, acc, n, cg, f0, t0 + 32 * wave, lane, s_red + (ti & 1) * (4 * COP * 2) + wave * (COP * 2), FTR,
+                                        a.act ? s_ctr + (ti & 3) * COP : nullptr);
         STAMP();
         if (stamp) a.dbg_buf[63] = si;
 #undef STAMP
@@ -799,7 +805,7 @@ __global__ __launch_bounds__(288) void conv_wprep_k(const float* wf, const doubl
 }
 
 static size_t dma2_lds_bytes(int NR) {
-  return (size_t)(2 * (2 * NR * 2 * TW + 2 * 9 * 2 * 32)) * 16 + (size_t)(2 * 3 * FT * 32 + 2 * 4 * 32 * 2) * sizeof(float);
+  return (size_t)(2 * (2 * NR * 2 * TW + 2 * 9 * 2 * 32)) * 16 + (size_t)(2 * 3 * FT * 32 + 2 * 4 * 32 * 2 + 4 * 32) * sizeof(float);
 }
 
 static size_t dma_lds_bytes(int NR) {

@@ -153,8 +153,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
   bf16x8* s_stage = reinterpret_cast<bf16x8*>(smem_b);         // [NS][SN]
   float* s_tab = reinterpret_cast<float*>(s_stage + NS * SN);  // [NS sets][bs | bl | br][FT][2][16] (written NS - 1 chunks ahead)
   float* s_red = s_tab + NS * 3 * FT * COP;                    // [2 sets][4 waves][COP][2]
-  float* s_ctr = s_red + 2 * 4 * COP * 2;                      // [4 sets][2 half-waves][16]: centres of the statistics (a set
-                                                               // lives from the tile's first DMA to its float64 flush)
+  float* s_ctr = s_red + 2 * 4 * COP * 2;                      // [4 sets][2 half-waves][16]: ELU(bias) per channel, the centre the
+                                                               // activations are stored about
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -280,40 +280,30 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
       tb_[slot_] = b3[0] + b3[1] + b3[2];                                                                       \
       tb_[FT * COP + slot_] = b3[0];                                                                            \
       tb_[2 * FT * COP + slot_] = b3[2];                                                                        \
-      /* centre of this tile's statistics per channel: ELU(bias) -- the pre-activation of normalised inputs has mean   */ \
+      /* centre of the stored activations per channel: ELU(bias) -- the pre-activation of normalised inputs has mean   */ \
       /* bias exactly.  (NOT the accumulator start value: bias - sum W' mean_in is far from the output when |mean_in|  */ \
-      /* >> std_in, and (x - c)^2 would then lose what the centring is there to keep.)                                 */ \
+      /* >> std_in.)                                                                                                    */ \
       if (rw == 0) s_ctr[(CS) * COP + slot_] = elu_fast(a.bias[cg * COP + lane]);                               \
     }                                                                                                           \
   }
 
-    // float64 statistics of finished tile number J of this workgroup (producer wave 0, lane = channel): the four
-    // consumer partials are moments about the tile's centres (s_ctr set J & 1): un-centre in float64, then two atomics
+    // float64 statistics of finished tile number J of this workgroup (producer wave 0): sum of the four consumer partials
+    // (the partials are sums of the STORED, centred values: conv_epilogue_rows_nb's s_ctr)
 #define TILE_STATS(J)                                                                                           \
   {                                                                                                             \
-    if (a.act && rw == 0 && lane < COP) {                                                                       \
+    if (a.act && rw == 0) {                                                                                     \
       const unsigned kj_ = slot + (unsigned)(J) * (unsigned)nslots;                                             \
       const unsigned grp_ = kj_ / per;                                                                          \
-      unsigned tile_ = kj_ - grp_ * per;                                                                        \
+      const unsigned tile_ = kj_ - grp_ * per;                                                                  \
       const int pn_ = (int)(grp_ * 8u + xcd);                                                                   \
-      const int pf0_ = (int)(tile_ % (unsigned)a.nty) * FT;                                                     \
-      tile_ /= (unsigned)a.nty;                                                                                 \
-      const int pcg_ = (int)(tile_ % (unsigned)a.ncg);                                                          \
-      const int pt0_ = (int)(tile_ / (unsigned)a.ncg) * TT;                                                     \
+      const int pcg_ = (int)((tile_ / (unsigned)a.nty) % (unsigned)a.ncg);                                      \
       const float* sr_ = s_red + ((J) & 1) * (4 * COP * 2);                                                     \
-      const int co = pcg_ * COP + lane;                                                                         \
+      const int co_l = lane >> 1, which = lane & 1;                                                             \
+      const int co = pcg_ * COP + co_l;                                                                         \
       if (co < a.Cout) {                                                                                        \
-        float t1_ = 0.f, t2_ = 0.f;                                                                             \
-        for (int w = 0; w < 4; ++w) { t1_ += sr_[(w * COP + lane) * 2]; t2_ += sr_[(w * COP + lane) * 2 + 1]; } \
-        const int rows_ = (a.Fout - pf0_) < FT ? (a.Fout - pf0_) : FT;                                          \
-        const int frames_ = (T - pt0_) < TT ? (T - pt0_) : TT;                                                  \
-        /* accumulator order: channel co = (i&3) + 8*(i>>2) + 4*h */                                            \
-        const float c_ = s_ctr[((J) & 3) * COP + ((lane >> 2) & 1) * 16 + (lane & 3) + 4 * (lane >> 3)];        \
-        double sx_, sxx_;                                                                                       \
-        stats_uncentre((double)t1_, (double)t2_, (double)c_, (double)rows_ * (double)frames_, sx_, sxx_);       \
-        double* o_ = a.out_stats + ((long long)pn_ * a.out_sstride + a.out_c0 + co) * 2;                        \
-        unsafeAtomicAdd(o_, sx_);                                                                               \
-        unsafeAtomicAdd(o_ + 1, sxx_);                                                                          \
+        float tot = 0.f;                                                                                        \
+        for (int w = 0; w < 4; ++w) tot += sr_[(w * COP + co_l) * 2 + which];                                   \
+        unsafeAtomicAdd(a.out_stats + ((long long)pn_ * a.out_sstride + a.out_c0 + co) * 2 + which, (double)tot); \
       }                                                                                                         \
     }                                                                                                           \
   }

@@ -189,13 +189,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_e(unsigned long long
                                            __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
 }
 
-// Tile partials of centred moments -> contribution to the global (sum x, sum x^2), in float64:
-//   sum x = t1 + cnt c ;  sum x^2 = t2 + 2 c t1 + cnt c^2     (t1 = sum (x - c), t2 = sum (x - c)^2 over cnt elements)
-__device__ __forceinline__ void stats_uncentre(double t1, double t2, double c, double cnt, double& sx, double& sxx) {
-  sx = t1 + cnt * c;
-  sxx = t2 + 2.0 * c * t1 + cnt * c * c;
-}
-
 // s_red: [COP][2] floats of THIS wave's row (the caller adds the rows of a tile).  COP = NCO * 32.
 // s_bias: optional LDS copy of this group's bias [COP].
 // s_b4:   optional LDS table [COP][4] = (bL, bC, bR, bL + bC + bR) of THIS wave's row: the bias plus the folded
@@ -203,8 +196,12 @@ __device__ __forceinline__ void stats_uncentre(double t1, double t2, double c, d
 //         (whose left / right taps fall into the zero padding) can drop their share.
 // OCTP:   0, or the number of bf16 parts of the oct-layout output path to compile: 2 (bf16x3: hi | lo) or 3 (bf16x6:
 //         hi | mid | lo) or 4 (f16x3: fp16 hi | lo); a.out_oct selects it at run time.
-// CENTRE: accumulate the statistics of (x - c) with c = ELU(bias) of the channel (the exact mean of the pre-activation
-//         when the inputs are instance-normalised); the caller un-centres with stats_uncentre.
+// CENTRE: the activation is STORED centred, y = ELU(conv + bias) - ELU(bias) (ELU(bias) is the activation at the exact
+//         mean of the pre-activation when the inputs are instance-normalised), and the statistics are those of y.  Every
+//         consumer of an activated conv output instance-normalises it, and the instance norm does not see a per-channel
+//         constant, so nothing downstream changes mathematically -- but (i) the one-pass float32 partial sums of y^2 no
+//         longer lose mean^2 / var of their accuracy and (ii) the folded modes' products W' * y cancel against a much
+//         smaller shift.  (Raw, un-normalised consumers only ever read act = 0 outputs and the TCN output.)
 template <int NCO, int NSEG, int OCTP, bool ACT, bool CENTRE = false>
 __device__ __forceinline__ void conv_epilogue_impl(const ConvArgs& a, f32x16_t (&acc)[NCO][NSEG], int n, int cg, int f,
                                                    int t0, bool row_ok, int lane, float* s_red,
@@ -265,10 +262,10 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvArgs& a, f32x16_t (
           float x = acc[j][s][r] + bs[r];
           if (t_edge) x -= (t == 0 ? bl[r] : 0.f) + (t == T - 1 ? br[r] : 0.f);
           if (ACT) x = elu_fast(x);
+          if (CENTRE && ACT) x -= elu_fast(bs[r]);            // stored CENTRED (see conv_epilogue_impl's header)
           v[r] = x;
           const int kr = j * 32 + (r & 3) + 8 * (r >> 2);
-          const float xd = (CENTRE && ACT) ? x - elu_fast(bs[r]) : x;
-          const float vm = (unmasked || (tm[s] && (full_c || kr < cmax))) ? xd : 0.f;
+          const float vm = (unmasked || (tm[s] && (full_c || kr < cmax))) ? x : 0.f;
           s1[r] += vm;
           s2[r] = fmaf(vm, vm, s2[r]);
         }
@@ -334,11 +331,10 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvArgs& a, f32x16_t (
 #pragma unroll
         for (int s = 0; s < NSEG; ++s) {
           float v = acc[j][s][r] + bs[r];
-          if (ACT) v = elu_fast(v);
+          if (ACT) v = elu_fast(v) - cr;
           if (!(a.dbg & 8)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff[s] + coff, 0, 0);
-          const float vd = v - cr;
-          a1 += vd;
-          a2 = fmaf(vd, vd, a2);
+          a1 += v;
+          a2 = fmaf(v, v, a2);
         }
       } else {
         const bool cok = full_c || (kr < cmax);
@@ -347,9 +343,9 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvArgs& a, f32x16_t (
           const int t = t0 + s * 32 + l31;
           float v = acc[j][s][r] + bs[r];
           if (t_edge) v -= (t == 0 ? bl[r] : 0.f) + (t == T - 1 ? br[r] : 0.f);
-          if (ACT) v = elu_fast(v);
+          if (ACT) v = elu_fast(v) - cr;
           if (!(a.dbg & 8)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff[s] + coff, 0, 0);
-          const float vm = (tm[s] && cok) ? v - cr : 0.f;
+          const float vm = (tm[s] && cok) ? v : 0.f;
           a1 += vm;
           a2 = fmaf(vm, vm, a2);
         }
@@ -435,7 +431,7 @@ __device__ __forceinline__ void conv_epilogue_rows_impl(const ConvArgs& a, f32x1
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       float x = (F16 ? acc[r][i] * a.descale : acc[r][i]) + bs[i];       // f16x3: the weights carry a power-of-two scale
-      if (ACT) x = elu_fast(x);
+      if (ACT) x = elu_fast(x) - elu_fast(a.bias[cbase + (i & 3) + 8 * (i >> 2) + 4 * half]);   // stored centred
       v[i] = x;
       const float vm = MASKED ? x * m : x;
       s1[i] += vm;
@@ -550,10 +546,8 @@ __device__ __forceinline__ void conv_acc_init_rows(f32x16_t (&acc)[4], int tw, i
   }
 }
 
-// s_ctr (optional): 16 floats per half-wave in accumulator order, the CENTRE c of this tile's statistics per channel.
-// The partial sums are then of (x - c) and (x - c)^2; whoever adds the tile's partials to the global float64 moments
-// converts them back (stats_uncentre).  With c near the channel mean the float32 partials keep their accuracy when
-// |mean| >> std (one-pass E[x^2] - mean^2 from float32 partials otherwise loses mean^2 / var of it).
+// s_ctr (optional): 16 floats per half-wave in accumulator order, the centre c = ELU(bias) per channel: the row is stored
+// as x - c and the statistics are those of the stored values (conv_epilogue_impl's CENTRE note).
 template <bool MASKED, bool ACT, int NP, bool F16 = false>
 __device__ __forceinline__ void conv_epilogue_rows_nb_impl(const ConvArgs& a, f32x16_t (&acc)[4], int cg, int f0, int tw,
                                                            int lane, const __amdgpu_buffer_rsrc_t (&rs)[3],
@@ -602,9 +596,9 @@ __device__ __forceinline__ void conv_epilogue_rows_nb_impl(const ConvArgs& a, f3
         x.x = x.x > 0.f ? x.x : e.x;
         x.y = x.y > 0.f ? x.y : e.y;
       }
+      x = x - ctr[i2];                                 // stored centred (zeros without s_ctr)
       v[2 * i2] = x.x; v[2 * i2 + 1] = x.y;
-      const f32x2_e xd = x - ctr[i2];
-      const f32x2_e vm = MASKED ? xd * m2 : xd;
+      const f32x2_e vm = MASKED ? x * m2 : x;
       s1[i2] = s1[i2] + vm;
       s2[i2].x = fmaf(vm.x, vm.x, s2[i2].x);
       s2[i2].y = fmaf(vm.y, vm.y, s2[i2].y);
@@ -692,6 +686,7 @@ struct EpiState {
   unsigned PH[2][2], PL[2][2];
   bool okk0, okk1;          // this lane's octet of pair 0 / 1 exists (Cout)
   float dsc;                // f16x3: 2^-k of the layer's weight scale (1 otherwise)
+  const float* ctr;         // LDS: ELU(bias) per channel in accumulator order [2 half-waves][16]; rows are stored centred
 };
 
 template <int ROW, int NSTEP, bool F16 = false>
@@ -713,6 +708,10 @@ __device__ __forceinline__ void conv_epi_step(int st, f32x16_t (&prev)[4], EpiSt
       ex = ex - kone;
       x.x = x.x > 0.f ? x.x : ex.x;
       x.y = x.y > 0.f ? x.y : ex.y;
+      {                                                  // stored centred (conv_epilogue_impl's CENTRE note)
+        const float2 c2 = reinterpret_cast<const float2*>(e.ctr + (lane >> 5) * 16)[q];
+        x.x -= c2.x; x.y -= c2.y;
+      }
       prev[ROW][2 * q] = x.x; prev[ROW][2 * q + 1] = x.y;
       const float mr = (ROW < e.prows) ? e.pmt : 0.f;
       const f32x2_e m2 = {mr, mr};
