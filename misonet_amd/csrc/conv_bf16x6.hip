@@ -137,14 +137,28 @@ __device__ __forceinline__ void chunk_mfma6(f32x16 (&acc)[4], const bf16x8* sx, 
 // the consumers' 4.2k-cycle MFMA phase does not shrink because its length is set by the power limit, not by the operand
 // fetch; (ii) the tile epilogue on the producer waves through an LDS mailbox -- 4 % slower: a producer wave needs 3.3k
 // cycles per accumulator row behind its DMA issue.
-template <int MODE>
+// LDS-DMA instructions producer wave rw issues per chunk (DMA_STAGE below): three input parts + the weight image
+constexpr int x6_dma_count(int XN, int rw) {
+  int nx = 0, nw = 0;
+  for (int i = 0; (i * 4 + rw) * 64 < XN; ++i) ++nx;
+  for (int i = 0; (i * 4 + rw) * 64 < X6_WU; ++i) ++nw;
+  return 3 * nx + nw;
+}
+
+template <int N>
+__device__ __forceinline__ void x6_wait_vm() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int MODE, int MG>
 __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int nslots) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (the LDS-DMA builtin has no host form)
   constexpr int COP = 32;
   constexpr int SF = MODE == 1 ? 2 : 1;
   constexpr bool TR2 = MODE == 2;
   constexpr int NR = MODE == 0 ? 6 : (MODE == 1 ? 9 : 3);      // staged input rows of a 4-row tile
-  constexpr int NS = 2;                                        // stages
+  constexpr int NS = (MG && MODE != 1) ? 3 : 2;                // stages (three 9-row stages do not fit the LDS)
   constexpr int XN = NR * X6_TW;                               // units per input part image
   constexpr int SN = 3 * XN + X6_WU;                           // units per stage: [x_h | x_m | x_l | w]
   constexpr int NXI = (XN + 255) / 256;
@@ -240,7 +254,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
     const unsigned wsoff_ = (unsigned)(KC) * (unsigned)X6_WU * 16u;                                             \
     _Pragma("unroll") for (int i = 0; i < NWI; ++i) {                                                           \
       const int ub = (i * 4 + rw) * 64;                                                                         \
-      if (ub < X6_WU) {                                                                                         \
+      if (ub < X6_WU && !(a.dbg & 128)) {                                                                       \
         if (ub + 64 <= X6_WU || ub + lane < X6_WU)                                                              \
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, MN_LDS(st_ + 3 * XN + ub), 16, wo + (unsigned)i * 4096u, \
                                                    wsoff_, 0, 0);                                               \
@@ -330,7 +344,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
     int bkc = -1;                                              // its chunk index (-1 before the first barrier)
     for (unsigned b = 0; b <= G; ++b) {
       STAMP(bt);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // everything issued has landed (hipcc does not count LDS-DMA loads)
+      // chunk b has landed (hipcc does not count LDS-DMA loads).  With three stages the batch of chunk b + 1, issued in
+      // the previous iteration, may stay in flight: loads retire in order, so "at most that batch's count outstanding"
+      // implies that everything older is in the LDS.
+      if (NS == 3 && b + 1 < G) {
+        if (rw == 0) x6_wait_vm<x6_dma_count(XN, 0)>();
+        else if (rw == 1) x6_wait_vm<x6_dma_count(XN, 1)>();
+        else if (rw == 2) x6_wait_vm<x6_dma_count(XN, 2)>();
+        else x6_wait_vm<x6_dma_count(XN, 3)>();
+      } else {
+        x6_wait_vm<0>();
+      }
       STAMP(bt);
       __syncthreads();                                         // barrier b
       STAMP(bt);
@@ -470,14 +494,17 @@ __global__ __launch_bounds__(288) void conv_wprep6_k(const float* wf, const doub
   btab[(long long)n * btab_nstride + ((long long)blockIdx.y * ncg * 32 + cg * 32 + co) * 9 + tap] = (float)bsum;
 }
 
-static size_t x6_lds_bytes(int NR) {
-  const int ns = 2;                                  // two stages + epilogue tables + statistics partials
+static size_t x6_lds_bytes(int NR, int mg) {
+  const int ns = (mg && NR != 9) ? 3 : 2;            // stages + epilogue tables + statistics partials
   return (size_t)(ns * (3 * NR * X6_TW + X6_WU)) * 16 + (size_t)(ns * 3 * FT * 32 + 2 * 4 * 32 * 2 + 4 * 32) * sizeof(float);
 }
 
 template <int MODE>
 static hipError_t x6_set_attr() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6<MODE>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6<MODE, 0>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6<MODE, 1>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -538,11 +565,24 @@ hipError_t launch_conv_bf16x6(const ConvArgs& a_in, int n_samples, hipStream_t s
   int nslots = g_cus / 8;
   if (nslots < 1) nslots = 1;
   if (nslots > nk_max) nslots = (int)nk_max;
+  {
+    static int cap = -1;                                           // MISONET_X6_SLOTS: workgroups per XCD (experiments)
+    if (cap < 0) { const char* e = getenv("MISONET_X6_SLOTS"); cap = e ? atoi(e) : 0; }
+    if (cap > 0 && nslots > cap) nslots = cap;
+  }
   const dim3 pgrid((unsigned)(8 * nslots), 1, 1);
   const int mode = a.tr2 ? 2 : (a.sf == 2 ? 1 : 0);
-  if (mode == 0) hipLaunchKernelGGL((conv3x3_bf16x6<0>), pgrid, dim3(512), x6_lds_bytes(6), s, a, nslots);
-  else if (mode == 1) hipLaunchKernelGGL((conv3x3_bf16x6<1>), pgrid, dim3(512), x6_lds_bytes(9), s, a, nslots);
-  else hipLaunchKernelGGL((conv3x3_bf16x6<2>), pgrid, dim3(512), x6_lds_bytes(3), s, a, nslots);
+  static int mg = -1;
+  if (mg < 0) { const char* e = getenv("MISONET_X6_MERGED"); mg = e ? atoi(e) : 0; }
+  if (mg) {
+    if (mode == 0) hipLaunchKernelGGL((conv3x3_bf16x6<0, 1>), pgrid, dim3(512), x6_lds_bytes(6, 1), s, a, nslots);
+    else if (mode == 1) hipLaunchKernelGGL((conv3x3_bf16x6<1, 1>), pgrid, dim3(512), x6_lds_bytes(9, 1), s, a, nslots);
+    else hipLaunchKernelGGL((conv3x3_bf16x6<2, 1>), pgrid, dim3(512), x6_lds_bytes(3, 1), s, a, nslots);
+  } else {
+    if (mode == 0) hipLaunchKernelGGL((conv3x3_bf16x6<0, 0>), pgrid, dim3(512), x6_lds_bytes(6, 0), s, a, nslots);
+    else if (mode == 1) hipLaunchKernelGGL((conv3x3_bf16x6<1, 0>), pgrid, dim3(512), x6_lds_bytes(9, 0), s, a, nslots);
+    else hipLaunchKernelGGL((conv3x3_bf16x6<2, 0>), pgrid, dim3(512), x6_lds_bytes(3, 0), s, a, nslots);
+  }
   if (do_tl && tl_buf) {
     unsigned long long h[64];
     (void)hipStreamSynchronize(s);
