@@ -131,19 +131,31 @@ __device__ __forceinline__ void chunk_mfma6(f32x16 (&acc)[4], const bf16x8* sx, 
 // arrive at it when chunk b has landed, consumers when they are done reading chunk b - 1; behind it the producers put
 // chunk b + 1 into the stage that chunk b - 1 occupied (the first chunk of the next tile is in flight during an epilogue).
 //
-// Measured and NOT kept (git history): (i) a third stage with the first operands of chunk b
-// fetched during the last steps of chunk b - 1, so that the matrix pipe runs through the barrier -- 10 % SLOWER on the
-// same box: the producers' per-chunk loop (DMA issue ~2.8k cycles + landing + barrier) becomes the critical path, and
-// the consumers' 4.2k-cycle MFMA phase does not shrink because its length is set by the power limit, not by the operand
-// fetch; (ii) the tile epilogue on the producer waves through an LDS mailbox -- 4 % slower: a producer wave needs 3.3k
-// cycles per accumulator row behind its DMA issue.
+// Where a chunk period goes (MISONET_TIMELINE=96 with MISONET_WS_DEBUG ablations, tools/gpu_x6_ablate.sh; Cin = 96,
+// F = 63, all 256 CUs busy): 4.6k cycles = 3.9k of MFMA phase (108 MFMAs at 36 instead of 32 cycles: operand fill behind
+// the barrier + LDS waits) + 0.7k at the barrier waiting for the stage.  With the DMA off the period is 4.1k, with the
+// MFMAs off 4.1-4.4k: the LDS-DMA stream of a CU (51 KB per chunk) runs at 17 B/clk when 8 CUs are active and at ~12 B/clk
+// when all 256 are (tools/gpu_x6_slots.sh), i.e. the kernel is CO-LIMITED by the matrix pipe and by bytes through the
+// texture path; without the 13.8 KB weight image of a chunk the period drops to 4.25k.
+//
+// Measured and NOT kept (git history):
+//   (i)   a third stage, (a) with the first operands of chunk b fetched during the last steps of chunk b - 1 (10 % slower)
+//         and (b) with `s_waitcnt vmcnt(N)` leaving the newest batch in flight across the barrier (no change): the DMA
+//         stream is throughput-bound, not latency-bound, so a deeper ring buys nothing;
+//   (ii)  the tile epilogue on the producer waves through an LDS mailbox -- 4 % slower;
+//   (iii) phases A and B of a staged row merged into one step (longer steps, first operands first): MFMA phase 4.14k
+//         instead of 3.91k cycles, 2 % slower;
+//   (iv)  PLANAR float32 activations (4 instead of 6 bytes per element in HBM and through the texture path), split into
+//         the three bf16 pieces by the producer waves (8 buffer_load_dwordx4 per lane and chunk, ~180 VALU, 12
+//         ds_write_b128): parity-green, 6 % slower -- beside an MFMA-saturating wave a producer instruction issues every
+//         ~10 cycles, so ~300 instructions per chunk take 3k+ cycles; raising the producers' s_setprio changes nothing.
 template <int N>
 __device__ __forceinline__ void x6_wait_vm() {
   static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int MODE, int PL>
+template <int MODE>
 __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int nslots) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (the LDS-DMA builtin has no host form)
   constexpr int COP = 32;
@@ -197,222 +209,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
     t0 = (int)(tile_ / (unsigned)a.ncg) * TT;                                                                   \
   }
 
-  if (producer && PL) {
-    // ====================================== producers, planar float32 input ======================================
-    // The activations stay PLANAR float32 in HBM (4 bytes per element instead of the 6 of the oct3 layout: the layers
-    // with one output-channel group read their input once and are within 2x of the HBM roofline in oct3).  A producer
-    // lane owns one 16-byte aligned group of 4 frames of one staged row: per chunk it loads the 8 channel planes of the
-    // group (8 x buffer_load_dwordx4 into registers, one K-chunk ahead of its use), splits the 32 values exactly into
-    // three bf16 pieces (split3_pair_t) and writes them as 16-byte units into the stage the consumers read -- the same
-    // stage image as the LDS-DMA path.  The per-sample folded weights still arrive by LDS-DMA.
-    //   per barrier period:  split + ds_write chunk b + 1  ->  weight DMA chunk b + 1  ->  x loads of chunk b + 2
-    // (VMEM returns in order: the weight DMA sits BEHIND the loads the split waits for and AHEAD of the loads that may
-    // stay in flight across the barrier, `s_waitcnt vmcnt(loads of one chunk)`).
-    constexpr int GPR = 34;                                    // 4-frame groups per staged row: frames t0 - 4 .. t0 + 131
-    constexpr int NTASK = NR * GPR;
-    constexpr int NRND = (NTASK + 255) / 256;
-    const unsigned P4 = (unsigned)Fin * (unsigned)Tp * 4u;     // bytes per channel plane
-    const unsigned in_rec = (unsigned)Cin * P4;                // channels [in_c0, in_c0 + Cin) of one sample
-    const unsigned wbytes = (unsigned)nchunk * (unsigned)X6_WU * 16u;
-    const unsigned wo = (unsigned)(tid & 255) * 16u;
-    const int btab_parts = nchunk >= 8 ? 4 : (nchunk >= 4 ? 2 : 1);
-    unsigned long long x_base = 0, w_base = 0;
-    int t_r[NRND], t_g[NRND], t_dst[NRND];                     // this lane's tasks: staged row, group, first unit slot - 3
-    unsigned xoff[NRND];                                       // byte offset of (chunk's first channel, row, group)
-    int l_nv[NRND], x_nv[NRND];                                // frames of the group inside the utterance (load tile / in regs)
-    bool l_edge = false, x_edge = false;                       // the tile reaches past the last frame (uniform)
-    u32x4_t xr[NRND][8];
-#pragma unroll
-    for (int q = 0; q < NRND; ++q) {
-      const int id = q * 256 + (tid & 255);
-      t_r[q] = id / GPR;
-      t_g[q] = id - t_r[q] * GPR;
-      t_dst[q] = id < NTASK ? t_r[q] * X6_TW + 4 * t_g[q] - 3 : -1000;
-      xoff[q] = 0x80000000u; l_nv[q] = x_nv[q] = 4;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) xr[q][c] = u32x4_t{0u, 0u, 0u, 0u};
-    }
-
-    // epilogue tables of the cursor's tile: as in the LDS-DMA path below
-#define TILE_TABLES(TS, CS)                                                                                      \
-  {                                                                                                             \
-    if (lane < COP) {                                                                                           \
-      const int f_ = f0 + rw;                                                                                   \
-      float b3[3] = {0.f, 0.f, 0.f};                                                                            \
-      if (a.btab) {                                                                                             \
-        const float* bt_ = a.btab + (long long)n * a.btab_nstride + (long long)(cg * COP + lane) * 9;           \
-        const long long pst_ = (long long)a.ncg * COP * 9;                                                      \
-        _Pragma("unroll") for (int kf = 0; kf < 3; ++kf) {                                                      \
-          bool ok_;                                                                                             \
-          if (TR2) {                                                                                            \
-            const int q_ = f_ + kf - 2;                                                                         \
-            ok_ = (q_ >= 0) && !(q_ & 1) && (q_ >> 1) < Fin;                                                    \
-          } else {                                                                                              \
-            const int fi_ = SF * f_ + kf - a.padf;                                                              \
-            ok_ = fi_ >= 0 && fi_ < Fin;                                                                        \
-          }                                                                                                     \
-          _Pragma("unroll") for (int kt = 0; kt < 3; ++kt) {                                                    \
-            float v_ = bt_[kt * 3 + kf];                                                                        \
-            for (int p_ = 1; p_ < btab_parts; ++p_) v_ += bt_[p_ * pst_ + kt * 3 + kf];                          \
-            b3[kt] += ok_ ? v_ : 0.f;                                                                           \
-          }                                                                                                     \
-        }                                                                                                       \
-      }                                                                                                         \
-      b3[1] += a.bias[cg * COP + lane];                                                                         \
-      const int slot_ = (rw * 2 + ((lane >> 2) & 1)) * 16 + (lane & 3) + 4 * (lane >> 3);                       \
-      float* tb_ = s_tab + (TS) * (3 * FT * COP);                                                               \
-      tb_[slot_] = b3[0] + b3[1] + b3[2];                                                                       \
-      tb_[FT * COP + slot_] = b3[0];                                                                            \
-      tb_[2 * FT * COP + slot_] = b3[2];                                                                        \
-      if (rw == 0) s_ctr[(CS) * COP + slot_] = elu_fast(a.bias[cg * COP + lane]);                               \
-    }                                                                                                           \
-  }
-#define TILE_STATS(J)                                                                                           \
-  {                                                                                                             \
-    if (a.act && rw == 0) {                                                                                     \
-      const unsigned kj_ = slot + (unsigned)(J) * (unsigned)nslots;                                             \
-      const unsigned grp_ = kj_ / per;                                                                          \
-      const unsigned tile_ = kj_ - grp_ * per;                                                                  \
-      const int pn_ = (int)(grp_ * 8u + xcd);                                                                   \
-      const int pcg_ = (int)((tile_ / (unsigned)a.nty) % (unsigned)a.ncg);                                      \
-      const float* sr_ = s_red + ((J) & 1) * (4 * COP * 2);                                                     \
-      const int co_l = lane >> 1, which = lane & 1;                                                             \
-      const int co = pcg_ * COP + co_l;                                                                         \
-      if (co < a.Cout) {                                                                                        \
-        float tot = 0.f;                                                                                        \
-        for (int w = 0; w < 4; ++w) tot += sr_[(w * COP + co_l) * 2 + which];                                   \
-        unsafeAtomicAdd(a.out_stats + ((long long)pn_ * a.out_sstride + a.out_c0 + co) * 2 + which, (double)tot); \
-      }                                                                                                         \
-    }                                                                                                           \
-  }
-
-    // load cursor: the next chunk whose input goes into the registers
-    unsigned lc_g = 0, lc_t = 0;
-    int lc_kc = 0;
-    int nld = 0;                                               // loads issued by the latest LOAD_NEXT (0 at the tail)
-#define LOAD_NEXT()                                                                                             \
-  {                                                                                                             \
-    nld = 0;                                                                                                    \
-    if (lc_g < G) {                                                                                             \
-      if (lc_kc == 0) {                                                                                         \
-        TILE_COORDS(slot + lc_t * (unsigned)nslots)                                                             \
-        const int fin0_ = TR2 ? (f0 >> 1) - 1 : SF * f0 - a.padf;                                               \
-        x_base = reinterpret_cast<unsigned long long>(a.in) + (unsigned long long)n * a.in_bstride * 4ull +     \
-                 (unsigned long long)a.in_c0 * P4;                                                              \
-        l_edge = t0 + 132 > T;                                                                                  \
-        _Pragma("unroll") for (int q = 0; q < NRND; ++q) {                                                      \
-          const int fin = fin0_ + t_r[q];                                                                       \
-          const int t4 = t0 - 4 + 4 * t_g[q];                                                                   \
-          const bool ok = t_dst[q] > -1000 && fin >= 0 && fin < Fin && t4 >= 0 && t4 < T;                       \
-          xoff[q] = ok ? (unsigned)(fin * Tp + t4) * 4u : 0x80000000u;                                          \
-          l_nv[q] = T - t4;                                                                                     \
-        }                                                                                                       \
-      }                                                                                                         \
-      if (!(a.dbg & 64)) {                                                                                      \
-        /* built at the use: a descriptor carried across the tile branch ends up in VGPRs (waterfall loops) */  \
-        const __amdgpu_buffer_rsrc_t rs_x = make_rsrc_e(x_base, in_rec);                                        \
-        _Pragma("unroll") for (int q = 0; q < NRND; ++q) {                                                      \
-          _Pragma("unroll") for (int c = 0; c < 8; ++c)                                                         \
-            xr[q][c] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xoff[q] + (unsigned)c * P4, 0, 0);           \
-        }                                                                                                       \
-        nld = 8 * NRND;                                                                                         \
-      }                                                                                                         \
-      _Pragma("unroll") for (int q = 0; q < NRND; ++q) { xoff[q] += 8u * P4; x_nv[q] = l_nv[q]; }               \
-      x_edge = l_edge;                                                                                          \
-      ++lc_g;                                                                                                   \
-      if (++lc_kc == nchunk) { lc_kc = 0; ++lc_t; }                                                             \
-    }                                                                                                           \
-  }
-
-    // write cursor: the next chunk to put into its LDS stage (input from the registers, weights by LDS-DMA)
-    unsigned wc_g = 0, wc_t = 0;
-    int wc_kc = 0;
-#define WRITE_NEXT()                                                                                            \
-  {                                                                                                             \
-    if (wc_g < G) {                                                                                             \
-      if (wc_kc == 0) {                                                                                         \
-        TILE_COORDS(slot + wc_t * (unsigned)nslots)                                                             \
-        w_base = reinterpret_cast<unsigned long long>(a.wps) + (unsigned long long)n * a.wps_nstride +           \
-                 (unsigned long long)cg * wbytes;                                                               \
-        TILE_TABLES(wc_t % NS, wc_t & 3)                                                                        \
-      }                                                                                                         \
-      bf16x8* st_ = s_stage + (wc_g % NS) * SN;                                                                 \
-      if (a.dbg & 512) __builtin_amdgcn_s_setprio(2);                                                           \
-      _Pragma("unroll") for (int q = 0; q < NRND; ++q) {                                                        \
-        _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                         \
-          const int j_ = 4 * t_g[q] + k - 3;                                                                    \
-          if (t_dst[q] > -1000 && j_ >= 0 && j_ < X6_TW) {                                                      \
-            float v_[8];                                                                                        \
-            /* (through a temporary: __builtin_bit_cast of a vector-element lvalue reads element 0) */          \
-            _Pragma("unroll") for (int c = 0; c < 8; ++c) { const unsigned u_ = xr[q][c][k]; v_[c] = __builtin_bit_cast(float, u_); } \
-            if (x_edge) {                                        /* frames >= T are zero padding */             \
-              _Pragma("unroll") for (int c = 0; c < 8; ++c) v_[c] = k < x_nv[q] ? v_[c] : 0.f;                  \
-            }                                                                                                   \
-            u32x4_t h_, m_, l_;                                                                                 \
-            if (a.dbg & 2048) {                                  /* timing experiment: no split */              \
-              _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
-                h_[i] = __builtin_bit_cast(unsigned, v_[2 * i]); m_[i] = __builtin_bit_cast(unsigned, v_[2 * i + 1]); l_[i] = h_[i]; \
-              }                                                                                                 \
-            } else {                                                                                            \
-              _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
-                unsigned hh_, mm_, ll_;                                                                         \
-                split3_pair_t(v_[2 * i], v_[2 * i + 1], hh_, mm_, ll_);                                         \
-                h_[i] = hh_; m_[i] = mm_; l_[i] = ll_;                                                          \
-              }                                                                                                 \
-            }                                                                                                   \
-            u32x4_t* su_ = reinterpret_cast<u32x4_t*>(st_) + t_dst[q] + k;                                      \
-            if (a.dbg & 1024) {                                  /* timing experiment: no LDS writes */         \
-              asm volatile("" ::"v"(h_), "v"(m_), "v"(l_));                                                     \
-            } else {                                                                                            \
-              su_[0] = h_; su_[XN] = m_; su_[2 * XN] = l_;                                                      \
-            }                                                                                                   \
-          }                                                                                                     \
-        }                                                                                                       \
-      }                                                                                                         \
-      if (a.dbg & 512) __builtin_amdgcn_s_setprio(0);                                                           \
-      if (!(a.dbg & 128)) {                                                                                     \
-        const __amdgpu_buffer_rsrc_t rs_w = make_rsrc_e(w_base, wbytes);                                        \
-        const unsigned wsoff_ = (unsigned)wc_kc * (unsigned)X6_WU * 16u;                                        \
-        _Pragma("unroll") for (int i = 0; i < NWI; ++i) {                                                       \
-          const int ub = (i * 4 + rw) * 64;                                                                     \
-          if (ub < X6_WU) {                                                                                     \
-            if (ub + 64 <= X6_WU || ub + lane < X6_WU)                                                          \
-              __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, MN_LDS(st_ + 3 * XN + ub), 16, wo + (unsigned)i * 4096u, \
-                                                       wsoff_, 0, 0);                                           \
-          }                                                                                                     \
-        }                                                                                                       \
-      }                                                                                                         \
-      ++wc_g;                                                                                                   \
-      if (++wc_kc == nchunk) { wc_kc = 0; ++wc_t; }                                                             \
-    }                                                                                                           \
-  }
-
-    LOAD_NEXT()                                                // chunk 0 -> registers
-    WRITE_NEXT()                                               // chunk 0 -> stage 0
-    LOAD_NEXT()                                                // chunk 1 -> registers
-    unsigned bt = 0;                                           // tile of chunk b - 1
-    int bkc = -1;                                              // its chunk index (-1 before the first barrier)
-    for (unsigned b = 0; b <= G; ++b) {
-      STAMP(bt);
-      // the weight image of chunk b has landed; the loads of chunk b + 1 behind it may stay in flight
-      if (nld) x6_wait_vm<8 * NRND>(); else x6_wait_vm<0>();
-      STAMP(bt);
-      __syncthreads();                                         // barrier b (waits for this wave's ds_writes too)
-      STAMP(bt);
-      if (bkc == 0 && bt >= 1) TILE_STATS(bt - 1)
-      WRITE_NEXT()                                             // chunk b + 1
-      STAMP(bt);
-      LOAD_NEXT()                                              // chunk b + 2
-      if (bkc >= 0 && ++bkc == nchunk) { bkc = 0; ++bt; } else if (bkc < 0) bkc = 0;
-    }
-    __syncthreads();                                           // final barrier: the last epilogue is done
-    TILE_STATS(ntile - 1)
-#undef TILE_TABLES
-#undef TILE_STATS
-#undef LOAD_NEXT
-#undef WRITE_NEXT
-  } else if (producer) {
-    // ========================================= producers, oct3 input (LDS-DMA) =========================================
+  if (producer) {
+    // =============================================== producers ===============================================
     const unsigned P16 = (unsigned)Fin * (unsigned)Tp * 16u;                 // bytes per octet plane
     const unsigned in_rec = (unsigned)((a.in_c0 + Cin) >> 3) * P16;
     const unsigned long long part_b = (unsigned long long)(a.in_sstride >> 3) * P16;   // bytes between the parts
@@ -697,10 +495,7 @@ static size_t x6_lds_bytes(int NR) {
 
 template <int MODE>
 static hipError_t x6_set_attr() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6<MODE, 0>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6<MODE, 1>),
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6<MODE>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -732,14 +527,7 @@ hipError_t launch_conv_wprep6(const ConvArgs& a, const float* wf, int n_samples,
 
 hipError_t launch_conv_bf16x6(const ConvArgs& a_in, int n_samples, hipStream_t s) {
   ConvArgs a = a_in;
-  if (!a.wps || a.cop != 32 || (a.Cin & 7)) return hipErrorInvalidValue;
-  if (a.in_oct == 3) {
-    if ((a.in_c0 & 7) || (a.in_sstride & 7)) return hipErrorInvalidValue;
-  } else if (a.in_oct == 0) {                    // planar float32: 16-byte aligned 4-frame groups
-    if ((a.Tp & 3) || (a.in_bstride & 3) || (reinterpret_cast<unsigned long long>(a.in) & 15)) return hipErrorInvalidValue;
-  } else {
-    return hipErrorInvalidValue;
-  }
+  if (a.in_oct != 3 || !a.wps || a.cop != 32 || (a.Cin & 7) || (a.in_c0 & 7) || (a.in_sstride & 7)) return hipErrorInvalidValue;
   if (a.out_oct && (a.out_oct != 3 || (a.Cout & 7) || (a.out_c0 & 7) || (a.out_sstride & 7))) return hipErrorInvalidValue;
   {
     static int dbg = -1;
@@ -775,15 +563,9 @@ hipError_t launch_conv_bf16x6(const ConvArgs& a_in, int n_samples, hipStream_t s
   }
   const dim3 pgrid((unsigned)(8 * nslots), 1, 1);
   const int mode = a.tr2 ? 2 : (a.sf == 2 ? 1 : 0);
-  if (a.in_oct == 0) {
-    if (mode == 0) hipLaunchKernelGGL((conv3x3_bf16x6<0, 1>), pgrid, dim3(512), x6_lds_bytes(6), s, a, nslots);
-    else if (mode == 1) hipLaunchKernelGGL((conv3x3_bf16x6<1, 1>), pgrid, dim3(512), x6_lds_bytes(9), s, a, nslots);
-    else hipLaunchKernelGGL((conv3x3_bf16x6<2, 1>), pgrid, dim3(512), x6_lds_bytes(3), s, a, nslots);
-  } else {
-    if (mode == 0) hipLaunchKernelGGL((conv3x3_bf16x6<0, 0>), pgrid, dim3(512), x6_lds_bytes(6), s, a, nslots);
-    else if (mode == 1) hipLaunchKernelGGL((conv3x3_bf16x6<1, 0>), pgrid, dim3(512), x6_lds_bytes(9), s, a, nslots);
-    else hipLaunchKernelGGL((conv3x3_bf16x6<2, 0>), pgrid, dim3(512), x6_lds_bytes(3), s, a, nslots);
-  }
+  if (mode == 0) hipLaunchKernelGGL((conv3x3_bf16x6<0>), pgrid, dim3(512), x6_lds_bytes(6), s, a, nslots);
+  else if (mode == 1) hipLaunchKernelGGL((conv3x3_bf16x6<1>), pgrid, dim3(512), x6_lds_bytes(9), s, a, nslots);
+  else hipLaunchKernelGGL((conv3x3_bf16x6<2>), pgrid, dim3(512), x6_lds_bytes(3), s, a, nslots);
   if (do_tl && tl_buf) {
     unsigned long long h[64];
     (void)hipStreamSynchronize(s);

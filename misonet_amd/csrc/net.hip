@@ -297,16 +297,8 @@ static long long align_up(long long x, long long a) { return (x + a - 1) / a * a
 // in the oct layout (2 bf16 parts = the bytes of float32, or 3 parts = 6 bytes per element); the network input/output
 // and the TCN stay planar float32, and so do the F <= 3 bottleneck buffers except in bf16x6.  Returns the ConvArgs::in_oct /
 // out_oct code.
-// bf16x6 reads PLANAR float32 activations (its producer waves split them on the way into the LDS) unless
-// MISONET_X6_PLANAR=0 selects the oct3 / LDS-DMA dataflow of the first version (kept for A/B measurements)
-static inline bool x6_planar() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("MISONET_X6_PLANAR"); v = e ? (atoi(e) != 0) : 1; }
-  return v != 0;
-}
 static inline int buf_oct(const misonet_net* n, int b) {
   if (n->precision < 2) return 0;
-  if (n->precision == 3 && x6_planar()) return 0;
   const bool o = (b >= B_E0 && b <= B_E4) || (b >= B_D2 && b <= B_D6) || (b >= B_X2 && b <= B_X6);
   // bf16x6 also keeps the F <= 3 bottleneck buffers D0 / D1 in its layout (the TCN reads / writes it at its two ends), so
   // that encoder 6 and decoders 0-1 run on the persistent kernel instead of the one-row-per-wave f32 kernel
@@ -408,8 +400,7 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
       fprintf(stderr, "%s\n", hipGetErrorString(e));
     }
   } sync_guard{s, a, sync_dbg};
-  if (a.in_oct == 3 || (n->precision == 3 && a.in_oct == 0 && x6_planar() && (a.Cin & 7) == 0)) {
-    a.cop = 32; a.ncg = (c.Cout + 31) / 32;
+  if (a.in_oct == 3) {
     a.wps = reinterpret_cast<char*>(ws) + L.wps_base + (long long)n0 * L.wps_nstride;
     a.wps_nstride = L.wps_nstride;
     a.btab = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + L.btab_base) + (long long)n0 * L.btab_nstride;
