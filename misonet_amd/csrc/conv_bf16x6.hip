@@ -53,8 +53,8 @@ __device__ __forceinline__ constexpr bool use6(int fr, int kf, int R) {
 //   sx: the three input part images [part][NR][X6_TW] (16-byte units), sw: the weight image of the chunk.
 // Phase A (time taps 0|1 paired in K): per staged row R three B fragments (h, m, l) and per (fr, kf) six MFMAs;
 // phase B (time tap 2, parts paired in K): two B fragments and three MFMAs per (fr, kf).  Small terms first.
-template <int NR, int SF, bool TR2>
-__device__ __forceinline__ void chunk_mfma6(f32x16 (&acc)[4], const bf16x8* sx, const bf16x8* sw, int wave, int half,
+template <int NR, int SF, bool TR2, int NROW>
+__device__ __forceinline__ void chunk_mfma6(f32x16 (&acc)[NROW], const bf16x8* sx, const bf16x8* sw, int wave, int half,
                                             int l31) {
   constexpr int XN = NR * X6_TW;
   const int wa = half * 32 + l31;                          // + ((kf * 3 + p) * 2) * 32
@@ -99,7 +99,7 @@ __device__ __forceinline__ void chunk_mfma6(f32x16 (&acc)[4], const bf16x8* sx, 
         const int ap = term == 0 ? 2 : ((term == 2 || term == 3) ? 1 : 0);
         const int bp = term == 1 ? 2 : ((term == 2 || term == 4) ? 1 : 0);
 #pragma unroll
-        for (int fr = 0; fr < 4; ++fr)
+        for (int fr = 0; fr < NROW; ++fr)
 #pragma unroll
           for (int kf = 0; kf < 3; ++kf)
             if (use6<SF, TR2>(fr, kf, R))
@@ -112,7 +112,7 @@ __device__ __forceinline__ void chunk_mfma6(f32x16 (&acc)[4], const bf16x8* sx, 
         const int aq = 2 - term;
         const int bq = term == 0 ? 1 : 0;
 #pragma unroll
-        for (int fr = 0; fr < 4; ++fr)
+        for (int fr = 0; fr < NROW; ++fr)
 #pragma unroll
           for (int kf = 0; kf < 3; ++kf)
             if (use6<SF, TR2>(fr, kf, R))
@@ -155,13 +155,14 @@ __device__ __forceinline__ void x6_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int MODE>
+template <int MODE, int FTR>
 __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int nslots) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (the LDS-DMA builtin has no host form)
   constexpr int COP = 32;
   constexpr int SF = MODE == 1 ? 2 : 1;
   constexpr bool TR2 = MODE == 2;
-  constexpr int NR = MODE == 0 ? 6 : (MODE == 1 ? 9 : 3);      // staged input rows of a 4-row tile
+  static_assert(FTR == 4 || (FTR == 8 && MODE != 1), "8-row tiles: not for the stride-2 layers (17 staged rows)");
+  constexpr int NR = MODE == 0 ? FTR + 2 : (MODE == 1 ? 9 : FTR / 2 + 1);   // staged input rows of an FTR-row tile
   constexpr int NS = 2;                                        // stages
   constexpr int XN = NR * X6_TW;                               // units per input part image
   constexpr int SN = 3 * XN + X6_WU;                           // units per stage: [x_h | x_m | x_l | w]
@@ -169,8 +170,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
   constexpr int NWI = (X6_WU + 255) / 256;
   extern __shared__ __align__(16) unsigned char smem_b[];
   bf16x8* s_stage = reinterpret_cast<bf16x8*>(smem_b);         // [NS][SN]
-  float* s_tab = reinterpret_cast<float*>(s_stage + NS * SN);  // [NS sets][bs | bl | br][FT][2][16] (written NS - 1 chunks ahead)
-  float* s_red = s_tab + NS * 3 * FT * COP;                    // [2 sets][4 waves][COP][2]
+  float* s_tab = reinterpret_cast<float*>(s_stage + NS * SN);  // [NS sets][bs | bl | br][FTR][2][16] (written NS - 1 chunks ahead)
+  float* s_red = s_tab + NS * 3 * FTR * COP;                   // [2 sets][4 waves][COP][2]
   float* s_ctr = s_red + 2 * 4 * COP * 2;                      // [4 sets][2 half-waves][16]: ELU(bias) per channel, the centre the
                                                                // activations are stored about
 
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
     const unsigned grp_ = (K) / per;                                                                            \
     unsigned tile_ = (K) - grp_ * per;                                                                          \
     n = (int)(grp_ * 8u + xcd);                                                                                 \
-    f0 = (int)(tile_ % (unsigned)a.nty) * FT;                                                                   \
+    f0 = (int)(tile_ % (unsigned)a.nty) * FTR;                                                                  \
     tile_ /= (unsigned)a.nty;                                                                                   \
     cg = (int)(tile_ % (unsigned)a.ncg);                                                                        \
     t0 = (int)(tile_ / (unsigned)a.ncg) * TT;                                                                   \
@@ -266,14 +267,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
     }                                                                                                           \
   }
 
-    // epilogue tables of the cursor's tile, set TS: producer wave rw builds output row f0 + rw, lane = output channel
+    // epilogue tables of the cursor's tile, set TS: half-wave h of producer wave rw builds output row f0 + rw + 4 h, lane & 31 =
+    // output channel
 #define TILE_TABLES(TS, CS)                                                                                      \
   {                                                                                                             \
-    if (lane < COP) {                                                                                           \
-      const int f_ = f0 + rw;                                                                                   \
+    const int rr_ = rw + 4 * (lane >> 5), lc_ = lane & 31;                                                      \
+    if (rr_ < FTR) {                                                                                            \
+      const int f_ = f0 + rr_;                                                                                  \
       float b3[3] = {0.f, 0.f, 0.f};                                                                            \
       if (a.btab) {                                                                                             \
-        const float* bt_ = a.btab + (long long)n * a.btab_nstride + (long long)(cg * COP + lane) * 9;           \
+        const float* bt_ = a.btab + (long long)n * a.btab_nstride + (long long)(cg * COP + lc_) * 9;            \
         const long long pst_ = (long long)a.ncg * COP * 9;          /* floats between the shares of the table */  \
         _Pragma("unroll") for (int kf = 0; kf < 3; ++kf) {                                                      \
           bool ok_;                                                                                             \
@@ -291,17 +294,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
           }                                                                                                     \
         }                                                                                                       \
       }                                                                                                         \
-      b3[1] += a.bias[cg * COP + lane];                                                                         \
+      b3[1] += a.bias[cg * COP + lc_];                                                                          \
       /* accumulator order: channel co = (i&3) + 8*(i>>2) + 4*h  ->  h = (co>>2)&1, i = (co&3) + 4*(co>>3) */    \
-      const int slot_ = (rw * 2 + ((lane >> 2) & 1)) * 16 + (lane & 3) + 4 * (lane >> 3);                       \
-      float* tb_ = s_tab + (TS) * (3 * FT * COP);                                                               \
+      const int slot_ = (rr_ * 2 + ((lc_ >> 2) & 1)) * 16 + (lc_ & 3) + 4 * (lc_ >> 3);                         \
+      float* tb_ = s_tab + (TS) * (3 * FTR * COP);                                                              \
       tb_[slot_] = b3[0] + b3[1] + b3[2];                                                                       \
-      tb_[FT * COP + slot_] = b3[0];                                                                            \
-      tb_[2 * FT * COP + slot_] = b3[2];                                                                        \
+      tb_[FTR * COP + slot_] = b3[0];                                                                           \
+      tb_[2 * FTR * COP + slot_] = b3[2];                                                                       \
       /* centre of the stored activations per channel: ELU(bias) -- the pre-activation of normalised inputs has mean   */ \
       /* bias exactly.  (NOT the accumulator start value: bias - sum W' mean_in is far from the output when |mean_in|  */ \
       /* >> std_in.)                                                                                                    */ \
-      if (rw == 0) s_ctr[(CS) * COP + slot_] = elu_fast(a.bias[cg * COP + lane]);                               \
+      if (rr_ == 0) s_ctr[(CS) * COP + slot_] = elu_fast(a.bias[cg * COP + lc_]);                               \
     }                                                                                                           \
   }
 
@@ -372,17 +375,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
     unsigned g = 0, ti = 0;
     __syncthreads();                                           // barrier 0: chunk 0 has landed
     for (;;) {
-      f32x16 acc[4];
+      f32x16 acc[FTR];
       const bool wave_live = (t0 + 32 * wave < T) && !(a.dbg & 1);   // this consumer's frames exist (ragged last tile)
       {
-        const float* tb = s_tab + (ti % NS) * (3 * FT * COP);  // accumulators start at bias + folded shift
-        conv_acc_init_rows(acc, t0 + 32 * wave, T, lane, tb, tb + FT * COP, tb + 2 * FT * COP);
+        const float* tb = s_tab + (ti % NS) * (3 * FTR * COP);  // accumulators start at bias + folded shift
+        conv_acc_init_rows(acc, t0 + 32 * wave, T, lane, tb, tb + FTR * COP, tb + 2 * FTR * COP);
       }
       for (int kc = 0; kc < nchunk; ++kc, ++g) {
         if (wave_live) {
           const bf16x8* st = s_stage + (g % NS) * SN;
           __builtin_amdgcn_s_setprio(1);
-          chunk_mfma6<NR, SF, TR2>(acc, st, st + 3 * XN, wave, half, l31);
+          chunk_mfma6<NR, SF, TR2, FTR>(acc, st, st + 3 * XN, wave, half, l31);
           __builtin_amdgcn_s_setprio(0);
         }
         STAMP(ti);
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
         STAMP(ti);
       }
       if (!(a.dbg & 4))
-        conv_epilogue_rows_nb<3>(a, acc, n, cg, f0, t0 + 32 * wave, lane, s_red + (ti & 1) * (4 * COP * 2) + wave * (COP * 2), 4,
+        conv_epilogue_rows_nb<3>(a, acc, n, cg, f0, t0 + 32 * wave, lane, s_red + (ti & 1) * (4 * COP * 2) + wave * (COP * 2), FTR,
                                  a.act ? s_ctr + (ti & 3) * COP : nullptr);
       ++ti;
       k += (unsigned)nslots;
@@ -488,22 +491,24 @@ __global__ __launch_bounds__(288) void conv_wprep6_k(const float* wf, const doub
   btab[(long long)n * btab_nstride + ((long long)blockIdx.y * ncg * 32 + cg * 32 + co) * 9 + tap] = (float)bsum;
 }
 
-static size_t x6_lds_bytes(int NR) {
+static size_t x6_lds_bytes(int NR, int ftr) {
   const int ns = 2;                                  // two stages + epilogue tables + statistics partials
-  return (size_t)(ns * (3 * NR * X6_TW + X6_WU)) * 16 + (size_t)(ns * 3 * FT * 32 + 2 * 4 * 32 * 2 + 4 * 32) * sizeof(float);
+  return (size_t)(ns * (3 * NR * X6_TW + X6_WU)) * 16 + (size_t)(ns * 3 * ftr * 32 + 2 * 4 * 32 * 2 + 4 * 32) * sizeof(float);
 }
 
-template <int MODE>
+template <int MODE, int FTR>
 static hipError_t x6_set_attr() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6<MODE>),
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6<MODE, FTR>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 hipError_t conv_bf16x6_init() {
   hipError_t e;
-  if ((e = x6_set_attr<0>()) != hipSuccess) return e;
-  if ((e = x6_set_attr<1>()) != hipSuccess) return e;
-  return x6_set_attr<2>();
+  if ((e = x6_set_attr<0, 4>()) != hipSuccess) return e;
+  if ((e = x6_set_attr<0, 8>()) != hipSuccess) return e;
+  if ((e = x6_set_attr<1, 4>()) != hipSuccess) return e;
+  if ((e = x6_set_attr<2, 8>()) != hipSuccess) return e;
+  return x6_set_attr<2, 4>();
 }
 
 long long conv_bf16x6_wps_bytes(int Cin, int Cout) {
@@ -543,7 +548,13 @@ hipError_t launch_conv_bf16x6(const ConvArgs& a_in, int n_samples, hipStream_t s
     if (!tl_buf && hipMalloc(reinterpret_cast<void**>(&tl_buf), 64 * 8) != hipSuccess) tl_buf = nullptr;
     if (tl_buf) { (void)hipMemsetAsync(tl_buf, 0, 64 * 8, s); a.dbg_buf = tl_buf; }
   }
-  (void)conv_grid(a, n_samples, TT, FT, 1);                       // tile geometry: 4 rows x 128 frames
+  const int mode = a.tr2 ? 2 : (a.sf == 2 ? 1 : 0);
+  // tile geometry: 128 frames x 8 rows for the stride-1 layers with more than 4 rows (10 staged rows per 8 instead of
+  // 6 per 4 and one weight image per 216 instead of 108 MFMAs: 25 % fewer staged bytes per MFMA), else x 4 rows
+  static int ft8 = -1;
+  if (ft8 < 0) { const char* e = getenv("MISONET_X6_ROWS8"); ft8 = e ? atoi(e) : 3; }   // bit 0: stride-1, bit 1: transposed
+  const int ftr = (mode != 1 && a.Fout > 4 && (ft8 & (mode == 0 ? 1 : 2))) ? 8 : 4;
+  (void)conv_grid(a, n_samples, TT, ftr, 1);
   static int g_cus = 0;
   if (!g_cus) {
     int dev = 0;
@@ -562,10 +573,11 @@ hipError_t launch_conv_bf16x6(const ConvArgs& a_in, int n_samples, hipStream_t s
     if (cap > 0 && nslots > cap) nslots = cap;
   }
   const dim3 pgrid((unsigned)(8 * nslots), 1, 1);
-  const int mode = a.tr2 ? 2 : (a.sf == 2 ? 1 : 0);
-  if (mode == 0) hipLaunchKernelGGL((conv3x3_bf16x6<0>), pgrid, dim3(512), x6_lds_bytes(6), s, a, nslots);
-  else if (mode == 1) hipLaunchKernelGGL((conv3x3_bf16x6<1>), pgrid, dim3(512), x6_lds_bytes(9), s, a, nslots);
-  else hipLaunchKernelGGL((conv3x3_bf16x6<2>), pgrid, dim3(512), x6_lds_bytes(3), s, a, nslots);
+  if (mode == 0 && ftr == 8) hipLaunchKernelGGL((conv3x3_bf16x6<0, 8>), pgrid, dim3(512), x6_lds_bytes(10, 8), s, a, nslots);
+  else if (mode == 0) hipLaunchKernelGGL((conv3x3_bf16x6<0, 4>), pgrid, dim3(512), x6_lds_bytes(6, 4), s, a, nslots);
+  else if (mode == 1) hipLaunchKernelGGL((conv3x3_bf16x6<1, 4>), pgrid, dim3(512), x6_lds_bytes(9, 4), s, a, nslots);
+  else if (ftr == 8) hipLaunchKernelGGL((conv3x3_bf16x6<2, 8>), pgrid, dim3(512), x6_lds_bytes(5, 8), s, a, nslots);
+  else hipLaunchKernelGGL((conv3x3_bf16x6<2, 4>), pgrid, dim3(512), x6_lds_bytes(3, 4), s, a, nslots);
   if (do_tl && tl_buf) {
     unsigned long long h[64];
     (void)hipStreamSynchronize(s);

@@ -516,13 +516,14 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvArgs& a, f32x16_t (
 typedef float f32x2_e __attribute__((ext_vector_type(2)));
 
 // acc[r][i] = bias + folded shift of (row f0 + r, channel of accumulator slot i); tables as in conv_epilogue_rows.
-__device__ __forceinline__ void conv_acc_init_rows(f32x16_t (&acc)[4], int tw, int T, int lane, const float* s_bs,
+template <int NROW>
+__device__ __forceinline__ void conv_acc_init_rows(f32x16_t (&acc)[NROW], int tw, int T, int lane, const float* s_bs,
                                                    const float* s_bl, const float* s_br) {
   const int half = lane >> 5, l31 = lane & 31;
   const int t = tw + l31;
   const bool t_edge = (tw == 0 || tw + 32 >= T);                            // uniform
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
+  for (int r = 0; r < NROW; ++r) {
     const float4* pb = reinterpret_cast<const float4*>(s_bs + (r * 2 + half) * 16);
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
@@ -533,7 +534,7 @@ __device__ __forceinline__ void conv_acc_init_rows(f32x16_t (&acc)[4], int tw, i
   if (t_edge) {
     const float e0 = (t == 0) ? 1.f : 0.f, e1 = (t == T - 1) ? 1.f : 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < NROW; ++r) {
       const float4* pl = reinterpret_cast<const float4*>(s_bl + (r * 2 + half) * 16);
       const float4* pr = reinterpret_cast<const float4*>(s_br + (r * 2 + half) * 16);
 #pragma unroll
@@ -548,8 +549,8 @@ __device__ __forceinline__ void conv_acc_init_rows(f32x16_t (&acc)[4], int tw, i
 
 // s_ctr (optional): 16 floats per half-wave in accumulator order, the centre c = ELU(bias) per channel: the row is stored
 // as x - c and the statistics are those of the stored values (conv_epilogue_impl's CENTRE note).
-template <bool MASKED, bool ACT, int NP, bool F16 = false>
-__device__ __forceinline__ void conv_epilogue_rows_nb_impl(const ConvArgs& a, f32x16_t (&acc)[4], int cg, int f0, int tw,
+template <bool MASKED, bool ACT, int NP, bool F16 = false, int NROW = 4>
+__device__ __forceinline__ void conv_epilogue_rows_nb_impl(const ConvArgs& a, f32x16_t (&acc)[NROW], int cg, int f0, int tw,
                                                            int lane, const __amdgpu_buffer_rsrc_t (&rs)[3],
                                                            f32x2_e (&s1)[8], f32x2_e (&s2)[8], int rows,
                                                            const float* s_ctr = nullptr) {
@@ -577,7 +578,7 @@ __device__ __forceinline__ void conv_epilogue_rows_nb_impl(const ConvArgs& a, f3
     }
   }
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
+  for (int r = 0; r < NROW; ++r) {
     const int f = f0 + r;
     const bool ok = !MASKED || ((f < a.Fout) && (t < T) && (r < rows));
     const float mf = ok ? 1.f : 0.f;
@@ -619,12 +620,12 @@ __device__ __forceinline__ void conv_epilogue_rows_nb_impl(const ConvArgs& a, f3
 }
 
 // rows: output rows of the tile (4, or 2 for the stride-2 layers of the bf16x3 kernel); NP: bf16 parts of an oct output
-template <int NP = 2, bool F16 = false>
-__device__ __forceinline__ void conv_epilogue_rows_nb(const ConvArgs& a, f32x16_t (&acc)[4], int n, int cg, int f0, int tw,
-                                                      int lane, float* s_red, int rows = 4, const float* s_ctr = nullptr) {
+template <int NP = 2, bool F16 = false, int NROW>
+__device__ __forceinline__ void conv_epilogue_rows_nb(const ConvArgs& a, f32x16_t (&acc)[NROW], int n, int cg, int f0, int tw,
+                                                      int lane, float* s_red, int rows = NROW, const float* s_ctr = nullptr) {
   const int half = lane >> 5;
   const int T = a.T, Tp = a.Tp;
-  const bool fast = (tw + 32 <= T) && (f0 + 4 <= a.Fout) && rows == 4;      // uniform: all 32 frames and 4 rows exist
+  const bool fast = (tw + 32 <= T) && (f0 + NROW <= a.Fout) && rows == NROW;   // uniform: all 32 frames and all rows exist
   f32x2_e s1[8], s2[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { s1[i] = f32x2_e{0.f, 0.f}; s2[i] = f32x2_e{0.f, 0.f}; }
@@ -647,10 +648,10 @@ __device__ __forceinline__ void conv_epilogue_rows_nb(const ConvArgs& a, f32x16_
   }
 
   if (a.act) {
-    if (fast) conv_epilogue_rows_nb_impl<false, true, NP, F16>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows, s_ctr);
-    else conv_epilogue_rows_nb_impl<true, true, NP, F16>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows, s_ctr);
+    if (fast) conv_epilogue_rows_nb_impl<false, true, NP, F16, NROW>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows, s_ctr);
+    else conv_epilogue_rows_nb_impl<true, true, NP, F16, NROW>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows, s_ctr);
   } else {
-    conv_epilogue_rows_nb_impl<true, false, NP, F16>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows);
+    conv_epilogue_rows_nb_impl<true, false, NP, F16, NROW>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows);
   }
 
   if (a.act && !(a.dbg & 16)) {
