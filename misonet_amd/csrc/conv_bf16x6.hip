@@ -28,7 +28,11 @@
 //     A = [w_h | w_l] gives hl + lh.  27 MFMAs per (output row, chunk) = 9 taps x 6 terms x 8 channels / 16: no padding;
 //   * row reuse as in the bf16x3 kernel: an input fragment of staged row R serves the output rows f' with f' + kf = R,
 //     and the 18 weight fragments of a phase stay in registers: 48 LDS fragment reads per 108 MFMAs;
-//   * all layer types run 4-row tiles (the 9 staged rows of a stride-2 tile fit: 140 KB for two stages).
+//   * tiles are 128 frames x 8 output rows for the stride-1 and transposed layers (10 resp. 5 staged rows; 152 KB for two
+//     stride-1 stages, 249 VGPRs with 128 accumulator registers) and x 4 rows for the stride-2 layers (9 staged rows)
+//     and for F <= 4.  The 8-row tile stages 25 % fewer bytes per MFMA than the 4-row tile of the first version (10
+//     rows per 8 instead of 6 per 4, one weight image per 216 instead of 108 MFMAs), which is what makes a chunk
+//     MFMA-bound (see below).
 #include "kernels.hpp"
 #include "conv_epilogue.hpp"
 #include "conv_bf16_core.hpp"
@@ -132,11 +136,14 @@ __device__ __forceinline__ void chunk_mfma6(f32x16 (&acc)[NROW], const bf16x8* s
 // chunk b + 1 into the stage that chunk b - 1 occupied (the first chunk of the next tile is in flight during an epilogue).
 //
 // Where a chunk period goes (MISONET_TIMELINE=96 with MISONET_WS_DEBUG ablations, tools/gpu_x6_ablate.sh; Cin = 96,
-// F = 63, all 256 CUs busy): 4.6k cycles = 3.9k of MFMA phase (108 MFMAs at 36 instead of 32 cycles: operand fill behind
-// the barrier + LDS waits) + 0.7k at the barrier waiting for the stage.  With the DMA off the period is 4.1k, with the
-// MFMAs off 4.1-4.4k: the LDS-DMA stream of a CU (51 KB per chunk) runs at 17 B/clk when 8 CUs are active and at ~12 B/clk
-// when all 256 are (tools/gpu_x6_slots.sh), i.e. the kernel is CO-LIMITED by the matrix pipe and by bytes through the
-// texture path; without the 13.8 KB weight image of a chunk the period drops to 4.25k.
+// F = 63, all 256 CUs busy).  4-ROW tiles (MISONET_X6_ROWS8=0): 4.6k cycles = 3.9k of MFMA phase (108 MFMAs at 36 instead
+// of 32 cycles: operand fill behind the barrier + LDS waits) + 0.7k at the barrier waiting for the stage.  With the DMA
+// off the period is 4.1k, with the MFMAs off 4.1-4.4k: the LDS-DMA stream of a CU (51 KB per chunk) runs at 17 B/clk when
+// 8 CUs are active and at ~12 B/clk when all 256 are (tools/gpu_x6_slots.sh), i.e. that tile is CO-LIMITED by the matrix
+// pipe and by bytes through the texture path.  8-ROW tiles: 76 KB per 216 MFMAs = 10 B/clk at the MFMA rate, the
+// producers have slack, the barrier wait is 0.17k and a chunk takes 7.6k cycles = 35 per MFMA (tile incl. epilogue:
+// 35.5 instead of 43.4).  The shader clock (s_memtime against s_memrealtime inside the kernel) answers with 1.56 instead
+// of 1.68 GHz -- the part is power-limited, a third of the cycle gain goes back -- so a layer gains 6-10 % in time.
 //
 // Measured and NOT kept (git history):
 //   (i)   a third stage, (a) with the first operands of chunk b fetched during the last steps of chunk b - 1 (10 % slower)
@@ -188,8 +195,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
   // wave 4 -> slots 32..); experiments only
   unsigned long long* const tl = (a.dbg_buf && blockIdx.x == 8 && lane == 0 && (wave == 0 || wave == 4)) ? a.dbg_buf + (wave ? 32 : 0) : nullptr;
   int tl_i = 0;
+  const unsigned tl_tile = (a.dbg >> 16) ? (unsigned)(a.dbg >> 16) : 2u;   // MISONET_WS_DEBUG bits 16+: the tile to stamp
   unsigned long long tl_base = 0;
-#define STAMP(TI) do { if (tl && (TI) == 2 && tl_i < 30) { const unsigned long long c_ = clock64(); if (!tl_i) tl_base = c_; tl[tl_i++] = c_ - tl_base; tl[31] = tl_i; } } while (0)
+#define STAMP(TI) do { if (tl && (TI) == tl_tile && tl_i < 28) { const unsigned long long c_ = clock64(); if (!tl_i) { tl_base = c_; tl[28] = wall_clock64(); } tl[tl_i++] = c_ - tl_base; tl[31] = tl_i; tl[29] = wall_clock64(); } } while (0)
 
   const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
   const unsigned per = (unsigned)(a.ntx * a.nty * a.ncg);                    // tiles per sample
@@ -583,9 +591,11 @@ hipError_t launch_conv_bf16x6(const ConvArgs& a_in, int n_samples, hipStream_t s
     (void)hipStreamSynchronize(s);
     (void)hipMemcpy(h, tl_buf, sizeof(h), hipMemcpyDeviceToHost);
     fprintf(stderr, "[timeline-x6] Cin=%d Fout=%d n=%d consumer(%llu):", a.Cin, a.Fout, n_samples, h[31]);
-    for (unsigned long long i = 0; i < h[31] && i < 30; ++i) fprintf(stderr, " %llu", h[i]);
+    for (unsigned long long i = 0; i < h[31] && i < 28; ++i) fprintf(stderr, " %llu", h[i]);
+    if (h[31] > 1 && h[29] > h[28])                                // shader cycles per 100 MHz wall-clock tick
+      fprintf(stderr, "\n[timeline-x6] shader clock over the stamped tile: %.3f GHz", 0.1 * (double)h[h[31] - 1] / (double)(h[29] - h[28]));
     fprintf(stderr, "\n[timeline-x6] producer(%llu):", h[63]);
-    for (unsigned long long i = 0; i < h[63] && i < 30; ++i) fprintf(stderr, " %llu", h[32 + i]);
+    for (unsigned long long i = 0; i < h[63] && i < 28; ++i) fprintf(stderr, " %llu", h[32 + i]);
     fprintf(stderr, "\n");
     ++tl_done;
   }
