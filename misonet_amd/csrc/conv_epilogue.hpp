@@ -129,14 +129,13 @@ __device__ __forceinline__ void split3_pair_t(float x0, float x1, unsigned& hi, 
   f32x2_t x = {x0, x1};
   const bf16x2_t h = __builtin_convertvector(x, bf16x2_t);
   const unsigned hu = __builtin_bit_cast(unsigned, h);
-  f32x2_t r;
-  r.x = x0 - __builtin_bit_cast(float, hu << 16);
-  r.y = x1 - __builtin_bit_cast(float, hu & 0xffff0000u);
+  // residuals as 2-wide vector subtractions (v_pk_add_f32 with negated source)
+  const f32x2_t hf = {__builtin_bit_cast(float, hu << 16), __builtin_bit_cast(float, hu & 0xffff0000u)};
+  const f32x2_t r = x - hf;
   const bf16x2_t m = __builtin_convertvector(r, bf16x2_t);
   const unsigned mu = __builtin_bit_cast(unsigned, m);
-  f32x2_t q;
-  q.x = r.x - __builtin_bit_cast(float, mu << 16);
-  q.y = r.y - __builtin_bit_cast(float, mu & 0xffff0000u);
+  const f32x2_t mf = {__builtin_bit_cast(float, mu << 16), __builtin_bit_cast(float, mu & 0xffff0000u)};
+  const f32x2_t q = r - mf;
   const bf16x2_t l = __builtin_convertvector(q, bf16x2_t);
   hi = hu;
   mid = mu;
