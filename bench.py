@@ -79,9 +79,12 @@ def conv_flops_per_forward(in_ch, out_ch, T, en=(24, 32, 32, 32, 32, 64, 128), d
     return 2.0 * mac
 
 
-def conv_bytes_per_forward(in_ch, out_ch, T, en=(24, 32, 32, 32, 32, 64, 128), de=(128, 64, 32, 32, 32, 32, 24)):
+def conv_bytes_per_forward(in_ch, out_ch, T, en=(24, 32, 32, 32, 32, 64, 128), de=(128, 64, 32, 32, 32, 32, 24),
+                           inner_elem_bytes=4.0):
     """Algorithmic HBM bytes of the conv layers of one forward-sample with layer-level fusion only (every conv reads its
-    whole (concatenated) input once and writes its output once, float32): the 1.46 GB figure of SURVEY.md 8(d)."""
+    whole (concatenated) input once and writes its output once, float32): the 1.46 GB figure of SURVEY.md 8(d).
+    inner_elem_bytes: bytes per element of every tensor except the network input / output (6 in the oct3 layout of the
+    bf16x6 mode: three bf16 pieces)."""
     Fe = [127, 63, 31, 15, 7, 3, 1]
     el = 0
 
@@ -100,7 +103,8 @@ def conv_bytes_per_forward(in_ch, out_ch, T, en=(24, 32, 32, 32, 32, 64, 128), d
         if i >= 2:
             el += dense(2 * de[i], de[i], 2 * de[i], Fi)
         el += 2 * de[i] * Fi + dech[i + 1] * Fo[i]
-    return 4.0 * el * T
+    el_io = ench[0] * Fin[0] + dech[7] * Fo[6]
+    return (4.0 * el_io + inner_elem_bytes * (el - el_io)) * T
 
 
 def run_steps(enh, mix, clean, out, steps, warmup, dist, L, _lib, profile):
@@ -147,6 +151,9 @@ def roofline_objects(precision, B, T, steps, dt_conv_ms, n_launch):
     by3 = conv_bytes_per_forward(2 * (N_MIC + 2), 2, T)
     flops_step = B * (N_MIC * fl1 + N_SPK * fl3)
     bytes_step = B * (N_MIC * by1 + N_SPK * by3)
+    ieb = 6.0 if precision == "bf16x6" else 4.0          # the oct3 layout stores three bf16 pieces per element
+    lay_step = B * (N_MIC * conv_bytes_per_forward(2 * N_MIC, 2 * N_SPK, T, inner_elem_bytes=ieb) +
+                    N_SPK * conv_bytes_per_forward(2 * (N_MIC + 2), 2, T, inner_elem_bytes=ieb))
     conv_s = dt_conv_ms / 1e3
     ach_tf = flops_step * steps / conv_s / 1e12
     ach_tb = bytes_step * steps / conv_s / 1e12
@@ -156,7 +163,10 @@ def roofline_objects(precision, B, T, steps, dt_conv_ms, n_launch):
               "launches_per_step": int(n_launch // steps), "avg_launch_ms": round(dt_conv_ms / max(n_launch, 1), 4),
               "algorithmic_gflop_per_launch": round(flops_step * steps / max(n_launch, 1) / 1e9, 2),
               "algorithmic_gbyte_per_launch": round(bytes_step * steps / max(n_launch, 1) / 1e9, 3),
+              # the same read-once / write-once count at the bytes per element of the mode's activation layout
+              "layout_gbyte_per_launch": round(lay_step * steps / max(n_launch, 1) / 1e9, 3),
               "traffic": traffic,
+              "traffic_over_layout_bytes": round(traffic / (lay_step * steps / max(n_launch, 1)), 3) if traffic else None,
               "traffic_source": (tsrc + " (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, x2 fetch correction)") if tsrc else None,
               "mfma_busy_frac_pmc": tj.get("mfma_busy_frac") if tj else None,
               # engine clock seen in the PMC pass (the peaks below are the guide's 2.4 GHz figures; under the bf16 MFMA
