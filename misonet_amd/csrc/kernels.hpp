@@ -122,7 +122,7 @@ hipError_t launch_tcn_pw(const float* d, const double* gln_stats, const float* g
                          const float* wpw /*packed [C/CK... see tcn.hip]*/, const float* residual /*or nullptr*/,
                          float* y, long long y_bstride, int y_c0, double* y_stats /*[n][C][2]*/, int C, int T, int Tp,
                          int n_samples, hipStream_t s,
-                         int y_oct3_cbuf = 0);   // != 0: y is an oct3 buffer with that many channels (bf16x6 mode)
+                         int y_oct3_cbuf = 0, int x6 = 0);   // != 0: y is an oct3 buffer with that many channels (bf16x6 mode)
 
 // ---- layout conversion ----------------------------------------------------------------------------------------
 // complex64 [B][Mseg][T][F] -> planar real/imag channel planes; optional circular mic shifts (tester.py:1034,1050):

@@ -480,20 +480,24 @@ static int forward_planar(misonet_net* n, const Layout& L, void* ws, hipStream_t
                               n->bufs[B_D0].C, xa, xs, 128, T, Tp, N, s, buf_oct(n, B_D0) == 3));
     float* cur = xa;
     float* nxt = xb;
+    // bf16x6 mode: the point-wise convs in the same arithmetic as the 3x3 convs (MISONET_TCN_X6=0: fp32 MFMA, A/B runs)
+    static int tcn_x6_env = -1;
+    if (tcn_x6_env < 0) { const char* e = getenv("MISONET_TCN_X6"); tcn_x6_env = e ? atoi(e) : 1; }
+    const int tcn_x6 = (n->precision == 3 && tcn_x6_env) ? 1 : 0;
     for (int k = 0; k < 14; ++k) {
       const TcnBlock& tb = n->tcn[k];
       const float* W = n->w_dev;
       HIPCHK(launch_tcn_dw(cur, xs + k * per, W + tb.h[0].o_dw, W + tb.h[0].o_prelu, td, gl + (2 * k) * (long long)N * 2,
                            128, T, Tp, tb.dilation, N, s));
       HIPCHK(launch_tcn_pw(td, gl + (2 * k) * (long long)N * 2, W + tb.h[0].o_gamma, W + tb.h[0].o_beta, W + tb.h[0].o_pw,
-                           nullptr, tp, 128LL * Tp, 0, ps + k * per, 128, T, Tp, N, s));
+                           nullptr, tp, 128LL * Tp, 0, ps + k * per, 128, T, Tp, N, s, 0, tcn_x6));
       HIPCHK(launch_tcn_dw(tp, ps + k * per, W + tb.h[1].o_dw, W + tb.h[1].o_prelu, td,
                            gl + (2 * k + 1) * (long long)N * 2, 128, T, Tp, tb.dilation, N, s));
       const bool last = (k == 13);
       float* y = last ? buf_ptr(L, ws, B_D0) : nxt;
       HIPCHK(launch_tcn_pw(td, gl + (2 * k + 1) * (long long)N * 2, W + tb.h[1].o_gamma, W + tb.h[1].o_beta,
                            W + tb.h[1].o_pw, cur, y, last ? bstride(n, L, B_D0) : 128LL * Tp, 0,
-                           xs + (k + 1) * per, 128, T, Tp, N, s, (last && buf_oct(n, B_D0) == 3) ? n->bufs[B_D0].C : 0));
+                           xs + (k + 1) * per, 128, T, Tp, N, s, (last && buf_oct(n, B_D0) == 3) ? n->bufs[B_D0].C : 0, tcn_x6));
       float* t = cur; cur = nxt; nxt = t;
     }
   }

@@ -159,14 +159,16 @@ constexpr int PW_TT = 128;
 constexpr int PW_KC = 16;
 // Y_OCT3: y is an oct3 buffer of the bf16x6 mode (the TCN output feeds decoder 0 there): the accumulator layout is the
 // conv kernels', so the row goes out through store_oct_row<3>; y_bstride in floats, y_cbuf = channels of that buffer.
-template <bool Y_OCT3>
+// X6: the 128x128 product in the bf16x6 arithmetic of conv_bf16x6.hip (both operands split exactly into three bf16
+// pieces, six leading partial products on v_mfma_f32_32x32x16_bf16, float32 accumulation) instead of the fp32 MFMA: the
+// kernel is bound by the matrix pipe otherwise (3.2 GFLOP per launch at 52 TF/s).  The split of the normalised input
+// happens once per workgroup on the way into the LDS, the split of a wave's weight fragment in its registers.
+template <bool Y_OCT3, bool X6>
 __global__ __launch_bounds__(256) void tcn_pw_k(const float* d, const double* gln_stats, const float* gamma,
                                                 const float* beta, const float* wt /*[ci][co]*/,
                                                 const float* residual, float* y, long long y_bstride, int y_c0,
                                                 double* y_stats, int T, int Tp, int y_cbuf) {
   constexpr int C = 128;
-  __shared__ __align__(16) float s_g[2][PW_KC][PW_TT];
-  __shared__ __align__(16) float s_w[2][PW_KC][C];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int t0 = blockIdx.x * PW_TT, n = blockIdx.y;
@@ -184,6 +186,81 @@ __global__ __launch_bounds__(256) void tcn_pw_k(const float* d, const double* gl
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
 
+  if constexpr (X6) {
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    __shared__ __align__(16) u32x4_t s_x[2][3][2][PW_TT];      // [buffer][piece][octet of the chunk][frame]
+    __shared__ float s_ga[C], s_be[C];
+    if (tid < C) {
+      const float g_ = gamma[tid] * rstd;
+      s_ga[tid] = g_;
+      s_be[tid] = beta[tid] - g_ * mean;
+    }
+    __syncthreads();
+    // staging role: thread <-> (octet so of the 16-channel chunk, frame sf); A fragment: lane (l31, half) <-> output
+    // channel wave * 32 + l31, input channels k0 + 8 * half .. + 7
+    const int so = tid >> 7, sf = tid & 127;
+    const int ts = t0 + sf;
+    const bool tok = ts < T;
+    const float* xl = dn + (long long)(8 * so) * Tp + ts;
+    const float* wl = wt + (long long)(8 * half) * C + wave * 32 + l31;
+    float xin[2][8], win[2][8];                                // loads run two chunks ahead of their use
+    u32x4_t A[3];
+#define X6_ISSUE(SL, K0)                                                                                          \
+  _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                                                \
+    xin[SL][c] = tok ? xl[(long long)((K0) + c) * Tp] : 0.f;                                                     \
+    win[SL][c] = wl[(long long)((K0) + c) * C];                                                                  \
+  }
+#define X6_COMMIT(BUF, SL, K0)                                                                                   \
+  {                                                                                                              \
+    u32x4_t h_, m_, l_;                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                              \
+      const int c0_ = (K0) + 8 * so + 2 * i;                                                                     \
+      const float v0_ = tok ? fmaf(xin[SL][2 * i], s_ga[c0_], s_be[c0_]) : 0.f;                                     \
+      const float v1_ = tok ? fmaf(xin[SL][2 * i + 1], s_ga[c0_ + 1], s_be[c0_ + 1]) : 0.f;                         \
+      unsigned hh_, mm_, ll_;                                                                                    \
+      split3_pair_t(v0_, v1_, hh_, mm_, ll_);                                                                    \
+      h_[i] = hh_; m_[i] = mm_; l_[i] = ll_;                                                                     \
+    }                                                                                                            \
+    s_x[BUF][0][so][sf] = h_; s_x[BUF][1][so][sf] = m_; s_x[BUF][2][so][sf] = l_;                                \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                              \
+      unsigned hh_, mm_, ll_;                                                                                    \
+      split3_pair_t(win[SL][2 * i], win[SL][2 * i + 1], hh_, mm_, ll_);                                                \
+      A[0][i] = hh_; A[1][i] = mm_; A[2][i] = ll_;                                                               \
+    }                                                                                                            \
+  }
+    X6_ISSUE(0, 0)
+    X6_ISSUE(1, 16)
+    X6_COMMIT(0, 0, 0)
+    __syncthreads();
+#pragma unroll
+    for (int kc = 0; kc < C / 16; ++kc) {
+      const int buf = kc & 1;
+      if (kc + 2 < C / 16) X6_ISSUE(kc & 1, (kc + 2) * 16)      // slot kc & 1 was consumed by the commit of chunk kc
+      const bf16x8_t Ah = __builtin_bit_cast(bf16x8_t, A[0]), Am = __builtin_bit_cast(bf16x8_t, A[1]),
+                     Al = __builtin_bit_cast(bf16x8_t, A[2]);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8_t Bh = __builtin_bit_cast(bf16x8_t, s_x[buf][0][half][s * 32 + l31]);
+        const bf16x8_t Bm = __builtin_bit_cast(bf16x8_t, s_x[buf][1][half][s * 32 + l31]);
+        const bf16x8_t Bl = __builtin_bit_cast(bf16x8_t, s_x[buf][2][half][s * 32 + l31]);
+        // small terms first: lh, hl, mm, mh, hm, hh
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acc[s], 0, 0, 0);
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acc[s], 0, 0, 0);
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm, acc[s], 0, 0, 0);
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, acc[s], 0, 0, 0);
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, acc[s], 0, 0, 0);
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc[s], 0, 0, 0);
+      }
+      if (kc + 1 < C / 16) {
+        X6_COMMIT(buf ^ 1, (kc + 1) & 1, (kc + 1) * 16)
+        __syncthreads();
+      }
+    }
+#undef X6_ISSUE
+#undef X6_COMMIT
+  } else {
+  __shared__ __align__(16) float s_g[2][PW_KC][PW_TT];
+  __shared__ __align__(16) float s_w[2][PW_KC][C];
   // staging roles: thread (q = tid & 31 -> frames 4q..4q+3, g = tid >> 5 -> channels g, g+8 of the chunk)
   const int sq = tid & 31, sg = tid >> 5;
   const int tg = t0 + 4 * sq;
@@ -231,6 +308,8 @@ __global__ __launch_bounds__(256) void tcn_pw_k(const float* d, const double* gl
   }
 #undef PW_ISSUE
 #undef PW_COMMIT
+
+  }
 
   // ---- epilogue ----
   // residual tile: this lane's (channel, frame) elements in accumulator order, all loads issued together
@@ -330,16 +409,20 @@ hipError_t launch_tcn_dw(const float* x, const double* x_stats, const float* wdw
 
 hipError_t launch_tcn_pw(const float* d, const double* gln_stats, const float* gamma, const float* beta,
                          const float* wpw, const float* residual, float* y, long long y_bstride, int y_c0,
-                         double* y_stats, int C, int T, int Tp, int n_samples, hipStream_t s, int y_oct3_cbuf) {
+                         double* y_stats, int C, int T, int Tp, int n_samples, hipStream_t s, int y_oct3_cbuf, int x6) {
   if (C != 128) return hipErrorInvalidValue;
   const dim3 g((T + PW_TT - 1) / PW_TT, n_samples);
   if (y_oct3_cbuf) {
     if ((y_c0 & 7) || (y_oct3_cbuf & 7)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(tcn_pw_k<true>, g, dim3(256), 0, s, d, gln_stats, gamma, beta, wpw, residual, y, y_bstride, y_c0,
-                       y_stats, T, Tp, y_oct3_cbuf);
+    if (x6) hipLaunchKernelGGL((tcn_pw_k<true, true>), g, dim3(256), 0, s, d, gln_stats, gamma, beta, wpw, residual, y,
+                               y_bstride, y_c0, y_stats, T, Tp, y_oct3_cbuf);
+    else hipLaunchKernelGGL((tcn_pw_k<true, false>), g, dim3(256), 0, s, d, gln_stats, gamma, beta, wpw, residual, y,
+                            y_bstride, y_c0, y_stats, T, Tp, y_oct3_cbuf);
   } else {
-    hipLaunchKernelGGL(tcn_pw_k<false>, g, dim3(256), 0, s, d, gln_stats, gamma, beta, wpw, residual, y, y_bstride, y_c0,
-                       y_stats, T, Tp, 0);
+    if (x6) hipLaunchKernelGGL((tcn_pw_k<false, true>), g, dim3(256), 0, s, d, gln_stats, gamma, beta, wpw, residual, y,
+                               y_bstride, y_c0, y_stats, T, Tp, 0);
+    else hipLaunchKernelGGL((tcn_pw_k<false, false>), g, dim3(256), 0, s, d, gln_stats, gamma, beta, wpw, residual, y,
+                            y_bstride, y_c0, y_stats, T, Tp, 0);
   }
   return hipGetLastError();
 }
