@@ -152,6 +152,12 @@ __device__ __forceinline__ void chunk_mfma6(f32x16 (&acc)[NROW], const bf16x8* s
 //   (ii)  the tile epilogue on the producer waves through an LDS mailbox -- 4 % slower;
 //   (iii) phases A and B of a staged row merged into one step (longer steps, first operands first): MFMA phase 4.14k
 //         instead of 3.91k cycles, 2 % slower;
+//   (v)   the tile epilogue on the producer waves through a GLOBAL-memory hand-over of the raw accumulators (consumers
+//         dump 32 x 16 bytes per lane and go on; producers post-process one row per chunk of the next tile, loads one
+//         chunk ahead, stores ahead of the next DMA batch; commit 6797d3f): parity-green, 4-8 % slower in three variants
+//         (row after the DMA batch, row steps between the DMA instructions, row written phase-wise for ILP) -- beside the
+//         MFMA wave of its SIMD a producer wave issues ONE INSTRUCTION PER 10-13 CYCLES whatever its priority or
+//         dependencies, i.e. ~600 instructions per 7.6k-cycle chunk, of which the DMA issue takes ~370 and a row ~330.
 //   (iv)  PLANAR float32 activations (4 instead of 6 bytes per element in HBM and through the texture path), split into
 //         the three bf16 pieces by the producer waves (8 buffer_load_dwordx4 per lane and chunk, ~180 VALU, 12
 //         ds_write_b128): parity-green, 6 % slower -- beside an MFMA-saturating wave a producer instruction issues every
@@ -198,16 +204,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
   const unsigned tl_tile = (a.dbg >> 16) ? (unsigned)(a.dbg >> 16) : 2u;   // MISONET_WS_DEBUG bits 16+: the tile to stamp
   unsigned long long tl_base = 0;
 #define STAMP(TI) do { if (tl && (TI) == tl_tile && tl_i < 28) { const unsigned long long c_ = clock64(); if (!tl_i) { tl_base = c_; tl[28] = wall_clock64(); } tl[tl_i++] = c_ - tl_base; tl[31] = tl_i; tl[29] = wall_clock64(); } } while (0)
-
-  // DEFERRED EPILOGUE (8-row stride-1 tiles with at least 9 chunks): the consumers only dump the raw accumulators of a
-  // finished tile into a per-workgroup scratch in global memory (32 x 16-byte stores per lane) and go on with the next
-  // tile; the PRODUCER waves, which otherwise only issue the DMA, run ELU + statistics + split + stores of its eight
-  // rows, one row per K-chunk of the next tile, in the shadow of the consumers' MFMAs on the same SIMD.  The last tile of
-  // a workgroup keeps the consumer epilogue (nothing left to hide behind).
-  constexpr bool CAN_DEFER = (MODE == 0 && FTR == 8);
-  const bool deferred = CAN_DEFER && nchunk >= 9 && a.act && a.out_oct == 3 && a.epi_scratch != nullptr && !(a.dbg & 32);
-  // scratch of this workgroup: [2 slots][8 rows][4 waves][4 quads][64 lanes] float4
-  float4* const epi_s = reinterpret_cast<float4*>(a.epi_scratch) + (size_t)blockIdx.x * (2 * 8 * 4 * 4 * 64);
 
   const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
   const unsigned per = (unsigned)(a.ntx * a.nty * a.ncg);                    // tiles per sample
@@ -260,7 +256,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
   }
 
     // chunk KC of the cursor's tile -> stage SB (xo walks one octet plane per chunk)
-#define DMA_STAGE(KC, SB, HOOK)                                                                                 \
+#define DMA_STAGE(KC, SB)                                                                                       \
   {                                                                                                             \
     bf16x8* st_ = s_stage + (SB) * SN;                                                                          \
     _Pragma("unroll") for (int i = 0; i < NXI; ++i) {                                                           \
@@ -273,7 +269,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
         }                                                                                                       \
       }                                                                                                         \
       if (xo[i] != 0x80000000u) xo[i] += P16;                                                                   \
-      HOOK(i)                                                                                                   \
     }                                                                                                           \
     const unsigned wsoff_ = (unsigned)(KC) * (unsigned)X6_WU * 16u;                                             \
     _Pragma("unroll") for (int i = 0; i < NWI; ++i) {                                                           \
@@ -283,10 +278,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, MN_LDS(st_ + 3 * XN + ub), 16, wo + (unsigned)i * 4096u, \
                                                    wsoff_, 0, 0);                                               \
       }                                                                                                         \
-      HOOK(NXI + i)                                                                                             \
     }                                                                                                           \
   }
-#define NO_HOOK(I)
 
     // epilogue tables of the cursor's tile, set TS: half-wave h of producer wave rw builds output row f0 + rw + 4 h, lane & 31 =
     // output channel
@@ -357,7 +350,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
     // issue cursor: the next chunk to put in flight = chunk ci_kc of this workgroup's tile number ci_t
     unsigned ci_g = 0, ci_t = 0;
     int ci_kc = 0;
-#define ISSUE_NEXT_H(HOOK)                                                                                      \
+#define ISSUE_NEXT()                                                                                            \
   {                                                                                                             \
     if (ci_g < G) {                                                                                             \
       if (ci_kc == 0) {                                                                                         \
@@ -365,217 +358,34 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
         TILE_SETUP()                                                                                            \
         TILE_TABLES(ci_t % NS, ci_t & 3)                                                                        \
       }                                                                                                         \
-      if (!(a.dbg & 64)) DMA_STAGE(ci_kc, ci_g % NS, HOOK)                                                      \
+      if (!(a.dbg & 64)) DMA_STAGE(ci_kc, ci_g % NS)                                                            \
       ++ci_g;                                                                                                   \
       if (++ci_kc == nchunk) { ci_kc = 0; ++ci_t; }                                                             \
     }                                                                                                           \
   }
-#define ISSUE_NEXT() ISSUE_NEXT_H(NO_HOOK)
-    // ---- deferred epilogue state (producer wave rw post-processes the rows of consumer wave rw) ----
-    const unsigned OP16 = (unsigned)a.Fout * (unsigned)Tp * 16u;               // bytes per output octet plane
-    int p1_n = 0, p1_cg = 0, p1_f0 = 0, p1_t0 = 0;             // the tile whose rows are being post-processed
-    float4 eqa[4], eqb[4];                                     // raw accumulator rows (even / odd), loaded one chunk ahead
-    unsigned eP[3][4][2];                                      // split row waiting for its stores (issued AHEAD of the next DMA batch)
-    unsigned e_vo = 0x80000000u;
-    bool e_ok0 = false, e_ok1 = false, e_store = false, e_run = false;
-    f32x2_e es1[8], es2[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { es1[i] = f32x2_e{0.f, 0.f}; es2[i] = f32x2_e{0.f, 0.f}; }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { eqa[q] = make_float4(0.f, 0.f, 0.f, 0.f); eqb[q] = eqa[q]; }
-    int stats_pending = -1;                                    // tile whose producer-made partials wait for TILE_STATS
-    int n_pref = 0;                                            // scratch loads issued behind the latest DMA batch
-
-    // stores of the row split in the previous iteration (same three descriptors as conv_epilogue_rows_nb)
-#define EPI_STORES()                                                                                            \
-  {                                                                                                             \
-    if (e_store) {                                                                                              \
-      const unsigned long long pa_ = reinterpret_cast<unsigned long long>(a.out) +                              \
-                                     (unsigned long long)p1_n * a.out_bstride * 4ull + (unsigned long long)(a.out_c0 >> 3) * OP16; \
-      const unsigned long long pb_ = (unsigned long long)(a.out_sstride >> 3) * OP16;                           \
-      const unsigned nrec_ = (unsigned)(a.Cout >> 3) * OP16;                                                    \
-      __amdgpu_buffer_rsrc_t ers_[3];                                                                           \
-      ers_[0] = make_rsrc_e(pa_, nrec_);                                                                        \
-      ers_[1] = make_rsrc_e(pa_ + pb_, nrec_);                                                                  \
-      ers_[2] = make_rsrc_e(pa_ + 2 * pb_, nrec_);                                                              \
-      _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                                           \
-        if (k == 0 ? e_ok0 : e_ok1) {                                                                           \
-          _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                       \
-            const u32x4_t u_ = {eP[p][2 * k][0], eP[p][2 * k][1], eP[p][2 * k + 1][0], eP[p][2 * k + 1][1]};    \
-            __builtin_amdgcn_raw_buffer_store_b128(u_, ers_[p], e_vo + (unsigned)(2 * k) * OP16, 0, 0);         \
-          }                                                                                                     \
-        }                                                                                                       \
-      }                                                                                                         \
-      e_store = false;                                                                                          \
-    }                                                                                                           \
-  }
-    // accumulator row ROW of tile p1 (slot SL of the scratch) -> registers
-#define EPI_LOAD(EQ, SL, ROW)                                                                                   \
-  {                                                                                                             \
-    const float4* sp_ = epi_s + ((((SL) * 8 + (ROW)) * 4 + rw) * 4) * 64 + lane;                                \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) EQ[q] = sp_[q * 64];                                          \
-    n_pref = 4;                                                                                                 \
-  }
-    // The row epilogue of the producers, written PHASE-WISE over the 16 values of the row (all multiplies, then all
-    // exponentials, ...) with scheduling barriers between the phases: beside the MFMA wave of its SIMD a producer wave
-    // issues a DEPENDENT instruction only every 10-13 cycles, so the 8 element pairs must be in flight together.
-    // EQ: register set of the row (output row ROW of tile p1), CS: set of the centre table.
-#define EPI_ROW(EQ, ROW, CS)                                                                                    \
-  {                                                                                                             \
-    f32x2_e x_[8], e_[8];                                                                                       \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                             \
-      x_[2 * q] = f32x2_e{EQ[q].x, EQ[q].y}; x_[2 * q + 1] = f32x2_e{EQ[q].z, EQ[q].w};                         \
-    }                                                                                                           \
-    const int f_ = p1_f0 + (ROW);                                                                               \
-    const int t_ = p1_t0 + 32 * rw + l31;                                                                       \
-    const bool ok_ = f_ < a.Fout && t_ < T;                                                                     \
-    const float mf_ = ok_ ? 1.f : 0.f;                                                                          \
-    const float4* pc_ = reinterpret_cast<const float4*>(s_ctr + (CS) * COP + half * 16);                        \
-    f32x2_e c_[8];                                                                                              \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                             \
-      const float4 cc_ = pc_[q];                                                                                \
-      c_[2 * q] = f32x2_e{cc_.x, cc_.y}; c_[2 * q + 1] = f32x2_e{cc_.z, cc_.w};                                 \
-    }                                                                                                           \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) e_[i] = x_[i] * f32x2_e{1.4426950408889634f, 1.4426950408889634f}; \
-    __builtin_amdgcn_sched_barrier(0);                                                                          \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) { e_[i].x = __builtin_amdgcn_exp2f(e_[i].x); e_[i].y = __builtin_amdgcn_exp2f(e_[i].y); } \
-    __builtin_amdgcn_sched_barrier(0);                                                                          \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) e_[i] = e_[i] - f32x2_e{1.f, 1.f};                            \
-    __builtin_amdgcn_sched_barrier(0);                                                                          \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                             \
-      x_[i].x = x_[i].x > 0.f ? x_[i].x : e_[i].x;                                                              \
-      x_[i].y = x_[i].y > 0.f ? x_[i].y : e_[i].y;                                                              \
-    }                                                                                                           \
-    __builtin_amdgcn_sched_barrier(0);                                                                          \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) x_[i] = x_[i] - c_[i];                                        \
-    __builtin_amdgcn_sched_barrier(0);                                                                          \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) e_[i] = x_[i] * f32x2_e{mf_, mf_};                            \
-    __builtin_amdgcn_sched_barrier(0);                                                                          \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                             \
-      es1[i] = es1[i] + e_[i];                                                                                  \
-      es2[i].x = fmaf(e_[i].x, e_[i].x, es2[i].x);                                                              \
-      es2[i].y = fmaf(e_[i].y, e_[i].y, es2[i].y);                                                              \
-    }                                                                                                           \
-    __builtin_amdgcn_sched_barrier(0);                                                                          \
-    /* exact 3-way split of the 8 pairs, phase-wise (split3_pair_t, conv_epilogue.hpp) */                        \
-    unsigned hu_[8], mu_[8];                                                                                    \
-    f32x2_e r_[8];                                                                                              \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                               \
-      hu_[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(x_[i], bf16x2_t));                          \
-    __builtin_amdgcn_sched_barrier(0);                                                                          \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                               \
-      r_[i] = x_[i] - f32x2_e{__builtin_bit_cast(float, hu_[i] << 16), __builtin_bit_cast(float, hu_[i] & 0xffff0000u)}; \
-    __builtin_amdgcn_sched_barrier(0);                                                                          \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                               \
-      mu_[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r_[i], bf16x2_t));                          \
-    __builtin_amdgcn_sched_barrier(0);                                                                          \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                               \
-      r_[i] = r_[i] - f32x2_e{__builtin_bit_cast(float, mu_[i] << 16), __builtin_bit_cast(float, mu_[i] & 0xffff0000u)}; \
-    __builtin_amdgcn_sched_barrier(0);                                                                          \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                             \
-      const int o = i >> 1, d = i & 1;            /* pair i = values 4 o + 2 d, + 1: dword d of octet part o */    \
-      eP[0][o][d] = hu_[i]; eP[1][o][d] = mu_[i];                                                               \
-      eP[2][o][d] = __builtin_bit_cast(unsigned, __builtin_convertvector(r_[i], bf16x2_t));                     \
-    }                                                                                                           \
-    __builtin_amdgcn_sched_barrier(0);                                                                          \
-    _Pragma("unroll") for (int k = 0; k < 2; ++k)                                                               \
-      _Pragma("unroll") for (int p = 0; p < 3; ++p)                                                             \
-        _Pragma("unroll") for (int d = 0; d < 2; ++d) {                                                         \
-          auto rr_ = __builtin_amdgcn_permlane32_swap(eP[p][2 * k][d], eP[p][2 * k + 1][d], false, false);      \
-          eP[p][2 * k][d] = rr_[0]; eP[p][2 * k + 1][d] = rr_[1];                                               \
-        }                                                                                                       \
-    e_vo = (unsigned)(f_ * Tp + t_) * 16u + (unsigned)(half + (p1_cg * COP >> 3)) * OP16;                       \
-    e_ok0 = ok_ && (p1_cg * COP + (0 + half) * 8 < a.Cout);                                                     \
-    e_ok1 = ok_ && (p1_cg * COP + (2 + half) * 8 < a.Cout);                                                     \
-    e_store = true;                                                                                             \
-  }
-    // this wave's partial sums of tile p1 -> s_red set RS (what a consumer's epilogue writes)
-#define EPI_REDUCE(RS)                                                                                          \
-  {                                                                                                             \
-    float f1_[16], f2_[16];                                                                                     \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                             \
-      f1_[2 * i] = es1[i].x; f1_[2 * i + 1] = es1[i].y; f2_[2 * i] = es2[i].x; f2_[2 * i + 1] = es2[i].y;       \
-      es1[i] = f32x2_e{0.f, 0.f}; es2[i] = f32x2_e{0.f, 0.f};                                                   \
-    }                                                                                                           \
-    const float x1_ = reduce16_halfwave(f1_, lane);                                                             \
-    const float x2_ = reduce16_halfwave(f2_, lane);                                                             \
-    if ((lane & 16) == 0) {                                                                                     \
-      const int q_ = lane & 15;                                                                                 \
-      const int co_l_ = (q_ & 3) + 8 * (q_ >> 2) + 4 * half;                                                    \
-      float* sr_ = s_red + (RS) * (4 * COP * 2) + rw * (COP * 2);                                               \
-      sr_[co_l_ * 2 + 0] = x1_;                                                                                 \
-      sr_[co_l_ * 2 + 1] = x2_;                                                                                 \
-    }                                                                                                           \
-  }
-
 #pragma unroll
     for (int i = 0; i < NS - 1; ++i) ISSUE_NEXT()
     unsigned bt = 0;                                           // tile of chunk b - 1
     int bkc = -1;                                              // its chunk index (-1 before the first barrier)
-#define PSTAMP(TI) do { if (!(a.dbg & 0x8000) || bkc >= 7) STAMP(TI); } while (0)
     for (unsigned b = 0; b <= G; ++b) {
-      PSTAMP(bt);
-      // everything the DMA issued has landed (hipcc does not count LDS-DMA loads); the scratch loads of the deferred
-      // epilogue, issued BEHIND the DMA batch, may stay in flight (loads return in order)
-      if (n_pref) x6_wait_vm<4>(); else x6_wait_vm<0>();
-      PSTAMP(bt);
+      STAMP(bt);
+      x6_wait_vm<0>();                                         // everything issued has landed (hipcc does not count LDS-DMA loads)
+      STAMP(bt);
       __syncthreads();                                         // barrier b
-      PSTAMP(bt);
-      // deferred epilogue of tile bt - 1 during the chunks of tile bt: row r is loaded behind the DMA batch of chunk r,
-      // post-processed behind the DMA batch of chunk r + 1 and stored ahead of the DMA batch of chunk r + 2
-      const bool e_tile = CAN_DEFER && deferred && bt >= 1 && bkc >= 0;
-      e_run = e_tile && bkc >= 1 && bkc <= 8;
-      if (CAN_DEFER && deferred) {
-        if (stats_pending >= 0) { TILE_STATS(stats_pending) stats_pending = -1; }
-        EPI_STORES()                                           // the row split during the previous chunk
-        if (e_tile && bkc == 0) {
-          const unsigned kj_ = slot + (bt - 1) * (unsigned)nslots;
-          const unsigned grp_ = kj_ / per;
-          unsigned tile_ = kj_ - grp_ * per;
-          p1_n = (int)(grp_ * 8u + xcd);
-          p1_f0 = (int)(tile_ % (unsigned)a.nty) * FTR;
-          tile_ /= (unsigned)a.nty;
-          p1_cg = (int)(tile_ % (unsigned)a.ncg);
-          p1_t0 = (int)(tile_ / (unsigned)a.ncg) * TT;
-        }
-        ISSUE_NEXT()                                           // chunk b + NS - 1
-        if (e_run) {                                           // row bkc - 1 of tile bt - 1, loaded during the previous chunk
-          if (bkc & 1) { EPI_ROW(eqa, bkc - 1, (bt - 1) & 3u) } else { EPI_ROW(eqb, bkc - 1, (bt - 1) & 3u) }
-          if (bkc == 8) { EPI_REDUCE((bt - 1) & 1u) stats_pending = (int)(bt - 1); }
-        }
-      } else {
-        // the consumers finished the epilogue of tile bt - 1 before they entered the first chunk of tile bt
-        if (bkc == 0 && bt >= 1) TILE_STATS(bt - 1)
-        ISSUE_NEXT()                                           // chunk b + NS - 1
-      }
-      PSTAMP(bt);
-      n_pref = 0;
-      asm volatile("" ::: "memory");                           // the scratch loads below stay BEHIND the DMA batch
-      __builtin_amdgcn_sched_barrier(0);
-      if (e_tile && bkc <= 7) {                                // row bkc of tile bt - 1 -> the register set of its parity
-        const unsigned sl_ = (bt - 1) & 1u;
-        if (bkc & 1) { EPI_LOAD(eqb, sl_, bkc) } else { EPI_LOAD(eqa, sl_, bkc) }
-      }
+      STAMP(bt);
+      // the consumers finished the epilogue of tile bt - 1 before they entered the first chunk of tile bt
+      if (bkc == 0 && bt >= 1) TILE_STATS(bt - 1)
+      ISSUE_NEXT()                                             // chunk b + NS - 1
+      STAMP(bt);
       if (bkc >= 0 && ++bkc == nchunk) { bkc = 0; ++bt; } else if (bkc < 0) bkc = 0;
     }
-#undef PSTAMP
     __syncthreads();                                           // final barrier: the last epilogue is done
-    if (CAN_DEFER && deferred) {
-      EPI_STORES()
-      if (stats_pending >= 0) TILE_STATS(stats_pending)
-    }
     TILE_STATS(ntile - 1)
-#undef EPI_STORES
-#undef EPI_LOAD
-#undef EPI_ROW
-#undef EPI_REDUCE
 #undef TILE_SETUP
 #undef DMA_STAGE
 #undef TILE_TABLES
 #undef TILE_STATS
 #undef ISSUE_NEXT
-#undef ISSUE_NEXT_H
-#undef NO_HOOK
   } else {
     // =============================================== consumers ===============================================
     unsigned k = slot;
@@ -600,18 +410,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
         __syncthreads();                                       // barrier g + 1: done reading chunk g
         STAMP(ti);
       }
-      if (CAN_DEFER && deferred && k + (unsigned)nslots < nk) {
-        // hand the raw accumulators to the producers (slot ti & 1 of the scratch); they are read behind the next barrier
-        float4* sp_ = epi_s + (((ti & 1u) * 8) * 4 + wave) * 4 * 64 + lane;
-#pragma unroll
-        for (int r = 0; r < FTR; ++r)
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            sp_[(r * 4 * 4 + q) * 64] = make_float4(acc[r][4 * q + 0], acc[r][4 * q + 1], acc[r][4 * q + 2], acc[r][4 * q + 3]);
-      } else if (!(a.dbg & 4)) {
+      if (!(a.dbg & 4))
         conv_epilogue_rows_nb<3>(a, acc, n, cg, f0, t0 + 32 * wave, lane, s_red + (ti & 1) * (4 * COP * 2) + wave * (COP * 2), FTR,
                                  a.act ? s_ctr + (ti & 3) * COP : nullptr);
-      }
       ++ti;
       k += (unsigned)nslots;
       if (k >= nk) break;
@@ -790,11 +591,6 @@ hipError_t launch_conv_bf16x6(const ConvArgs& a_in, int n_samples, hipStream_t s
     if (cap > 0 && nslots > cap) nslots = cap;
   }
   const dim3 pgrid((unsigned)(8 * nslots), 1, 1);
-  {
-    static int defer = -1;                                         // MISONET_X6_DEFER=0: consumer epilogue everywhere (A/B runs)
-    if (defer < 0) { const char* e = getenv("MISONET_X6_DEFER"); defer = e ? atoi(e) : 1; }
-    if (!defer || pgrid.x > (unsigned)X6_EPI_WG) a.epi_scratch = nullptr;
-  }
   if (mode == 0 && ftr == 8) hipLaunchKernelGGL((conv3x3_bf16x6<0, 8>), pgrid, dim3(512), x6_lds_bytes(10, 8), s, a, nslots);
   else if (mode == 0) hipLaunchKernelGGL((conv3x3_bf16x6<0, 4>), pgrid, dim3(512), x6_lds_bytes(6, 4), s, a, nslots);
   else if (mode == 1) hipLaunchKernelGGL((conv3x3_bf16x6<1, 4>), pgrid, dim3(512), x6_lds_bytes(9, 4), s, a, nslots);

@@ -57,7 +57,6 @@ struct ConvArgs {
   int xcd;                  // 1: 1-D grid with the XCD-aware tile order of conv_tile() (ntx, nty, nsamp valid)
   int ntx, nty, nsamp;      // frame tiles, row tiles, samples of this launch
   unsigned long long* dbg_buf;   // timeline stamps of one workgroup (MISONET_TIMELINE=1, experiments only)
-  float* epi_scratch;            // bf16x6: accumulator hand-over area of the deferred epilogue (X6_EPI_WG x 256 KB) or null
   int dbg;                  // timing experiments only (MISONET_WS_DEBUG bits): 1 skip MFMAs, 4 skip epilogue, 8 skip stores,
                             // 16 skip statistics reductions, 32 no deferred epilogue
 };
@@ -109,8 +108,6 @@ hipError_t launch_conv_bf16x6(const ConvArgs& a, int n_samples, hipStream_t s);
 hipError_t launch_conv_wprep6(const ConvArgs& a, const float* wf6, int n_samples, hipStream_t s);
 hipError_t conv_bf16x6_init();
 long long conv_bf16x6_wps_bytes(int Cin, int Cout);   // per-sample folded-weight bytes of one layer
-constexpr int X6_EPI_WG = 320;                        // workgroups the hand-over area is sized for
-constexpr long long X6_EPI_WG_BYTES = 2LL * 8 * 4 * 4 * 64 * 16;   // [2 slots][8 rows][4 waves][4 quads][64 lanes] float4
 
 // ---- TCN (reference model.py:486-632) -----------------------------------------------------------------------------
 // x0 = IN2d(raw) materialised as the residual stream + its per-(n,c) statistics

@@ -122,7 +122,6 @@ struct Layout {
   long long data_base;           // bytes from ws start to the float arena
   long long wps_base, wps_nstride;   // bytes: per-sample folded weights of the layer in flight (DMA dataflow)
   long long btab_base, btab_nstride; // bytes / floats: per-sample border-aware shift table
-  long long epi_base;                // bytes: accumulator hand-over area of the bf16x6 deferred epilogue (0 = none)
   long long total_bytes;
 };
 
@@ -345,11 +344,6 @@ static Layout make_layout(const misonet_net* n, int N, int T) {
   L.btab_base = align_up(L.wps_base + wmax * N, 256);
   L.btab_nstride = cmax * 9 * 4;                    // up to 4 shares of the shift table (conv_wprep6_k)
   L.total_bytes = L.btab_base + L.btab_nstride * 4 * N;
-  L.epi_base = 0;
-  if (n->precision == 3) {
-    L.epi_base = align_up(L.total_bytes, 256);
-    L.total_bytes = L.epi_base + (long long)X6_EPI_WG * X6_EPI_WG_BYTES;
-  }
   return L;
 }
 
@@ -380,7 +374,6 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
   a.ncg = c.ncg; a.cop = c.cop;
   a.dbg = 0;
   a.dbg_buf = nullptr;
-  a.epi_scratch = L.epi_base ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + L.epi_base) : nullptr;
   a.xcd = 0; a.ntx = a.nty = a.nsamp = 0;
   a.in_oct = a.out_oct = 0; a.wps = nullptr; a.wps_nstride = 0; a.btab = nullptr; a.btab_nstride = 0;
   if (nb < 0) nb = L.N;
