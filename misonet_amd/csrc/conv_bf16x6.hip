@@ -142,7 +142,9 @@ __device__ __forceinline__ void chunk_mfma6(f32x16 (&acc)[NROW], const bf16x8* s
 // 8 CUs are active and at ~12 B/clk when all 256 are (tools/gpu_x6_slots.sh), i.e. that tile is CO-LIMITED by the matrix
 // pipe and by bytes through the texture path.  8-ROW tiles: 76 KB per 216 MFMAs = 10 B/clk at the MFMA rate, the
 // producers have slack, the barrier wait is 0.17k and a chunk takes 7.6k cycles = 35 per MFMA (tile incl. epilogue:
-// 35.5 instead of 43.4).  The shader clock (s_memtime against s_memrealtime inside the kernel) answers with 1.56 instead
+// 35.5 instead of 43.4).  (What the stamps showed as a 5.6-8.9k wait at the LAST barrier of a tile was the producers'
+// set-up of the coming tile -- three integer divisions, 36 dependent table loads behind a full DMA queue, ~500
+// instructions at one per 12 cycles; it is now spread over three iterations, see ISSUE_NEXT: +2-3 %.)  The shader clock (s_memtime against s_memrealtime inside the kernel) answers with 1.56 instead
 // of 1.68 GHz -- the part is power-limited, a third of the cycle gain goes back -- so a layer gains 6-10 % in time.
 //
 // Measured and NOT kept (git history):
@@ -234,6 +236,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
     const int btab_parts = nchunk >= 8 ? 4 : (nchunk >= 4 ? 2 : 1);          // conv_bf16x6_btab_parts
     __amdgpu_buffer_rsrc_t rs_x0, rs_x1, rs_x2, rs_w;
     unsigned xo[NXI];
+    int xr_[NXI], xj_[NXI];                                    // staged row / slot of this lane's units (the same in every tile)
+#pragma unroll
+    for (int i = 0; i < NXI; ++i) {
+      const int u = (i * 4 + rw) * 64 + lane;
+      xr_[i] = u / X6_TW;
+      xj_[i] = u - xr_[i] * X6_TW;
+    }
 
 #define TILE_SETUP()                                                                                            \
   {                                                                                                             \
@@ -246,11 +255,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
     rs_w = make_rsrc_e(reinterpret_cast<unsigned long long>(a.wps) + (unsigned long long)n * a.wps_nstride +    \
                            (unsigned long long)cg * wbytes, wbytes);                                            \
     _Pragma("unroll") for (int i = 0; i < NXI; ++i) {                                                           \
-      const int u = (i * 4 + rw) * 64 + lane;                                                                   \
-      const int r = u / X6_TW, j = u - r * X6_TW;                                                               \
-      const int fin = fin0_ + r;                                                                                \
-      const int t = t0 - 1 + j;                                                                                 \
-      const bool ok = u < XN && fin >= 0 && fin < Fin && t >= 0 && t < T;                                       \
+      const int fin = fin0_ + xr_[i];                                                                           \
+      const int t = t0 - 1 + xj_[i];                                                                            \
+      const bool ok = xr_[i] < NR && fin >= 0 && fin < Fin && t >= 0 && t < T;                                  \
       xo[i] = ok ? ((unsigned)((a.in_c0 >> 3) * Fin + fin) * (unsigned)Tp + (unsigned)t) * 16u : 0x80000000u;   \
     }                                                                                                           \
   }
@@ -283,19 +290,35 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
 
     // epilogue tables of the cursor's tile, set TS: half-wave h of producer wave rw builds output row f0 + rw + 4 h, lane & 31 =
     // output channel
-#define TILE_TABLES(TS, CS)                                                                                      \
+    // in two parts, so that the table loads can be put in flight AHEAD of a DMA batch and consumed behind it
+    float tv_[4][9], tbias_ = 0.f;
+#pragma unroll
+    for (int p_ = 0; p_ < 4; ++p_)
+#pragma unroll
+      for (int j_ = 0; j_ < 9; ++j_) tv_[p_][j_] = 0.f;
+#define TABLES_LOAD()                                                                                           \
+  {                                                                                                             \
+    const int rr_ = rw + 4 * (lane >> 5), lc_ = lane & 31;                                                      \
+    if (rr_ < FTR) {                                                                                            \
+      tbias_ = a.bias[cg * COP + lc_];                                                                          \
+      if (a.btab) {                                                                                             \
+        const float* bt_ = a.btab + (long long)n * a.btab_nstride + (long long)(cg * COP + lc_) * 9;            \
+        const long long pst_ = (long long)a.ncg * COP * 9;          /* floats between the shares of the table */  \
+        /* all shares of the table in flight together (36 independent loads), summed in the fixed order p = 0..3 */ \
+        _Pragma("unroll") for (int p_ = 0; p_ < 4; ++p_) {                                                      \
+          const int pc_ = p_ < btab_parts ? p_ : btab_parts - 1;                                                \
+          _Pragma("unroll") for (int j_ = 0; j_ < 9; ++j_) tv_[p_][j_] = bt_[pc_ * pst_ + j_];                  \
+        }                                                                                                       \
+      }                                                                                                         \
+    }                                                                                                           \
+  }
+#define TABLES_FINISH(TS, CS)                                                                                   \
   {                                                                                                             \
     const int rr_ = rw + 4 * (lane >> 5), lc_ = lane & 31;                                                      \
     if (rr_ < FTR) {                                                                                            \
       const int f_ = f0 + rr_;                                                                                  \
       float b3[3] = {0.f, 0.f, 0.f};                                                                            \
       if (a.btab) {                                                                                             \
-        const float* bt_ = a.btab + (long long)n * a.btab_nstride + (long long)(cg * COP + lc_) * 9;            \
-        const long long pst_ = (long long)a.ncg * COP * 9;          /* floats between the shares of the table */  \
-        /* all shares of the table in flight together (36 independent loads), summed in the fixed order p = 0..3 */ \
-        float tv_[4][9];                                                                                        \
-        _Pragma("unroll") for (int p_ = 0; p_ < 4; ++p_)                                                        \
-          _Pragma("unroll") for (int j_ = 0; j_ < 9; ++j_) tv_[p_][j_] = p_ < btab_parts ? bt_[p_ * pst_ + j_] : 0.f; \
         _Pragma("unroll") for (int kf = 0; kf < 3; ++kf) {                                                      \
           bool ok_;                                                                                             \
           if (TR2) {                                                                                            \
@@ -307,12 +330,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
           }                                                                                                     \
           _Pragma("unroll") for (int kt = 0; kt < 3; ++kt) {                                                    \
             float v_ = tv_[0][kt * 3 + kf];                                                                     \
-            _Pragma("unroll") for (int p_ = 1; p_ < 4; ++p_) v_ += tv_[p_][kt * 3 + kf];                        \
+            _Pragma("unroll") for (int p_ = 1; p_ < 4; ++p_) v_ += p_ < btab_parts ? tv_[p_][kt * 3 + kf] : 0.f; \
             b3[kt] += ok_ ? v_ : 0.f;                                                                           \
           }                                                                                                     \
         }                                                                                                       \
       }                                                                                                         \
-      b3[1] += a.bias[cg * COP + lc_];                                                                          \
+      b3[1] += tbias_;                                                                                          \
       /* accumulator order: channel co = (i&3) + 8*(i>>2) + 4*h  ->  h = (co>>2)&1, i = (co&3) + 4*(co>>3) */    \
       const int slot_ = (rr_ * 2 + ((lc_ >> 2) & 1)) * 16 + (lc_ & 3) + 4 * (lc_ >> 3);                         \
       float* tb_ = s_tab + (TS) * (3 * FTR * COP);                                                              \
@@ -322,9 +345,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
       /* centre of the stored activations per channel: ELU(bias) -- the pre-activation of normalised inputs has mean   */ \
       /* bias exactly.  (NOT the accumulator start value: bias - sum W' mean_in is far from the output when |mean_in|  */ \
       /* >> std_in.)                                                                                                    */ \
-      if (rr_ == 0) s_ctr[(CS) * COP + slot_] = elu_fast(a.bias[cg * COP + lc_]);                               \
+      if (rr_ == 0) s_ctr[(CS) * COP + slot_] = elu_fast(tbias_);                                               \
     }                                                                                                           \
   }
+#define TILE_TABLES(TS, CS) { TABLES_LOAD() TABLES_FINISH(TS, CS) }
 
     // float64 statistics of finished tile number J of this workgroup (producer wave 0): sum of the four consumer partials
     // (the partials are sums of the STORED, centred values: conv_epilogue_rows_nb's s_ctr)
@@ -350,26 +374,50 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
     // issue cursor: the next chunk to put in flight = chunk ci_kc of this workgroup's tile number ci_t
     unsigned ci_g = 0, ci_t = 0;
     int ci_kc = 0;
+    // The set-up of the COMING tile (~500 producer instructions) is spread over the three iterations before the switch:
+    // the loads of its epilogue tables behind the third-to-last DMA batch of the current tile (they stay in flight across
+    // the barrier), the tables themselves ahead of the second-to-last batch, its descriptors and offsets behind the last
+    // one (in one piece at the switch it made the consumers wait 5.6-8.9k cycles per tile).
+    bool tab_loaded = false;                                   // table loads of the coming tile are in flight
 #define ISSUE_NEXT()                                                                                            \
   {                                                                                                             \
     if (ci_g < G) {                                                                                             \
-      if (ci_kc == 0) {                                                                                         \
-        TILE_COORDS(slot + ci_t * (unsigned)nslots)                                                             \
-        TILE_SETUP()                                                                                            \
-        TILE_TABLES(ci_t % NS, ci_t & 3)                                                                        \
+      const bool nxt_ = ci_t + 1 < ntile;                                                                       \
+      if (tab_loaded) {                                    /* loaded behind the previous DMA batch */           \
+        TABLES_FINISH((ci_t + 1) % NS, (ci_t + 1) & 3)                                                          \
+        tab_loaded = false;                                                                                     \
       }                                                                                                         \
       if (!(a.dbg & 64)) DMA_STAGE(ci_kc, ci_g % NS)                                                            \
       ++ci_g;                                                                                                   \
-      if (++ci_kc == nchunk) { ci_kc = 0; ++ci_t; }                                                             \
+      ++ci_kc;                                                                                                  \
+      if (nxt_) {                                                                                               \
+        if (nchunk >= 3 && ci_kc == nchunk - 2) {          /* behind the third-to-last DMA batch */             \
+          x6_wait_vm<0>();                                 /* the DMA batch has landed: nothing to count at the barrier */ \
+          TILE_COORDS(slot + (ci_t + 1) * (unsigned)nslots)                                                     \
+          TABLES_LOAD()                                                                                         \
+          tab_loaded = true;                                                                                    \
+        }                                                                                                       \
+        if (ci_kc == nchunk) {                                                                                  \
+          TILE_COORDS(slot + (ci_t + 1) * (unsigned)nslots)                                                     \
+          if (nchunk < 3) TILE_TABLES((ci_t + 1) % NS, (ci_t + 1) & 3)                                          \
+          TILE_SETUP()                                                                                          \
+        }                                                                                                       \
+      }                                                                                                         \
+      if (ci_kc == nchunk) { ci_kc = 0; ++ci_t; }                                                               \
     }                                                                                                           \
   }
+    TILE_COORDS(slot)
+    TILE_SETUP()
+    TILE_TABLES(0, 0)
 #pragma unroll
     for (int i = 0; i < NS - 1; ++i) ISSUE_NEXT()
     unsigned bt = 0;                                           // tile of chunk b - 1
     int bkc = -1;                                              // its chunk index (-1 before the first barrier)
     for (unsigned b = 0; b <= G; ++b) {
       STAMP(bt);
-      x6_wait_vm<0>();                                         // everything issued has landed (hipcc does not count LDS-DMA loads)
+      // everything the DMA issued has landed (hipcc does not count LDS-DMA loads); when the table loads of the coming
+      // tile are in flight, the DMA batch was waited for before they were issued and they may cross the barrier
+      if (!tab_loaded) x6_wait_vm<0>();
       STAMP(bt);
       __syncthreads();                                         // barrier b
       STAMP(bt);
@@ -384,6 +432,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
 #undef TILE_SETUP
 #undef DMA_STAGE
 #undef TILE_TABLES
+#undef TABLES_LOAD
+#undef TABLES_FINISH
 #undef TILE_STATS
 #undef ISSUE_NEXT
   } else {
