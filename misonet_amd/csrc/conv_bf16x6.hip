@@ -205,7 +205,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
   int tl_i = 0;
   const unsigned tl_tile = (a.dbg >> 16) ? (unsigned)(a.dbg >> 16) : 2u;   // MISONET_WS_DEBUG bits 16+: the tile to stamp
   unsigned long long tl_base = 0;
-#define STAMP(TI) do { if (tl && (TI) == tl_tile && tl_i < 28) { const unsigned long long c_ = clock64(); if (!tl_i) { tl_base = c_; tl[28] = wall_clock64(); } tl[tl_i++] = c_ - tl_base; tl[31] = tl_i; tl[29] = wall_clock64(); } } while (0)
+#define STAMP(TI) do { if (tl && ((TI) == tl_tile || ((TI) == tl_tile + 1 && tl_i == 2 * nchunk)) && tl_i < 28) { const unsigned long long c_ = clock64(); if (!tl_i) { tl_base = c_; tl[28] = wall_clock64(); } tl[tl_i++] = c_ - tl_base; tl[31] = tl_i; tl[29] = wall_clock64(); } } while (0)
 
   const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
   const unsigned per = (unsigned)(a.ntx * a.nty * a.ncg);                    // tiles per sample
