@@ -110,6 +110,26 @@ def test_device_handling(sd1, sd3):
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16x6", "f16x3", "bf16x3"])
+def test_one_chunk_layers(mode):
+    """8-channel dense-block growth: layers of ONE and TWO 8-channel K-chunks (the bf16x6 producers fold the set-up of the
+    coming tile into fewer iterations there) and output groups of 8 channels."""
+    _need_gpu()
+    import misonet_amd as mz
+    from misonet_amd import weights as W
+    from oracle import miso_oracle
+    en, de = (8, 16, 40, 32, 48, 64, 128), (128, 64, 48, 32, 40, 16, 8)
+    sd = W.make_state_dict(W.tensor_spec(12, 4, en, de), seed=9)
+    m = mz.MISO_1(2, 6, 7, list(en), list(de), "IN").cuda(0)
+    m.load_state_dict(sd)
+    m.eval().set_precision(mode)
+    r = np.random.default_rng(43)
+    x = (r.standard_normal((2, 6, 150, 129)) + 1j * r.standard_normal((2, 6, 150, 129))).astype(np.complex64)
+    y = m(torch.from_numpy(x).cuda()).cpu().numpy()
+    ref = np.concatenate([miso_oracle.miso1_forward(torch.from_numpy(x[b:b + 1]), sd).numpy() for b in range(2)])
+    _assert_parity(y, ref, f"[{mode}] 8-channel growth (en={en})")
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x6", "f16x3", "bf16x3"])
 def test_non_default_geometry(mode):
     """A geometry other than config/NN_BSS.yml's: 4 microphones, 3 speakers, bottleneck channels
     (16,24,40,32,48,64,128) -- output groups of 16/24/40/48 channels, 2-chunk layers, a dense block that grows to 200
