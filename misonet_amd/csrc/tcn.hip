@@ -82,9 +82,10 @@ constexpr int DW_HALO = 64;                        // largest dilation of Tempor
 constexpr int DW_SEG = DW_MAXT - 2 * DW_HALO;      // output frames per segment
 __global__ __launch_bounds__(256) void tcn_dw_k(const float* x, const double* x_stats, const float* wdw,
                                                 const float* prelu, float* d, double* gln_stats, int C, int T,
-                                                int Tp, int dil) {
+                                                int Tp, int dil, int seg_f) {
   __shared__ double s_tmp[4][2];
-  __shared__ __align__(16) float s_a[4][DW_MAXT];
+  extern __shared__ __align__(16) float s_a_dyn[];             // [4 rows][row_f]: row_f = frames of a segment + 2 halos
+  const int row_f = seg_f + 2 * DW_HALO;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 4 + wave, n = blockIdx.y;
   float mean, rstd;
@@ -94,13 +95,13 @@ __global__ __launch_bounds__(256) void tcn_dw_k(const float* x, const double* x_
   const float slope = prelu[0];
   const float* src = x + ((long long)n * C + c) * Tp;
   float* dst = d + ((long long)n * C + c) * Tp;
-  float* a = s_a[wave];
+  float* a = s_a_dyn + wave * row_f;
   const int Tq = (T + 3) & ~3;
   double r1 = 0.0, r2 = 0.0;
-  for (int ts = 0; ts < Tq; ts += DW_SEG) {
+  for (int ts = 0; ts < Tq; ts += seg_f) {
     if (ts) __syncthreads();                                             // the previous segment is consumed
     // LDS slot j holds frame ts - DW_HALO + j
-    for (int j = lane * 4; j < DW_MAXT; j += 256) {
+    for (int j = lane * 4; j < row_f; j += 256) {
       const int t = ts - DW_HALO + j;
       float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
       if (t >= 0 && t < Tq) {                                            // Tp is a multiple of 32 >= Tq
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256) void tcn_dw_k(const float* x, const double* x_
       *reinterpret_cast<float4*>(a + j) = o;
     }
     __syncthreads();
-    const int te = (ts + DW_SEG < Tq) ? ts + DW_SEG : Tq;
+    const int te = (ts + seg_f < Tq) ? ts + seg_f : Tq;
     float s1 = 0.f, s2 = 0.f;
     for (int t = ts + lane * 4; t < te; t += 256) {
       float o[4];
@@ -402,8 +403,12 @@ hipError_t launch_tcn_dw(const float* x, const double* x_stats, const float* wdw
                          double* gln_stats, int C, int T, int Tp, int dilation, int n_samples, hipStream_t s) {
   if (dilation < 1 || dilation > DW_HALO) return hipErrorInvalidValue;
   if (C % 4) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(tcn_dw_k, dim3(C / 4, n_samples), dim3(256), 0, s, x, x_stats, wdw, prelu, d, gln_stats, C, T, Tp,
-                     dilation);
+  // LDS row = the frames of one segment + two halos: a 4-second utterance (T = 1001) takes 18 KB per workgroup instead
+  // of the 32 KB of a full 1920-frame segment, i.e. 8 instead of 5 workgroups per CU of this latency-bound kernel
+  const int tq = (T + 3) & ~3;
+  const int seg_f = tq < DW_SEG ? tq : DW_SEG;
+  hipLaunchKernelGGL(tcn_dw_k, dim3(C / 4, n_samples), dim3(256), (size_t)4 * (seg_f + 2 * DW_HALO) * sizeof(float), s, x,
+                     x_stats, wdw, prelu, d, gln_stats, C, T, Tp, dilation, seg_f);
   return hipGetLastError();
 }
 
