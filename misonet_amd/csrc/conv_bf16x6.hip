@@ -611,7 +611,14 @@ hipError_t launch_conv_bf16x6(const ConvArgs& a_in, int n_samples, hipStream_t s
   static int tl_env = -1, tl_done = 0;
   static unsigned long long* tl_buf = nullptr;
   if (tl_env < 0) { const char* e = getenv("MISONET_TIMELINE"); tl_env = e ? atoi(e) : 0; }
-  const bool do_tl = tl_env && tl_done < 2 && !a.tr2 && a.sf == 1 && a.Cin == tl_env && a.Fout == 63 && n_samples >= 8;
+  static int tl_f = 63, tl_mode = 0;                               // MISONET_TIMELINE_F / _MODE: which layer (defaults: F = 63, stride 1)
+  if (tl_env > 0 && tl_done == 0) {
+    const char* ef = getenv("MISONET_TIMELINE_F");
+    const char* em = getenv("MISONET_TIMELINE_MODE");
+    if (ef) tl_f = atoi(ef);
+    if (em) tl_mode = atoi(em);
+  }
+  const bool do_tl = tl_env && tl_done < 2 && (a.tr2 ? 2 : (a.sf == 2 ? 1 : 0)) == tl_mode && a.Cin == tl_env && a.Fout == tl_f && n_samples >= 8;
   if (do_tl) {
     if (!tl_buf && hipMalloc(reinterpret_cast<void**>(&tl_buf), 64 * 8) != hipSuccess) tl_buf = nullptr;
     if (tl_buf) { (void)hipMemsetAsync(tl_buf, 0, 64 * 8, s); a.dbg_buf = tl_buf; }
