@@ -600,8 +600,7 @@ __device__ __forceinline__ void conv_epilogue_rows_nb_impl(const ConvArgs& a, f3
       v[2 * i2] = x.x; v[2 * i2 + 1] = x.y;
       const f32x2_e vm = MASKED ? x * m2 : x;
       s1[i2] = s1[i2] + vm;
-      s2[i2].x = fmaf(vm.x, vm.x, s2[i2].x);
-      s2[i2].y = fmaf(vm.y, vm.y, s2[i2].y);
+      s2[i2] = __builtin_elementwise_fma(vm, vm, s2[i2]);   // one v_pk_fma_f32 (the two fused multiply-adds, bit for bit)
     }
     if (a.dbg & 8) continue;
     if (a.out_oct) {
