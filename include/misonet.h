@@ -66,7 +66,7 @@ int misonet_net_commit(misonet_net* net);
  *               (24 bits), the six leading partial products are accumulated in float32 (the dropped ones are < 2^-23
  *               of a product, one float32 rounding); activations travel pre-split (oct3 layout: hi | mid | lo, 8 channels
  *               per 16-byte unit), the instance norm is folded into per-sample weights, staging is LDS-DMA.  Same error
- *               against the reference as mode 0 (2.3e-6 per forward) at 1.5-1.6 x its speed: what bench.py reports;
+ *               against the reference as mode 0 (2.3e-6 per forward) at 1.65 x its speed: what bench.py reports;
  *   4 "f16x3"   operands rounded to two fp16 pieces (22 bits; the weights carry a per-layer power-of-two scale), three
  *               terms, float32 accumulation: measured at or below mode 0's error on well-conditioned data (1.9e-6 per
  *               forward) at mode 2's cost, but 2.4 x mode 0 under |mean| >> std and limited to fp16's range;
