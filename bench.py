@@ -9,9 +9,11 @@ N > 1: either launched by the driver as ``python -m torch.distributed.run --npro
 
 A "step" = one pass of the complete reference semantics (6 x MISO_1 forward over the circular mic shifts +
 shift alignment + clean alignment + 2 x MVDR + 2 x MISO_3 forward; reference tester.py:865-939) over one batch of
-synthetic 6-mic / 16 kHz / 4 s utterances (T = 1001 frames, F = 129) already resident in HBM.  Workload =
-BASELINE.json configs[3] (batch 16 per GPU, full pipeline); utterances are sharded over ranks with no data-path
-collective (weak scaling).  Prints ONE JSON line on rank 0.
+synthetic 6-mic / 16 kHz / 4 s utterances (T = 1001 frames, F = 129) already resident in HBM.  Workload at N = 1 =
+BASELINE.json configs[3] (batch 16, full pipeline); at N = 8 = configs[4] (batch 128 = 8 x 16): utterances are sharded
+over ranks with no data-path collective (weak scaling; ``config.workload`` names what ran).  ``--verify-gather`` adds the
+path's one collective (all_gather of the results over RCCL) after the timed loop, checked by the oracle.  Prints ONE
+JSON line on rank 0.
 
 The timed loop is un-instrumented.  The headline arithmetic is fp32-faithful (``HEADLINE_PRECISION``); the other
 arithmetic modes are timed beside it with the same steps / warm-up and reported under ``alt_precision``.
@@ -132,7 +134,7 @@ def run_steps(enh, mix, clean, out, steps, warmup, dist, L, _lib, profile):
 
 def _traffic_entry(precision):
     """measured HBM bytes per conv launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/)"""
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", name)))
             if precision in tj:
@@ -168,6 +170,10 @@ def roofline_objects(precision, B, T, steps, dt_conv_ms, n_launch):
               "traffic": traffic,
               "traffic_over_layout_bytes": round(traffic / (lay_step * steps / max(n_launch, 1)), 3) if traffic else None,
               "traffic_source": (tsrc + " (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, x2 fetch correction)") if tsrc else None,
+              # the three PMC-derived fields (traffic, mfma_busy_frac_pmc, clock_ghz_observed_pmc) are COMMITTED
+              # measurements of the same command on another box / day, read from that file -- not counters of this run
+              # (counters need their own rocprofv3 --pmc passes); everything else on the line is measured live
+              "pmc_fields_measured_live": False,
               "mfma_busy_frac_pmc": tj.get("mfma_busy_frac") if tj else None,
               # engine clock seen in the PMC pass (the peaks below are the guide's 2.4 GHz figures; under the bf16 MFMA
               # load the part is power-limited)
@@ -191,6 +197,18 @@ def roofline_objects(precision, B, T, steps, dt_conv_ms, n_launch):
     ai = flops_step / bytes_step
     binding = r_mfma if ai >= eff_peak * 1e12 / (PEAK_HBM_TBS * 1e12) else r_hbm
     return binding, (r_hbm if binding is r_mfma else r_mfma)
+
+
+def workload_name(world, B):
+    """BASELINE.json's name of what this launch runs: configs[3] = batch 16 on one GPU, configs[4] = batch 128 sharded over
+    8 GPUs (8 x 16); other rank counts / batch sizes run configs[4]'s sharding at their own global batch."""
+    pipe = "synthetic 6-mic 16 kHz 4 s, full MISO1x6 -> align -> MVDRx2 -> MISO3x2"
+    if world == 1:
+        return f"BASELINE configs[3]: {pipe}" + ("" if B == 16 else f" (batch {B} instead of 16)")
+    if world == 8 and B == 16:
+        return f"BASELINE configs[4]: {pipe}, batch 128 sharded over 8 GPUs (8 x 16), no data-path collective"
+    return (f"BASELINE configs[4] sharding at {world} ranks: {pipe}, global batch {world * B} = {world} x {B} "
+            f"(configs[4] itself is 8 x 16), no data-path collective")
 
 
 def free_port():
@@ -222,6 +240,10 @@ def main():
     ap.add_argument("--no-alt", action="store_true", help="skip the runs of the other precision modes (N = 1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the event-instrumented pass (no roofline object)")
+    ap.add_argument("--verify-gather", action="store_true",
+                    help="after the timed loop: all_gather every rank's enhanced spectrograms over the process group (RCCL "
+                         "on GPUs; 33 MB per rank at batch 16, SURVEY.md 8(e)) and let rank 0 check one utterance that came "
+                         "from the LAST rank against the CPU oracle; adds gather_ms / gather_parity to the line")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -289,6 +311,32 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         rccl_ranks = dist.get_world_size()
+    # ---- optional: the one collective of the path (result gather, outside the timed loop), verified by the oracle ----
+    gather = None
+    if args.verify_gather:
+        from misonet_amd.pipeline import gather_outputs
+        enh.enhance(mix, clean, check_nan=False, out=out)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        tg = time.perf_counter()
+        allout = gather_outputs(out, world * B) if dist is not None else out
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        if rank == 0:
+            from oracle import pipeline_oracle
+            u = (world - 1) * B                              # first utterance of the LAST rank's shard
+            obs, s0, s1 = W.synthetic_utterance(u, n)
+            mx = pipeline_oracle.stft_chunk(obs)
+            cl = np.stack([pipeline_oracle.stft_chunk(s0)[0], pipeline_oracle.stft_chunk(s1)[0]])
+            ref = pipeline_oracle.enhance_utterance(mx, cl, sd1, sd3, ref_ch=0)["out"]
+            got = allout[u].cpu().numpy()
+            err = float(np.linalg.norm(np.abs(got) - np.abs(ref)) / np.linalg.norm(np.abs(ref)))
+            gather = {"gather_ms": round(gather_ms, 3), "gathered_shape": list(allout.shape),
+                      "bytes_per_rank": int(out.numel() * 8),
+                      "gather_parity": {"utterance": u, "from_rank": world - 1,
+                                        "rel_l2_magnitudes_vs_oracle": float(f"{err:.3e}"), "tolerance": 1e-3,
+                                        "ok": bool(np.isfinite(err) and err < 1e-3)}}
     # ---- roofline leg: the same steps once more with HIP events around every launch ----
     prof = None
     if not args.no_profile:
@@ -340,13 +388,16 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "fp32_faithful": MODES[args.precision][2],
             "operand_bits": MODES[args.precision][3], "data": "synthetic",
-            "config": {"workload": "BASELINE configs[3]: synthetic 6-mic 16 kHz 4 s, full MISO1x6 -> align -> MVDRx2 -> MISO3x2",
-                       "batch_per_gpu": B, "frames": T, "freq_bins": 129, "parallelism": f"utterance-shard x{world}"},
+            "config": {"workload": workload_name(world, B),
+                       "batch_per_gpu": B, "global_batch": world * B, "frames": T, "freq_bins": 129,
+                       "parallelism": f"utterance-shard x{world}"},
             "realtime_factor": round(value * (n / 16000.0), 2),
             "rccl_ranks": rccl_ranks, "per_rank_utt_per_s": [round(v, 3) for v in per_rank],
             "parity": (cpu or {}).pop("parity_of_headline", None) if cpu else None,
             "roofline": roof, "roofline_other": roof2, "alt_precision": alts, "cpu_baseline": cpu,
         }
+        if gather:
+            line.update(gather)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -61,12 +61,12 @@ int misonet_net_commit(misonet_net* net);
 
 /* arithmetic of the 3x3 convolutions (99.4 % of the FLOPs; the reference computes them in float32, model.py:77-80,
  * 401-482):
- *   0 "f32"     exact float32 matrix cores (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain); the default of a new handle;
- *   3 "bf16x6"  fp32-FAITHFUL on the bf16 matrix cores: both operands are represented exactly as three bf16 pieces
+ *   0 "f32"     exact float32 matrix cores (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain);
+ *   3 "bf16x6"  (the DEFAULT of a new handle, and what bench.py reports) fp32-FAITHFUL on the bf16 matrix cores: both operands are represented exactly as three bf16 pieces
  *               (24 bits), the six leading partial products are accumulated in float32 (the dropped ones are < 2^-23
  *               of a product, one float32 rounding); activations travel pre-split (oct3 layout: hi | mid | lo, 8 channels
  *               per 16-byte unit), the instance norm is folded into per-sample weights, staging is LDS-DMA.  Same error
- *               against the reference as mode 0 (2.3e-6 per forward) at 1.65 x its speed: what bench.py reports;
+ *               against the reference as mode 0 (2.3e-6 per forward) at 1.65 x its speed;
  *   4 "f16x3"   operands rounded to two fp16 pieces (22 bits; the weights carry a per-layer power-of-two scale), three
  *               terms, float32 accumulation: measured at or below mode 0's error on well-conditioned data (1.9e-6 per
  *               forward) at mode 2's cost, but 2.4 x mode 0 under |mean| >> std and limited to fp16's range;
@@ -91,8 +91,14 @@ int misonet_net_forward(misonet_net* net, int n_seg, const void* const* seg_dev,
 /* synchronises the stream and reports MISONET_ENAN if the last forward on this workspace produced a NaN */
 int misonet_net_check(misonet_net* net, const void* ws_dev, misonet_stream stream);
 
+/* Workspace liveness: by default activation buffers whose lifetimes do not overlap share memory (the only cross-level
+ * lifetime of the reference is the skip list xs, model.py:84-99): 0.26 GB per forward-sample at T = 1001 in mode 3
+ * instead of 0.55.  keep != 0 gives every buffer its own memory so that every tap below stays readable after a forward;
+ * the workspace size changes (ask misonet_net_workspace_bytes again). */
+int misonet_net_keep_activations(misonet_net* net, int keep);
 /* test/diagnostic taps: copy an intermediate activation of the LAST forward (still in ws_dev) out as float32
- * [B, C, T, F] in the reference's layout and normalisation.  Names: enc0_conv, enc0..enc6, tcn_out, dec0..dec6. */
+ * [B, C, T, F] in the reference's layout and normalisation.  Names: enc0_conv, enc0..enc6, tcn_out, dec0..dec6.
+ * Needs misonet_net_keep_activations(net, 1) BEFORE that forward (MISONET_ESTATE otherwise), except dec6 (the output). */
 int misonet_net_tap_shape(const misonet_net* net, const char* name, int* C, int* F);
 int misonet_net_tap(misonet_net* net, const char* name, const void* ws_dev, int B, int T, float* dst_dev,
                     misonet_stream stream);
@@ -110,8 +116,10 @@ int misonet_mvdr_debug(const void* ws_dev, int B, int F, int M, void* steer_c128
 
 /* ---- PIT speaker alignment (tester.py:1043-1065 and 889-915) ----------------------------------------------- */
 /* anchor_dev, cand_dev: complex64 [B, S, T, F]; sel_dev: int32 [B, S] with aligned speaker i = cand[sel[i]];
- * dist_dev (required: it is the call's only scratch, so the call allocates nothing and stays asynchronous): float64
- * [B, S, S], receives dist[i][j] = sum_{t,f} | |anchor_i| - |cand_j| |.  All S! permutations are enumerated in
+ * dist_dev (required: it is the call's only scratch, so the call allocates nothing and stays asynchronous): float64,
+ * B*S*S*(F+1) elements.  The first [B, S, S] receive dist[i][j] = sum_{t,f} | |anchor_i| - |cand_j| |; the rest holds
+ * the per-bin partial sums [B, F, S, S], which are added in bin order (no atomics: the distances and the selected
+ * permutation are bit-reproducible from run to run).  All S! permutations are enumerated in
  * itertools.permutations order with the first minimum winning, as the reference's einsum('bij,pij->bp') + argmin
  * (tester.py:1053-1064); 1 <= S <= 4. */
 int misonet_pit_select(const void* anchor_dev, const void* cand_dev, int B, int S, int T, int F,

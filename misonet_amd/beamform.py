@@ -70,8 +70,8 @@ def pit_select(anchor, cand, return_dist=False):
         raise ValueError("anchor and cand must both be [B, S, T, F]")
     B, S, T, F = a.shape
     sel = torch.empty((B, S), dtype=torch.int32, device=a.device)
-    dist = torch.empty((B, S, S), dtype=torch.float64, device=a.device)
+    dist = torch.empty((B * (F + 1), S, S), dtype=torch.float64, device=a.device)    # result [B,S,S] + per-bin partials
     with torch.cuda.device(a.device):
         _lib.check(_lib.lib().misonet_pit_select(a.data_ptr(), c.data_ptr(), B, S, T, F, sel.data_ptr(), dist.data_ptr(),
                                                  _lib.stream_ptr(a.device)))
-    return (sel, dist) if return_dist else sel
+    return (sel, dist[:B]) if return_dist else sel

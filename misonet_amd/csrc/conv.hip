@@ -20,7 +20,8 @@
 #include "kernels.hpp"
 #include <stdlib.h>
 #include "conv_epilogue.hpp"
-#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+#include <atomic>
 
 namespace mn {
 
@@ -129,10 +130,10 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0) ? 3 : 2)
   for (int c = tid; c < nchunk * CK; c += 256) {
     float mean = 0.f, rstd = (c < Cin) ? 1.f : 0.f;       // channels beyond Cin stage as zeros
     if (c >= a.ident_c && c < Cin) {
-      const double* st = a.in_stats + ((long long)n * a.in_sstride + a.in_c0 + c) * 2;
+      const dstat_t* st = a.in_stats + ((long long)n * a.in_sstride + a.in_c0 + c) * (2 * DS_NL);
       const double cnt = (double)Fin * (double)T;
-      const double m = st[0] / cnt;
-      double var = st[1] / cnt - m * m;
+      const double m = dstat_read(st) / cnt;
+      double var = dstat_read(st + DS_NL) / cnt - m * m;
       var = var > 0.0 ? var : 0.0;
       mean = (float)m;
       rstd = (float)(1.0 / sqrt(var + (double)IN_EPS));
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0) ? 3 : 2)
         float tot = 0.f;
         for (int w = 0; w < FT; ++w)
           if (f0 + w < a.Fout) tot += s_red[(w * COP + co_l) * 2 + which];
-        unsafeAtomicAdd(a.out_stats + ((long long)n * a.out_sstride + a.out_c0 + co) * 2 + which, (double)tot);
+        dstat_add(a.out_stats + (((long long)n * a.out_sstride + a.out_c0 + co) * 2 + which) * DS_NL, (double)tot);
       }
     }
   }
@@ -315,6 +316,18 @@ hipError_t conv_init() {
   if ((e = set_lds_attr<1, 2, 4>()) != hipSuccess) return e;
   if ((e = set_lds_attr<2, 0, 4>()) != hipSuccess) return e;
   return set_lds_attr<2, 2, 4>();
+}
+
+int device_cus() {
+  static std::atomic<int> cus[64];                   // 0 = not asked yet
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+  int c = cus[dev].load(std::memory_order_relaxed);
+  if (!c) {
+    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) return -1;
+    cus[dev].store(c, std::memory_order_relaxed);
+  }
+  return c;
 }
 
 int conv_xcd_env() {

@@ -16,7 +16,6 @@
 #include "kernels.hpp"
 #include "conv_epilogue.hpp"
 #include "conv_bf16_core.hpp"
-#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -59,10 +58,10 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 1) ? 2 : 1)) void conv3x
   for (int c = tid; c < nchunk * CKB; c += 256) {
     float mean = 0.f, rstd = (c < Cin) ? 1.f : 0.f;       // channels beyond Cin stage as zeros
     if (c >= a.ident_c && c < Cin) {
-      const double* st = a.in_stats + ((long long)n * a.in_sstride + a.in_c0 + c) * 2;
+      const dstat_t* st = a.in_stats + ((long long)n * a.in_sstride + a.in_c0 + c) * (2 * DS_NL);
       const double cnt = (double)Fin * (double)T;
-      const double m = st[0] / cnt;
-      double var = st[1] / cnt - m * m;
+      const double m = dstat_read(st) / cnt;
+      double var = dstat_read(st + DS_NL) / cnt - m * m;
       var = var > 0.0 ? var : 0.0;
       mean = (float)m;
       rstd = (float)(1.0 / sqrt(var + (double)IN_EPS));
@@ -262,7 +261,7 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 1) ? 2 : 1)) void conv3x
         float tot = 0.f;
         for (int w = 0; w < FT; ++w)
           if (f0 + w < a.Fout) tot += s_red[(w * COP + co_l) * 2 + which];
-        unsafeAtomicAdd(a.out_stats + ((long long)n * a.out_sstride + a.out_c0 + co) * 2 + which, (double)tot);
+        dstat_add(a.out_stats + (((long long)n * a.out_sstride + a.out_c0 + co) * 2 + which) * DS_NL, (double)tot);
       }
     }
   }

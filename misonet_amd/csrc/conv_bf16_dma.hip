@@ -17,7 +17,6 @@
 #include "kernels.hpp"
 #include "conv_epilogue.hpp"
 #include "conv_bf16_core.hpp"
-#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -272,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_dma(const ConvArgs a) {
       if (co < a.Cout) {
         float tot = 0.f;
         for (int w = 0; w < 4; ++w) tot += s_red[(w * COP + co_l) * 2 + which];
-        unsafeAtomicAdd(a.out_stats + ((long long)n * a.out_sstride + a.out_c0 + co) * 2 + which, (double)tot);
+        dstat_add(a.out_stats + (((long long)n * a.out_sstride + a.out_c0 + co) * 2 + which) * DS_NL, (double)tot);
       }
     }
   }
@@ -521,7 +520,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
       if (co < a.Cout) {                                                                                        \
         float tot = 0.f;                                                                                        \
         for (int w = 0; w < 4; ++w) tot += sr_[(w * COP + co_l) * 2 + which];                                   \
-        unsafeAtomicAdd(a.out_stats + ((long long)(PN) * a.out_sstride + a.out_c0 + co) * 2 + which, (double)tot); \
+        dstat_add(a.out_stats + (((long long)(PN) * a.out_sstride + a.out_c0 + co) * 2 + which) * DS_NL, (double)tot); \
       }                                                                                                         \
     }                                                                                                           \
   }
@@ -729,7 +728,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_dma2(const ConvArgs a, 
 // F16 (f16x3 mode): the pieces are fp16 and carry the layer's power-of-two scale `wscale` (so that the lo pieces of small
 // weights stay in fp16's normal range); btab stays unscaled (the consumer scales the accumulator start values).
 template <bool F16>
-__global__ __launch_bounds__(288) void conv_wprep_k(const float* wf, const double* in_stats, int in_sstride, int in_c0,
+__global__ __launch_bounds__(288) void conv_wprep_k(const float* wf, const dstat_t* in_stats, int in_sstride, int in_c0,
                                                     int Cin, int ident_c, int Fin, int T, int nchunk, int ncg,
                                                     unsigned short* wps, long long wps_nstride_b, float* btab,
                                                     long long btab_nstride, float wscale) {
@@ -739,10 +738,10 @@ __global__ __launch_bounds__(288) void conv_wprep_k(const float* wf, const doubl
   for (int c = tid; c < nchunk * CKB; c += 288) {
     float mean = 0.f, rstd = (c < Cin) ? 1.f : 0.f;
     if (c >= ident_c && c < Cin) {
-      const double* st = in_stats + ((long long)n * in_sstride + in_c0 + c) * 2;
+      const dstat_t* st = in_stats + ((long long)n * in_sstride + in_c0 + c) * (2 * DS_NL);
       const double cnt = (double)Fin * (double)T;
-      const double m = st[0] / cnt;
-      double var = st[1] / cnt - m * m;
+      const double m = dstat_read(st) / cnt;
+      double var = dstat_read(st + DS_NL) / cnt - m * m;
       var = var > 0.0 ? var : 0.0;
       mean = (float)m;
       rstd = (float)(1.0 / sqrt(var + (double)IN_EPS));
@@ -886,13 +885,8 @@ hipError_t launch_conv_bf16_dma(const ConvArgs& a_in, int n_samples, hipStream_t
   if (dma2_env && dma2_ok) {
     if (mode == 1) (void)conv_grid(a, n_samples, TT, 2, 1);          // tile geometry with 2 output rows
     // persistent launch: one workgroup per CU, capped by the largest per-XCD tile list
-    static int g_cus = 0;
-    if (!g_cus) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-      g_cus = prop.multiProcessorCount;
-    }
+    const int g_cus = device_cus();
+    if (g_cus <= 0) return hipErrorUnknown;
     const long long nk_max = (long long)((n_samples + 7) / 8) * a.ntx * a.nty * a.ncg;
     int nslots = g_cus / 8;
     if (nslots < 1) nslots = 1;

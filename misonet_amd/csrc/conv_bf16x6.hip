@@ -36,7 +36,6 @@
 #include "kernels.hpp"
 #include "conv_epilogue.hpp"
 #include "conv_bf16_core.hpp"
-#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -130,7 +129,7 @@ __device__ __forceinline__ void chunk_mfma6(f32x16 (&acc)[NROW], const bf16x8* s
 // ---------------------------------------------------------------------------------------------------------------------
 // ONE persistent workgroup per CU, 8 waves: waves 0-3 = consumers (MFMAs + tile epilogue), waves 4-7 = producers (LDS-DMA,
 // epilogue tables of the coming tile, float64 statistics atomics of finished tiles).  Workgroup b belongs to XCD b & 7 and
-// walks that XCD's own samples (n % 8 == xcd) tile by tile, row tile fastest.  K-chunks are numbered across tiles; chunk
+// walks that XCD's own units (samples n % 8 == xcd, or (sample, frame tile) columns) tile by tile, row tile fastest.  K-chunks are numbered across tiles; chunk
 // c lives in stage c & 1.  ONE workgroup barrier per chunk: barrier b separates chunk b - 1 from chunk b; producers
 // arrive at it when chunk b has landed, consumers when they are done reading chunk b - 1; behind it the producers put
 // chunk b + 1 into the stage that chunk b - 1 occupied (the first chunk of the next tile is in flight during an epilogue).
@@ -207,9 +206,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
   unsigned long long tl_base = 0;
 #define STAMP(TI) do { if (tl && ((TI) == tl_tile || ((TI) == tl_tile + 1 && tl_i == 2 * nchunk)) && tl_i < 28) { const unsigned long long c_ = clock64(); if (!tl_i) { tl_base = c_; tl[28] = wall_clock64(); } tl[tl_i++] = c_ - tl_base; tl[31] = tl_i; tl[29] = wall_clock64(); } } while (0)
 
+  // Unit of XCD locality (unit u belongs to XCD u % 8): a whole SAMPLE when the number of samples is a multiple of 8 (a.xcd
+  // == 1: the per-sample folded weights and every halo are fetched into one L2 only), else a (sample, frame tile) COLUMN
+  // (a.xcd == 2, u = n * ntx + tt): all row tiles and channel groups of a column share their halo rows / re-read the same
+  // input, columns of one sample share only 2 of 130 staged frames -- so every XCD has work for any number of samples
+  // (B = 1 of the reference harness: 6 and 2 samples; launch_conv_bf16x6 picks the mode).
   const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-  const unsigned per = (unsigned)(a.ntx * a.nty * a.ncg);                    // tiles per sample
-  const unsigned nk = (unsigned)((a.nsamp + 7 - (int)xcd) / 8) * per;        // tiles of this XCD's samples
+  const unsigned ux = a.xcd == 2 ? (unsigned)a.ntx : 1u;                     // units per sample
+  const unsigned per = (unsigned)(a.nty * a.ncg) * (a.xcd == 2 ? 1u : (unsigned)a.ntx);   // tiles per unit
+  const unsigned nunit = (unsigned)a.nsamp * ux;
+  const unsigned nk = ((nunit + 7u - xcd) / 8u) * per;                       // tiles of this XCD's units
   if (slot >= nk) return;
   const unsigned ntile = (nk - slot + (unsigned)nslots - 1u) / (unsigned)nslots;   // tiles of this workgroup
   const unsigned G = ntile * (unsigned)nchunk;                               // its chunks
@@ -219,11 +225,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
   {                                                                                                             \
     const unsigned grp_ = (K) / per;                                                                            \
     unsigned tile_ = (K) - grp_ * per;                                                                          \
-    n = (int)(grp_ * 8u + xcd);                                                                                 \
+    const unsigned unit_ = grp_ * 8u + xcd;                                                                     \
+    n = (int)(unit_ / ux);                                                                                      \
     f0 = (int)(tile_ % (unsigned)a.nty) * FTR;                                                                  \
     tile_ /= (unsigned)a.nty;                                                                                   \
     cg = (int)(tile_ % (unsigned)a.ncg);                                                                        \
-    t0 = (int)(tile_ / (unsigned)a.ncg) * TT;                                                                   \
+    t0 = (int)(tile_ / (unsigned)a.ncg + (unit_ - (unsigned)n * ux)) * TT;                                      \
   }
 
   if (producer) {
@@ -358,7 +365,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
       const unsigned kj_ = slot + (unsigned)(J) * (unsigned)nslots;                                             \
       const unsigned grp_ = kj_ / per;                                                                          \
       const unsigned tile_ = kj_ - grp_ * per;                                                                  \
-      const int pn_ = (int)(grp_ * 8u + xcd);                                                                   \
+      const int pn_ = (int)((grp_ * 8u + xcd) / ux);                                                            \
       const int pcg_ = (int)((tile_ / (unsigned)a.nty) % (unsigned)a.ncg);                                      \
       const float* sr_ = s_red + ((J) & 1) * (4 * COP * 2);                                                     \
       const int co_l = lane >> 1, which = lane & 1;                                                             \
@@ -366,7 +373,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
       if (co < a.Cout) {                                                                                        \
         float tot = 0.f;                                                                                        \
         for (int w = 0; w < 4; ++w) tot += sr_[(w * COP + co_l) * 2 + which];                                   \
-        unsafeAtomicAdd(a.out_stats + ((long long)pn_ * a.out_sstride + a.out_c0 + co) * 2 + which, (double)tot); \
+        dstat_add(a.out_stats + (((long long)pn_ * a.out_sstride + a.out_c0 + co) * 2 + which) * DS_NL, (double)tot); \
       }                                                                                                         \
     }                                                                                                           \
   }
@@ -387,6 +394,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
         TABLES_FINISH((ci_t + 1) % NS, (ci_t + 1) & 3)                                                          \
         tab_loaded = false;                                                                                     \
       }                                                                                                         \
+      /* one-chunk layers: the tables of the tile being issued (first used behind the NEXT barrier).  Building the   */ \
+      /* following tile's here, as the longer layers do, would overwrite the set the consumers are reading (two sets) */ \
+      if (nchunk == 1 && ci_t >= 1) TILE_TABLES(ci_t % NS, ci_t & 3)                                            \
       if (!(a.dbg & 64)) DMA_STAGE(ci_kc, ci_g % NS)                                                            \
       ++ci_g;                                                                                                   \
       ++ci_kc;                                                                                                  \
@@ -399,7 +409,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
         }                                                                                                       \
         if (ci_kc == nchunk) {                                                                                  \
           TILE_COORDS(slot + (ci_t + 1) * (unsigned)nslots)                                                     \
-          if (nchunk < 3) TILE_TABLES((ci_t + 1) % NS, (ci_t + 1) & 3)                                          \
+          if (nchunk == 2) TILE_TABLES((ci_t + 1) % NS, (ci_t + 1) & 3)                                         \
           TILE_SETUP()                                                                                          \
         }                                                                                                       \
       }                                                                                                         \
@@ -483,7 +493,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
 //   btab : [n][nparts][ncg*32][9] float32, share p = sum over the chunks of part p of wf[..ci..] * (-mean * rstd)[n][ci]
 //          (float64 accumulation, fixed order)
 // One workgroup of 288 threads per (sample, group); thread = (tap, output channel).
-__global__ __launch_bounds__(288) void conv_wprep6_k(const float* wf, const double* in_stats, int in_sstride, int in_c0,
+__global__ __launch_bounds__(288) void conv_wprep6_k(const float* wf, const dstat_t* in_stats, int in_sstride, int in_c0,
                                                      int Cin, int ident_c, int Fin, int T, int nchunk, int ncg,
                                                      u32x4_t* wps, long long wps_nstride_b, float* btab,
                                                      long long btab_nstride, int nparts) {
@@ -498,10 +508,10 @@ __global__ __launch_bounds__(288) void conv_wprep6_k(const float* wf, const doub
   for (int c = kc_lo * 8 + tid; c < kc_hi * 8; c += 288) {
     float mean = 0.f, rstd = (c < Cin) ? 1.f : 0.f;
     if (c >= ident_c && c < Cin) {
-      const double* st = in_stats + ((long long)n * in_sstride + in_c0 + c) * 2;
+      const dstat_t* st = in_stats + ((long long)n * in_sstride + in_c0 + c) * (2 * DS_NL);
       const double cnt = (double)Fin * (double)T;
-      const double m = st[0] / cnt;
-      double var = st[1] / cnt - m * m;
+      const double m = dstat_read(st) / cnt;
+      double var = dstat_read(st + DS_NL) / cnt - m * m;
       var = var > 0.0 ? var : 0.0;
       mean = (float)m;
       rstd = (float)(1.0 / sqrt(var + (double)IN_EPS));
@@ -602,22 +612,16 @@ hipError_t launch_conv_bf16x6(const ConvArgs& a_in, int n_samples, hipStream_t s
   ConvArgs a = a_in;
   if (a.in_oct != 3 || !a.wps || a.cop != 32 || (a.Cin & 7) || (a.in_c0 & 7) || (a.in_sstride & 7)) return hipErrorInvalidValue;
   if (a.out_oct && (a.out_oct != 3 || (a.Cout & 7) || (a.out_c0 & 7) || (a.out_sstride & 7))) return hipErrorInvalidValue;
-  {
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("MISONET_WS_DEBUG"); dbg = e ? atoi(e) : 0; }
-    a.dbg = dbg;
-  }
+  // measurement hooks: read once per process (thread-safe function-local statics)
+  static const int dbg = [] { const char* e = getenv("MISONET_WS_DEBUG"); return e ? atoi(e) : 0; }();
+  a.dbg = dbg;
   a.dbg_buf = nullptr;
-  static int tl_env = -1, tl_done = 0;
+  static const int tl_env = [] { const char* e = getenv("MISONET_TIMELINE"); return e ? atoi(e) : 0; }();
+  // MISONET_TIMELINE_F / _MODE: which layer (defaults: F = 63, stride 1); the timeline itself is a single-threaded experiment
+  static const int tl_f = [] { const char* e = getenv("MISONET_TIMELINE_F"); return e ? atoi(e) : 63; }();
+  static const int tl_mode = [] { const char* e = getenv("MISONET_TIMELINE_MODE"); return e ? atoi(e) : 0; }();
+  static int tl_done = 0;
   static unsigned long long* tl_buf = nullptr;
-  if (tl_env < 0) { const char* e = getenv("MISONET_TIMELINE"); tl_env = e ? atoi(e) : 0; }
-  static int tl_f = 63, tl_mode = 0;                               // MISONET_TIMELINE_F / _MODE: which layer (defaults: F = 63, stride 1)
-  if (tl_env > 0 && tl_done == 0) {
-    const char* ef = getenv("MISONET_TIMELINE_F");
-    const char* em = getenv("MISONET_TIMELINE_MODE");
-    if (ef) tl_f = atoi(ef);
-    if (em) tl_mode = atoi(em);
-  }
   const bool do_tl = tl_env && tl_done < 2 && (a.tr2 ? 2 : (a.sf == 2 ? 1 : 0)) == tl_mode && a.Cin == tl_env && a.Fout == tl_f && n_samples >= 8;
   if (do_tl) {
     if (!tl_buf && hipMalloc(reinterpret_cast<void**>(&tl_buf), 64 * 8) != hipSuccess) tl_buf = nullptr;
@@ -626,25 +630,20 @@ hipError_t launch_conv_bf16x6(const ConvArgs& a_in, int n_samples, hipStream_t s
   const int mode = a.tr2 ? 2 : (a.sf == 2 ? 1 : 0);
   // tile geometry: 128 frames x 8 rows for the stride-1 layers with more than 4 rows (10 staged rows per 8 instead of
   // 6 per 4 and one weight image per 216 instead of 108 MFMAs: 25 % fewer staged bytes per MFMA), else x 4 rows
-  static int ft8 = -1;
-  if (ft8 < 0) { const char* e = getenv("MISONET_X6_ROWS8"); ft8 = e ? atoi(e) : 3; }   // bit 0: stride-1, bit 1: transposed
+  static const int ft8 = [] { const char* e = getenv("MISONET_X6_ROWS8"); return e ? atoi(e) : 3; }();   // bit 0: stride-1, bit 1: transposed
   const int ftr = (mode != 1 && a.Fout > 4 && (ft8 & (mode == 0 ? 1 : 2))) ? 8 : 4;
   (void)conv_grid(a, n_samples, TT, ftr, 1);
-  static int g_cus = 0;
-  if (!g_cus) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-    g_cus = prop.multiProcessorCount;
-  }
+  if (n_samples % 8) a.xcd = 2;                                    // columns, not samples, are dealt to the XCDs
+  const int g_cus = device_cus();
+  if (g_cus <= 0) return hipErrorUnknown;
   // persistent launch: one workgroup per CU, capped by the largest per-XCD tile list
-  const long long nk_max = (long long)((n_samples + 7) / 8) * a.ntx * a.nty * a.ncg;
+  const long long nk_max = a.xcd == 2 ? (long long)((n_samples * a.ntx + 7) / 8) * a.nty * a.ncg
+                                      : (long long)(n_samples / 8) * a.ntx * a.nty * a.ncg;
   int nslots = g_cus / 8;
   if (nslots < 1) nslots = 1;
   if (nslots > nk_max) nslots = (int)nk_max;
   {
-    static int cap = -1;                                           // MISONET_X6_SLOTS: workgroups per XCD (experiments)
-    if (cap < 0) { const char* e = getenv("MISONET_X6_SLOTS"); cap = e ? atoi(e) : 0; }
+    static const int cap = [] { const char* e = getenv("MISONET_X6_SLOTS"); return e ? atoi(e) : 0; }();   // workgroups per XCD (experiments)
     if (cap > 0 && nslots > cap) nslots = cap;
   }
   const dim3 pgrid((unsigned)(8 * nslots), 1, 1);

@@ -261,7 +261,9 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvArgs& a, f32x16_t (
           float x = acc[j][s][r] + bs[r];
           if (t_edge) x -= (t == 0 ? bl[r] : 0.f) + (t == T - 1 ? br[r] : 0.f);
           if (ACT) x = elu_fast(x);
-          if (CENTRE && ACT) x -= elu_fast(bs[r]);            // stored CENTRED (see conv_epilogue_impl's header)
+          // stored CENTRED about ELU(bias) (see conv_epilogue_impl's header); with s_b4 bs[r] also carries the folded
+          // shift of this row, which is not a per-channel constant: the centre always comes from the plain bias
+          if (CENTRE && ACT) x -= elu_fast(s_b4 ? a.bias[cbase + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] : bs[r]);
           v[r] = x;
           const int kr = j * 32 + (r & 3) + 8 * (r >> 2);
           const float vm = (unmasked || (tm[s] && (full_c || kr < cmax))) ? x : 0.f;
@@ -325,7 +327,7 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvArgs& a, f32x16_t (
       const int kr = j * 32 + (r & 3) + 8 * (r >> 2);
       const unsigned coff = (unsigned)(cbase + kr) * P4;                      // uniform plane offset
       float a1 = 0.f, a2 = 0.f;
-      const float cr = (CENTRE && ACT) ? elu_fast(bs[r]) : 0.f;
+      const float cr = (CENTRE && ACT) ? elu_fast(s_b4 ? a.bias[cbase + kr + 4 * half] : bs[r]) : 0.f;
       if (unmasked && !t_edge) {                                              // the common case: no masks at all
 #pragma unroll
         for (int s = 0; s < NSEG; ++s) {

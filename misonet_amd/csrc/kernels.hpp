@@ -2,12 +2,13 @@
 //
 // Activation layout in HBM ("planar"): float32 [n][c][f][Tp], frames (t) innermost, Tp = T rounded up to 32 so
 // every row starts 128-byte aligned.  Conv outputs are stored RAW (bias + ELU applied, instance norm NOT applied);
-// each producer accumulates per-(n,c) sum / sum-of-squares in float64 next to the buffer and every consumer
+// each producer accumulates per-(n,c) sum / sum-of-squares exactly (det_stats.hpp) next to the buffer and every consumer
 // normalises while it stages its input tile into LDS ("normalise on load").  Dense-block concatenation is free:
 // a block's tensors are channel slices of one buffer.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "det_stats.hpp"
 
 namespace mn {
 
@@ -24,9 +25,9 @@ inline int frames_pitch(int T) { return round_up(T, 32); }
 // ---- 3x3 convolution family (reference model.py:401-482), one launch per layer ------------------------------
 struct ConvArgs {
   const float* in;          // planar buffer base
-  const double* in_stats;   // [n][in_sstride][2] (sum, sumsq) or nullptr when every input channel is identity
+  const dstat_t* in_stats;  // [n][in_sstride][2][DS_NL] (sum, sumsq as det_stats.hpp limbs) or nullptr when every input channel is identity
   float* out;
-  double* out_stats;        // [n][out_sstride][2], accumulated with atomics when act != 0
+  dstat_t* out_stats;       // [n][out_sstride][2][DS_NL], accumulated with integer atomics (ds_add) when act != 0
   const float* w;           // packed [ncg][nchunk][9][CK][COP]
   const float* bias;        // [ncg*COP]
   const unsigned short* w16; // bf16x3 path: packed [ncg][nchunk16][hi|lo][9][2][COP][8] bf16, or nullptr
@@ -94,6 +95,7 @@ inline dim3 conv_grid(ConvArgs& a, int n_samples, int tt, int ft, int xcd) {
   return dim3(a.ntx, a.nty, n_samples * a.ncg);
 }
 int conv_xcd_env();                          // MISONET_XCD (default 1)
+int device_cus();                            // compute units of the CURRENT device (cached per device, thread-safe); <= 0 on error
 int conv_cop(int Cout);                      // 32 (Cout <= 32) or 64
 int conv_rows(int sf, int tr2);              // NR for the mode
 hipError_t launch_conv(const ConvArgs& a, int n_samples, hipStream_t s);
@@ -111,16 +113,16 @@ long long conv_bf16x6_wps_bytes(int Cin, int Cout);   // per-sample folded-weigh
 
 // ---- TCN (reference model.py:486-632) -----------------------------------------------------------------------------
 // x0 = IN2d(raw) materialised as the residual stream + its per-(n,c) statistics
-hipError_t launch_tcn_prepare(const float* raw, long long raw_bstride, int raw_c0, const double* raw_stats, int raw_sstride,
-                              float* x, double* x_stats, int C, int T, int Tp, int n_samples, hipStream_t s,
+hipError_t launch_tcn_prepare(const float* raw, long long raw_bstride, int raw_c0, const dstat_t* raw_stats, int raw_sstride,
+                              float* x, dstat_t* x_stats, int C, int T, int Tp, int n_samples, hipStream_t s,
                               int raw_oct3 = 0);   // raw_oct3: source in the bf16x6 oct3 layout
 // d = PReLU(dwconv_dilated(ELU(IN1d(x)))) ; accumulates gLN statistics (per sample) of d
-hipError_t launch_tcn_dw(const float* x, const double* x_stats, const float* wdw /*[C][3]*/, const float* prelu /*[1]*/,
-                         float* d, double* gln_stats /*[n][2]*/, int C, int T, int Tp, int dilation, int n_samples, hipStream_t s);
+hipError_t launch_tcn_dw(const float* x, const dstat_t* x_stats, const float* wdw /*[C][3]*/, const float* prelu /*[1]*/,
+                         float* d, dstat_t* gln_stats /*[n][2][DS_NL]*/, int C, int T, int Tp, int dilation, int n_samples, hipStream_t s);
 // y = pwconv(gLN(d)) (+ residual) ; accumulates IN statistics of y
-hipError_t launch_tcn_pw(const float* d, const double* gln_stats, const float* gamma, const float* beta,
+hipError_t launch_tcn_pw(const float* d, const dstat_t* gln_stats, const float* gamma, const float* beta,
                          const float* wpw /*packed [C/CK... see tcn.hip]*/, const float* residual /*or nullptr*/,
-                         float* y, long long y_bstride, int y_c0, double* y_stats /*[n][C][2]*/, int C, int T, int Tp,
+                         float* y, long long y_bstride, int y_c0, dstat_t* y_stats /*[n][C][2][DS_NL]*/, int C, int T, int Tp,
                          int n_samples, hipStream_t s,
                          int y_oct3_cbuf = 0, int x6 = 0);   // != 0: y is an oct3 buffer with that many channels (bf16x6 mode)
 
@@ -134,7 +136,7 @@ hipError_t launch_unpack(const float* src, long long src_bstride, int Tp, int S,
                          int* nan_flag, hipStream_t s);
 // planar view (+ optional instance norm) -> float32 [n][C][T][F]  (diagnostic taps)
 hipError_t launch_export(const float* src, long long src_bstride, int c0, int C, int Fq, int T, int Tp,
-                         const double* stats, int sstride, int ident_c, float* dst, int n_samples, hipStream_t s,
+                         const dstat_t* stats, int sstride, int ident_c, float* dst, int n_samples, hipStream_t s,
                          int oct = 0);   // oct: bf16 parts of a source in the oct layout (0 planar, 2, 3; sstride = channels
                                          // of the whole buffer)
 
@@ -161,14 +163,14 @@ struct COut { float* re; float* im; long long ob, os, ot, of; };
 hipError_t launch_mvdr(const MvdrArgs& a, const COut& out, void* ws, hipStream_t s);
 hipError_t launch_mvdr_debug(const void* ws, int B, int S, int F, int M, double* steer, double* w, hipStream_t s);
 
-// dist[b][i][j] = sum_{t,f} | |A_i| - |B_j| | for S = 1..4 speakers, accumulated in float64 with atomics; then sel
-// = the cheapest of the S! permutations (itertools order, first minimum).
+// dist[b][i][j] = sum_{t,f} | |A_i| - |B_j| | for S = 1..4 speakers: per-bin float64 partials, added in bin order (bit-
+// reproducible); then sel = the cheapest of the S! permutations (itertools order, first minimum).
 struct PitArgs {
   CView a, b;             // sm = speaker stride here; (b, f, spk, t) addressing
   int B, F, T;
 };
 // K candidates per anchor: grid row bk = b*K + k uses anchor b and candidate bk
-hipError_t launch_pit_dist_k(const PitArgs& p, int S, int K, double* dist /*[B*K][S][S], pre-zeroed*/, hipStream_t s);
-hipError_t launch_pit_pick(const double* dist, int S, int n, int* sel /*[n][S]*/, hipStream_t s);
+hipError_t launch_pit_dist_k(const PitArgs& p, int S, int K, double* part /*[B*K][F][S][S]*/, hipStream_t s);
+hipError_t launch_pit_pick(const double* part, int F, int S, int n, double* dist /*[n][S][S]*/, int* sel /*[n][S]*/, hipStream_t s);
 
 }  // namespace mn

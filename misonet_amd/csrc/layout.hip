@@ -88,17 +88,17 @@ __global__ __launch_bounds__(256) void unpack_k(const float* src, int Cbuf, int 
 // oct = 2 / 3 / 4: the source buffer is in the oct layout of the bf16x3 / bf16x6 / f16x3 DMA dataflow (kernels.hpp), value =
 // the sum of its pieces (exact for three bf16 parts)
 __global__ __launch_bounds__(256) void export_k(const float* src, long long src_bstride, int c0, int C, int Fq, int T,
-                                                int Tp, const double* stats, int sstride, int ident_c, float* dst,
+                                                int Tp, const dstat_t* stats, int sstride, int ident_c, float* dst,
                                                 int oct) {
   __shared__ float s_v[LFMAX][LT + 1];
   const int t0 = blockIdx.x * LT, c = blockIdx.y, n = blockIdx.z;
   const int tid = threadIdx.x;
   float mean = 0.f, rstd = 1.f;
   if (stats && c >= ident_c) {
-    const double* st = stats + ((long long)n * sstride + c0 + c) * 2;
+    const dstat_t* st = stats + ((long long)n * sstride + c0 + c) * (2 * DS_NL);
     const double cnt = (double)Fq * (double)T;
-    const double m = st[0] / cnt;
-    double var = st[1] / cnt - m * m;
+    const double m = dstat_read(st) / cnt;
+    double var = dstat_read(st + DS_NL) / cnt - m * m;
     var = var > 0.0 ? var : 0.0;
     mean = (float)m;
     rstd = (float)(1.0 / sqrt(var + (double)IN_EPS));
@@ -158,7 +158,7 @@ hipError_t launch_unpack(const float* src, long long src_bstride, int Tp, int S,
 }
 
 hipError_t launch_export(const float* src, long long src_bstride, int c0, int C, int Fq, int T, int Tp,
-                         const double* stats, int sstride, int ident_c, float* dst, int n_samples, hipStream_t s,
+                         const dstat_t* stats, int sstride, int ident_c, float* dst, int n_samples, hipStream_t s,
                          int oct) {
   if (Fq > LFMAX) return hipErrorInvalidValue;
   hipLaunchKernelGGL(export_k, dim3((T + LT - 1) / LT, C, n_samples), dim3(256), 0, s, src, src_bstride, c0, C, Fq, T,

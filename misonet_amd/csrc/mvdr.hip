@@ -10,7 +10,6 @@
 //                     w = (Phi_n + eps I)^-1 d / (d^H (Phi_n + eps I)^-1 d)   (tester.py:1211-1225)
 //   k3 mvdr_apply   : out[t] = sum_m conj(w_m) Y_m[t]                (tester.py:1227-1228)
 #include "kernels.hpp"
-#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 namespace mn {
 
@@ -410,10 +409,12 @@ hipError_t launch_mvdr_debug(const void* ws, int B, int S, int F, int M, double*
 }
 
 // ---- PIT distances, S speakers (1..4) -----------------------------------------------------------------------------
-// dist[bk][i][j] = sum_{t,f} | |A_i| - |B_j| |   (tester.py:1047-1052, 906-908), float64 accumulation.
-// grid (F, B*K): blockIdx.y = b*K + k; anchors are per b, candidates per (b, k).
+// part[bk][f][i][j] = sum_t | |A_i| - |B_j| | of frequency bin f   (tester.py:1047-1052, 906-908), float64.
+// grid (F, B*K): blockIdx.y = b*K + k; anchors are per b, candidates per (b, k).  Every reduction runs in a fixed
+// order (no atomics): pit_pick_k adds the F partials of an item in bin order, so the distances -- and with them the
+// argmin over the permutations -- are bit-reproducible.
 template <int S>
-__global__ __launch_bounds__(256) void pit_dist_k(const PitArgs p, int K, double* dist) {
+__global__ __launch_bounds__(256) void pit_dist_k(const PitArgs p, int K, double* part) {
   __shared__ double s_tmp[4][S * S];
   const int f = blockIdx.x, bk = blockIdx.y;
   const int b = bk / K;
@@ -448,17 +449,26 @@ __global__ __launch_bounds__(256) void pit_dist_k(const PitArgs p, int K, double
   __syncthreads();
   if (threadIdx.x < S * S) {
     const int i = threadIdx.x;
-    unsafeAtomicAdd(dist + (long long)bk * (S * S) + i, s_tmp[0][i] + s_tmp[1][i] + s_tmp[2][i] + s_tmp[3][i]);
+    part[((long long)bk * gridDim.x + f) * (S * S) + i] = (s_tmp[0][i] + s_tmp[1][i]) + (s_tmp[2][i] + s_tmp[3][i]);
   }
 }
 
 // sel[bk][i] = perm[i] of the cheapest permutation, cost(perm) = sum_i dist[i][perm[i]]; permutations in the order of
 // itertools.permutations (lexicographic), first minimum on ties (torch.argmin; tester.py:1053-1064, 909-915)
 template <int S>
-__global__ void pit_pick_k(const double* dist, int n, int* sel) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const double* d = dist + (long long)i * (S * S);
+__global__ __launch_bounds__(64) void pit_pick_k(const double* part, int F, double* dist, int* sel) {
+  __shared__ double s_d[S * S];
+  const int i = blockIdx.x;                          // item (b, k)
+  if (threadIdx.x < S * S) {
+    const double* q = part + (long long)i * F * (S * S) + threadIdx.x;
+    double acc = 0.0;
+    for (int f = 0; f < F; ++f) acc += q[(long long)f * (S * S)];      // fixed order: bin 0, 1, ...
+    s_d[threadIdx.x] = acc;
+    dist[(long long)i * (S * S) + threadIdx.x] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const double* d = s_d;
   int perm[S], best[S];
 #pragma unroll
   for (int k = 0; k < S; ++k) { perm[k] = k; best[k] = k; }
@@ -485,24 +495,24 @@ __global__ void pit_pick_k(const double* dist, int n, int* sel) {
   for (int k = 0; k < S; ++k) sel[i * S + k] = best[k];
 }
 
-hipError_t launch_pit_dist_k(const PitArgs& p, int S, int K, double* dist, hipStream_t s) {
+hipError_t launch_pit_dist_k(const PitArgs& p, int S, int K, double* part, hipStream_t s) {
   const dim3 g(p.F, p.B * K);
   switch (S) {
-    case 1: hipLaunchKernelGGL(pit_dist_k<1>, g, dim3(256), 0, s, p, K, dist); break;
-    case 2: hipLaunchKernelGGL(pit_dist_k<2>, g, dim3(256), 0, s, p, K, dist); break;
-    case 3: hipLaunchKernelGGL(pit_dist_k<3>, g, dim3(256), 0, s, p, K, dist); break;
-    case 4: hipLaunchKernelGGL(pit_dist_k<4>, g, dim3(256), 0, s, p, K, dist); break;
+    case 1: hipLaunchKernelGGL(pit_dist_k<1>, g, dim3(256), 0, s, p, K, part); break;
+    case 2: hipLaunchKernelGGL(pit_dist_k<2>, g, dim3(256), 0, s, p, K, part); break;
+    case 3: hipLaunchKernelGGL(pit_dist_k<3>, g, dim3(256), 0, s, p, K, part); break;
+    case 4: hipLaunchKernelGGL(pit_dist_k<4>, g, dim3(256), 0, s, p, K, part); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
-hipError_t launch_pit_pick(const double* dist, int S, int n, int* sel, hipStream_t s) {
-  const dim3 g((n + 63) / 64);
+hipError_t launch_pit_pick(const double* part, int F, int S, int n, double* dist, int* sel, hipStream_t s) {
+  const dim3 g(n);
   switch (S) {
-    case 1: hipLaunchKernelGGL(pit_pick_k<1>, g, dim3(64), 0, s, dist, n, sel); break;
-    case 2: hipLaunchKernelGGL(pit_pick_k<2>, g, dim3(64), 0, s, dist, n, sel); break;
-    case 3: hipLaunchKernelGGL(pit_pick_k<3>, g, dim3(64), 0, s, dist, n, sel); break;
-    case 4: hipLaunchKernelGGL(pit_pick_k<4>, g, dim3(64), 0, s, dist, n, sel); break;
+    case 1: hipLaunchKernelGGL(pit_pick_k<1>, g, dim3(64), 0, s, part, F, dist, sel); break;
+    case 2: hipLaunchKernelGGL(pit_pick_k<2>, g, dim3(64), 0, s, part, F, dist, sel); break;
+    case 3: hipLaunchKernelGGL(pit_pick_k<3>, g, dim3(64), 0, s, part, F, dist, sel); break;
+    case 4: hipLaunchKernelGGL(pit_pick_k<4>, g, dim3(64), 0, s, part, F, dist, sel); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -115,10 +115,12 @@ struct Tap { std::string name; int buf, c0, C; bool normalised; };
 
 struct Layout {
   int N, T, Tp;
-  long long data_off[NBUF];      // floats
-  long long stats_off[NBUF];     // doubles
-  long long tcn_xs, tcn_ps, tcn_gln;   // doubles: [15][N*128*2], [14][N*128*2], [28][N*2]
-  long long stats_doubles;
+  long long data_off[NBUF];      // floats: activation buffers (b < B_TXA): offset INSIDE a sample's block of the arena (sample n
+                                 // at + n * sample_stride); TCN buffers: offset of the whole [N][128][Tp] block
+  long long sample_stride;       // floats per sample of the activation arena
+  long long stats_off[NBUF];     // 8-byte words (dstat_t): [N][C][2][DS_NL] per buffer
+  long long tcn_xs, tcn_ps, tcn_gln;   // words: [15][N*128*2*DS_NL], [14][N*128*2*DS_NL], [28][N*2*DS_NL]
+  long long stats_doubles;       // words in all
   long long data_base;           // bytes from ws start to the float arena
   long long wps_base, wps_nstride;   // bytes: per-sample folded weights of the layer in flight (DMA dataflow)
   long long btab_base, btab_nstride; // bytes / floats: per-sample border-aware shift table
@@ -135,8 +137,9 @@ struct misonet_net {
   std::vector<Tap> taps;
   float* w_dev = nullptr;
   bool committed = false;
-  int precision = 0;             // 0: exact f32 MFMA, 1: bf16x3 planar, 2: bf16x3 DMA dataflow, 3: bf16x6 DMA dataflow,
-                                 // 4: f16x3 DMA dataflow
+  bool keep_taps = false;        // true: no buffer shares memory with another (every tap stays readable after a forward)
+  int precision = 3;             // 0: exact f32 MFMA, 1: bf16x3 planar, 2: bf16x3 DMA dataflow, 3: bf16x6 DMA dataflow (the
+                                 // default: fp32-faithful, what bench.py reports), 4: f16x3 DMA dataflow
 };
 
 static int find_tensor(const misonet_net* n, const std::string& name) {
@@ -305,10 +308,28 @@ static inline int buf_oct(const misonet_net* n, int b) {
   if (n->precision == 3 && (b == B_D0 || b == B_D1)) return 3;
   return o ? (n->precision == 3 ? 3 : (n->precision == 4 ? 4 : 1)) : 0;
 }
-// floats per sample of buffer b (an oct3 buffer holds 1.5 floats per element; C is a multiple of 8 there)
-static inline long long bstride(const misonet_net* n, const Layout& L, int b) {
-  const long long e = (long long)n->bufs[b].C * n->bufs[b].F * L.Tp;
+// floats one sample occupies in buffer b (an oct3 buffer holds 1.5 floats per element; C is a multiple of 8 there)
+static inline long long buf_floats(const misonet_net* n, int Tp, int b) {
+  const long long e = (long long)n->bufs[b].C * n->bufs[b].F * Tp;
   return buf_oct(n, b) == 3 ? e + e / 2 : e;
+}
+// floats between consecutive samples of buffer b: the activation arena is SAMPLE-major (all buffers of a sample in one
+// block, so that buffers whose lifetimes do not overlap can share memory: make_layout), the TCN buffers are buffer-major
+static inline long long bstride(const misonet_net* n, const Layout& L, int b) {
+  return b >= B_TXA ? buf_floats(n, L.Tp, b) : L.sample_stride;
+}
+
+// Lifetime of an activation buffer in steps of a forward: 0 = input written (pack / MISO3 input assembly), 1 + b =
+// encoder b, 8 = TCN, 9 + i = decoder i, 16 = results read (unpack; the pipeline also reads MISO1's input and output
+// planes after the forward: PIT, MVDR, MISO3 input assembly).  The only cross-level lifetime of the reference is the
+// skip list xs (model.py:84-99): decoder buffer D[i] receives xs[6 - i] at encoder 6 - i and is consumed by decoder i;
+// an encoder's dense-block buffer E[b] is dead once its last conv has written xs[b], X[i] lives inside decoder i.
+static void buf_lifetime(int b, int& t0, int& t1) {
+  if (b == B_IN) { t0 = 0; t1 = 16; }
+  else if (b >= B_E0 && b <= B_E4) { t0 = t1 = 1 + (b - B_E0); }
+  else if (b >= B_D0 && b <= B_D6) { const int i = b - B_D0; t0 = 7 - i; t1 = 9 + i; }
+  else if (b >= B_X2 && b <= B_X6) { t0 = t1 = 9 + 2 + (b - B_X2); }
+  else { t0 = 15; t1 = 16; }                                     // B_OUT
 }
 
 static Layout make_layout(const misonet_net* n, int N, int T) {
@@ -317,17 +338,51 @@ static Layout make_layout(const misonet_net* n, int N, int T) {
   long long so = 0;
   for (int b = 0; b < NBUF; ++b) {
     L.stats_off[b] = so;
-    so += (long long)N * n->bufs[b].C * 2;
+    so += (long long)N * n->bufs[b].C * 2 * DS_NL;
   }
-  L.tcn_xs = so;  so += 15LL * N * 128 * 2;
-  L.tcn_ps = so;  so += 14LL * N * 128 * 2;
-  L.tcn_gln = so; so += 28LL * N * 2;
+  L.tcn_xs = so;  so += 15LL * N * 128 * 2 * DS_NL;
+  L.tcn_ps = so;  so += 14LL * N * 128 * 2 * DS_NL;
+  L.tcn_gln = so; so += 28LL * N * 2 * DS_NL;
   L.stats_doubles = so;
   L.data_base = align_up(256 + so * 8, 256);
-  long long d = 0;
-  for (int b = 0; b < NBUF; ++b) {
+  // ---- activation arena: per-sample offsets by first fit over (lifetime x address) rectangles, largest buffer first ----
+  {
+    struct Rect { int b, t0, t1; long long off, size; };
+    std::vector<Rect> placed;
+    std::vector<int> order;
+    for (int b = 0; b < B_TXA; ++b) order.push_back(b);
+    std::sort(order.begin(), order.end(), [&](int x, int y) {
+      const long long sx = buf_floats(n, L.Tp, x), sy = buf_floats(n, L.Tp, y);
+      return sx != sy ? sx > sy : x < y;
+    });
+    long long top = 0;
+    for (int b : order) {
+      Rect r;
+      r.b = b;
+      r.size = align_up(buf_floats(n, L.Tp, b), 64);
+      buf_lifetime(b, r.t0, r.t1);
+      if (n->keep_taps) { r.t0 = 0; r.t1 = 16; }
+      // candidate offsets: 0 and the end of every placed rectangle that is alive at the same time
+      std::vector<long long> cand(1, 0);
+      for (const Rect& q : placed)
+        if (q.t0 <= r.t1 && r.t0 <= q.t1) cand.push_back(q.off + q.size);
+      std::sort(cand.begin(), cand.end());
+      for (long long o : cand) {
+        bool ok = true;
+        for (const Rect& q : placed)
+          if (q.t0 <= r.t1 && r.t0 <= q.t1 && o < q.off + q.size && q.off < o + r.size) { ok = false; break; }
+        if (ok) { r.off = o; break; }
+      }
+      placed.push_back(r);
+      L.data_off[b] = r.off;
+      top = std::max(top, r.off + r.size);
+    }
+    L.sample_stride = top;
+  }
+  long long d = (long long)N * L.sample_stride;
+  for (int b = B_TXA; b < NBUF; ++b) {
     L.data_off[b] = d;
-    d += align_up((long long)N * bstride(n, L, b), 64);
+    d += align_up((long long)N * buf_floats(n, L.Tp, b), 64);
   }
   long long wmax = 0, cmax = 0;
   auto scan = [&](const std::vector<ConvL>& v) {
@@ -350,8 +405,8 @@ static Layout make_layout(const misonet_net* n, int N, int T) {
 static inline float* buf_ptr(const Layout& L, void* ws, int b) {
   return reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + L.data_base) + L.data_off[b];
 }
-static inline double* stats_base(void* ws) { return reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + 256); }
-static inline double* stats_ptr(const Layout& L, void* ws, int b) { return stats_base(ws) + L.stats_off[b]; }
+static inline dstat_t* stats_base(void* ws) { return reinterpret_cast<dstat_t*>(reinterpret_cast<char*>(ws) + 256); }
+static inline dstat_t* stats_ptr(const Layout& L, void* ws, int b) { return stats_base(ws) + L.stats_off[b]; }
 
 static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL& c, hipStream_t s, int n0 = 0, int nb = -1) {
   ConvArgs a;
@@ -379,8 +434,8 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
   if (nb < 0) nb = L.N;
   a.in += (long long)n0 * a.in_bstride;
   a.out += (long long)n0 * a.out_bstride;
-  a.in_stats += (long long)n0 * a.in_sstride * 2;
-  a.out_stats += (long long)n0 * a.out_sstride * 2;
+  a.in_stats += (long long)n0 * a.in_sstride * 2 * DS_NL;
+  a.out_stats += (long long)n0 * a.out_sstride * 2 * DS_NL;
   a.in_oct = buf_oct(n, c.in_buf);
   a.out_oct = buf_oct(n, c.out_buf);
   // bf16x6 / f16x3: the planar-input layers (network input, F <= 3 bottleneck) run on the exact f32 kernel
@@ -388,8 +443,8 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
   a.wscale = a.descale = 1.f;
   if (a.in_oct == 4) { a.wscale = c.wscale; a.descale = 1.f / c.wscale; }
   if (a.w16 || a.in_oct) { a.cop = 32; a.ncg = (c.Cout + 31) / 32; }
-  static int sync_dbg = -1;                 // MISONET_SYNC_DEBUG=1: name every conv launch and wait for it (fault hunting)
-  if (sync_dbg < 0) { const char* e = getenv("MISONET_SYNC_DEBUG"); sync_dbg = e ? atoi(e) : 0; }
+  // MISONET_SYNC_DEBUG=1: name every conv launch and wait for it (fault hunting)
+  static const int sync_dbg = [] { const char* e = getenv("MISONET_SYNC_DEBUG"); return e ? atoi(e) : 0; }();
   struct SyncDbg {
     hipStream_t s; const ConvArgs& a; int on;
     ~SyncDbg() {
@@ -439,8 +494,7 @@ static int forward_planar(misonet_net* n, const Layout& L, void* ws, hipStream_t
   HIPCHK(hipMemsetAsync(ws, 0, (size_t)(256 + L.stats_doubles * 8), s));
   // Optional sample sub-batching of the conv stacks (MISONET_SUBBATCH = samples per pass at F = 127; deeper levels take
   // proportionally more): keeps a level's producer->consumer traffic inside the 256 MiB Infinity Cache.
-  static int sub_env = -2;
-  if (sub_env == -2) { const char* e = getenv("MISONET_SUBBATCH"); sub_env = e ? atoi(e) : 0; }
+  static const int sub_env = [] { const char* e = getenv("MISONET_SUBBATCH"); return e ? atoi(e) : 0; }();
   auto run_stack = [&](const std::vector<ConvL>& v) -> int {
     if (sub_env <= 0) {
       for (const ConvL& c : v) { int r = run_conv(n, L, ws, c, s); if (r) return r; }
@@ -467,10 +521,11 @@ static int forward_planar(misonet_net* n, const Layout& L, void* ws, hipStream_t
   {
     ProfScope ps_tcn(s, PK_TCN);
     const int N = L.N, T = L.T, Tp = L.Tp;
-    double* xs = stats_base(ws) + L.tcn_xs;
-    double* ps = stats_base(ws) + L.tcn_ps;
-    double* gl = stats_base(ws) + L.tcn_gln;
-    const long long per = (long long)N * 128 * 2;
+    dstat_t* xs = stats_base(ws) + L.tcn_xs;
+    dstat_t* ps = stats_base(ws) + L.tcn_ps;
+    dstat_t* gl = stats_base(ws) + L.tcn_gln;
+    const long long per = (long long)N * 128 * 2 * DS_NL;
+    const long long gper = (long long)N * 2 * DS_NL;
     float* xa = buf_ptr(L, ws, B_TXA);
     float* xb = buf_ptr(L, ws, B_TXB);
     float* td = buf_ptr(L, ws, B_TD);
@@ -481,21 +536,20 @@ static int forward_planar(misonet_net* n, const Layout& L, void* ws, hipStream_t
     float* cur = xa;
     float* nxt = xb;
     // bf16x6 mode: the point-wise convs in the same arithmetic as the 3x3 convs (MISONET_TCN_X6=0: fp32 MFMA, A/B runs)
-    static int tcn_x6_env = -1;
-    if (tcn_x6_env < 0) { const char* e = getenv("MISONET_TCN_X6"); tcn_x6_env = e ? atoi(e) : 1; }
+    static const int tcn_x6_env = [] { const char* e = getenv("MISONET_TCN_X6"); return e ? atoi(e) : 1; }();
     const int tcn_x6 = (n->precision == 3 && tcn_x6_env) ? 1 : 0;
     for (int k = 0; k < 14; ++k) {
       const TcnBlock& tb = n->tcn[k];
       const float* W = n->w_dev;
-      HIPCHK(launch_tcn_dw(cur, xs + k * per, W + tb.h[0].o_dw, W + tb.h[0].o_prelu, td, gl + (2 * k) * (long long)N * 2,
+      HIPCHK(launch_tcn_dw(cur, xs + k * per, W + tb.h[0].o_dw, W + tb.h[0].o_prelu, td, gl + (2 * k) * gper,
                            128, T, Tp, tb.dilation, N, s));
-      HIPCHK(launch_tcn_pw(td, gl + (2 * k) * (long long)N * 2, W + tb.h[0].o_gamma, W + tb.h[0].o_beta, W + tb.h[0].o_pw,
+      HIPCHK(launch_tcn_pw(td, gl + (2 * k) * gper, W + tb.h[0].o_gamma, W + tb.h[0].o_beta, W + tb.h[0].o_pw,
                            nullptr, tp, 128LL * Tp, 0, ps + k * per, 128, T, Tp, N, s, 0, tcn_x6));
       HIPCHK(launch_tcn_dw(tp, ps + k * per, W + tb.h[1].o_dw, W + tb.h[1].o_prelu, td,
-                           gl + (2 * k + 1) * (long long)N * 2, 128, T, Tp, tb.dilation, N, s));
+                           gl + (2 * k + 1) * gper, 128, T, Tp, tb.dilation, N, s));
       const bool last = (k == 13);
       float* y = last ? buf_ptr(L, ws, B_D0) : nxt;
-      HIPCHK(launch_tcn_pw(td, gl + (2 * k + 1) * (long long)N * 2, W + tb.h[1].o_gamma, W + tb.h[1].o_beta,
+      HIPCHK(launch_tcn_pw(td, gl + (2 * k + 1) * gper, W + tb.h[1].o_gamma, W + tb.h[1].o_beta,
                            W + tb.h[1].o_pw, cur, y, last ? bstride(n, L, B_D0) : 128LL * Tp, 0,
                            xs + (k + 1) * per, 128, T, Tp, N, s, (last && buf_oct(n, B_D0) == 3) ? n->bufs[B_D0].C : 0, tcn_x6));
       float* t = cur; cur = nxt; nxt = t;
@@ -721,6 +775,12 @@ int misonet_net_set_precision(misonet_net* n, int mode) {
 }
 int misonet_net_get_precision(const misonet_net* n) { return n ? n->precision : -1; }
 
+int misonet_net_keep_activations(misonet_net* n, int keep) {
+  if (!n) return fail(MISONET_EINVAL, "null argument");
+  n->keep_taps = keep != 0;
+  return MISONET_OK;
+}
+
 long long misonet_net_workspace_bytes(const misonet_net* n, int n_samples, int n_frames) {
   if (!n || n_samples <= 0 || n_frames <= 0) return -1;
   return make_layout(n, n_samples, n_frames).total_bytes;
@@ -775,6 +835,9 @@ int misonet_net_tap(misonet_net* n, const char* name, const void* ws, int B, int
   const Layout L = make_layout(n, B, T);
   for (const Tap& t : n->taps)
     if (t.name == name) {
+      if (!n->keep_taps && t.buf != B_OUT)
+        return fail(MISONET_ESTATE, "tap '%s': activation buffers share memory; call misonet_net_keep_activations(net, 1) "
+                                    "before the forward", name);
       void* w = const_cast<void*>(ws);
       HIPCHK(launch_export(buf_ptr(L, w, t.buf), bstride(n, L, t.buf), t.c0, t.C, n->bufs[t.buf].F, T, L.Tp,
                            t.normalised ? stats_ptr(L, w, t.buf) : nullptr, n->bufs[t.buf].C, 0, dst, B,
@@ -815,11 +878,10 @@ int misonet_mvdr_debug(const void* ws, int B, int F, int M, void* steer, void* w
 
 int misonet_pit_select(const void* anchor, const void* cand, int B, int S, int T, int F, int* sel, double* dist,
                        misonet_stream stream) {
-  if (!anchor || !cand || !sel || !dist) return fail(MISONET_EINVAL, "null argument (dist is required scratch: B*S*S doubles)");
+  if (!anchor || !cand || !sel || !dist) return fail(MISONET_EINVAL, "null argument (dist is required: B*S*S*(F+1) doubles)");
   if (S < 1 || S > 4) return fail(MISONET_EINVAL, "PIT alignment enumerates S! permutations: 1 <= num_spks <= 4 (got %d)", S);
   if (B <= 0 || T <= 0 || F <= 0) return fail(MISONET_EINVAL, "B, T, F must be positive");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  HIPCHK(hipMemsetAsync(dist, 0, (size_t)B * S * S * sizeof(double), s));
   const float* a = reinterpret_cast<const float*>(anchor);
   const float* c = reinterpret_cast<const float*>(cand);
   PitArgs p;
@@ -827,8 +889,9 @@ int misonet_pit_select(const void* anchor, const void* cand, int B, int S, int T
   p.a = {a, a + 1, 2LL * S * T * F, 2, 2LL * T * F, 2 * F};
   p.b = {c, c + 1, 2LL * S * T * F, 2, 2LL * T * F, 2 * F};
   p.B = B; p.F = F; p.T = T;
-  HIPCHK(launch_pit_dist_k(p, S, 1, dist, s));
-  HIPCHK(launch_pit_pick(dist, S, B, sel, s));
+  double* part = dist + (long long)B * S * S;          // per-bin partials [B][F][S][S] behind the result
+  HIPCHK(launch_pit_dist_k(p, S, 1, part, s));
+  HIPCHK(launch_pit_pick(part, F, S, B, dist, sel, s));
   return MISONET_OK;
 }
 
@@ -896,7 +959,8 @@ static PipeLayout pipe_layout(const misonet_pipeline* p, int B, int T) {
   P.L3 = make_layout(p->n3, B * p->S, T);
   const int F = p->n1->cfg.n_freq, Tp = P.L1.Tp;
   long long o = 256;                                   // [0]: nan flag
-  P.off_dist = o;  o += align_up((long long)(B * p->M + B) * p->S * p->S * 8, 256);
+  // PIT distances [B*M + B][S][S] followed by their per-bin partials [B*M + B][F][S][S] (mvdr.hip pit_dist_k)
+  P.off_dist = o;  o += align_up((long long)(B * p->M + B) * p->S * p->S * (F + 1) * 8, 256);
   P.off_sel = o;   o += align_up((long long)(B * p->M * p->S * 2 + B * p->S) * 4, 256);
   P.off_mvdr = o;  o += align_up(mvdr_ws_bytes(B, p->S, F, p->M), 256);
   P.clean_bstride = (long long)2 * p->S * F * Tp;
@@ -944,10 +1008,12 @@ static int pipeline_run_impl(misonet_pipeline* p, const void* mix, const void* c
   misonet_net *n1 = p->n1, *n3 = p->n3;
   double* dist_shift = reinterpret_cast<double*>(base + P.off_dist);          // [B*M][S][S]
   double* dist_clean = dist_shift + (long long)B * M * S * S;                  // [B][S][S]
+  double* part_shift = dist_clean + (long long)B * S * S;                      // [B*M][F][S][S]
+  double* part_clean = part_shift + (long long)B * M * F * S * S;              // [B][F][S][S]
   int* sel_shift = reinterpret_cast<int*>(base + P.off_sel);                   // [B*M][S]
   int* sel_final = sel_shift + (long long)B * M * S;                           // [B*M][S]
   int* sel_clean = sel_final + (long long)B * M * S;                           // [B][S]
-  HIPCHK(hipMemsetAsync(base, 0, (size_t)P.off_sel, s));                       // nan flag + distances
+  HIPCHK(hipMemsetAsync(base, 0, 256, s));                                     // nan flag
 
   // 1. MISO1_Inference: the M circular shifts as one batch of B*M samples (tester.py:1033-1051)
   float* in1 = buf_ptr(P.L1, ws1, B_IN);
@@ -969,8 +1035,8 @@ static int pipeline_run_impl(misonet_pipeline* p, const void* mix, const void* c
     q.a = {anc, anc + S * plane, (long long)M * out1_bs, Tp, plane, 1};
     q.b = {out1, out1 + S * plane, out1_bs, Tp, plane, 1};
     q.B = B; q.F = F; q.T = T;
-    HIPCHK(launch_pit_dist_k(q, S, M, dist_shift, s));
-    HIPCHK(launch_pit_pick(dist_shift, S, B * M, sel_shift, s));
+    HIPCHK(launch_pit_dist_k(q, S, M, part_shift, s));
+    HIPCHK(launch_pit_pick(part_shift, F, S, B * M, dist_shift, sel_shift, s));
   }
   // 3. align to the clean references at ref_ch (tester.py:889-915), optional
   if (clean || clean_wav) {
@@ -984,8 +1050,8 @@ static int pipeline_run_impl(misonet_pipeline* p, const void* mix, const void* c
     q.a = {cl, cl + S * plane, P.clean_bstride, Tp, plane, 1};
     q.b = {cand, cand + S * plane, (long long)M * out1_bs, Tp, plane, 1};
     q.B = B; q.F = F; q.T = T;
-    HIPCHK(launch_pit_dist_k(q, S, 1, dist_clean, s));
-    HIPCHK(launch_pit_pick(dist_clean, S, B, sel_clean, s));
+    HIPCHK(launch_pit_dist_k(q, S, 1, part_clean, s));
+    HIPCHK(launch_pit_pick(part_clean, F, S, B, dist_clean, sel_clean, s));
   }
   HIPCHK(launch_compose_sel(sel_shift, (clean || clean_wav) ? sel_clean : nullptr, B, M, S, sel_final, s));
 

@@ -8,7 +8,6 @@
 // All sums are float64.  Activations are planar [n][c][Tp] (F = 1).
 #include "kernels.hpp"
 #include "conv_epilogue.hpp"
-#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 namespace mn {
 
@@ -24,9 +23,9 @@ __device__ inline double block_sum_256(double v, double* s_tmp /*[4]*/) {
   return s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
 }
 
-__device__ inline void in_params(const double* st, int T, float& mean, float& rstd) {
-  const double m = st[0] / (double)T;
-  double var = st[1] / (double)T - m * m;
+__device__ inline void in_params(const dstat_t* st, int T, float& mean, float& rstd) {
+  const double m = dstat_read(st) / (double)T;
+  double var = dstat_read(st + DS_NL) / (double)T - m * m;
   var = var > 0.0 ? var : 0.0;
   mean = (float)m;
   rstd = (float)(1.0 / sqrt(var + (double)IN_EPS));
@@ -36,12 +35,12 @@ __device__ inline void in_params(const double* st, int T, float& mean, float& rs
 // raw_oct3: the source buffer is in the oct3 layout of the bf16x6 mode (three bf16 parts [c/8][f = 0][Tp][8], value = their
 // exact sum); raw_sstride = channels of that buffer.
 __global__ __launch_bounds__(256) void tcn_prepare_k(const float* raw, long long raw_bstride, int raw_c0,
-                                                     const double* raw_stats, int raw_sstride, float* x,
-                                                     double* x_stats, int C, int T, int Tp, int raw_oct3) {
+                                                     const dstat_t* raw_stats, int raw_sstride, float* x,
+                                                     dstat_t* x_stats, int C, int T, int Tp, int raw_oct3) {
   __shared__ double s_tmp[4];
   const int c = blockIdx.x, n = blockIdx.y;
   float mean, rstd;
-  in_params(raw_stats + ((long long)n * raw_sstride + raw_c0 + c) * 2, T, mean, rstd);
+  in_params(raw_stats + ((long long)n * raw_sstride + raw_c0 + c) * (2 * DS_NL), T, mean, rstd);
   const float* src = raw + (long long)n * raw_bstride + (long long)(raw_c0 + c) * Tp;
   const unsigned short* so = reinterpret_cast<const unsigned short*>(raw + (long long)n * raw_bstride);
   const int ch = raw_c0 + c;
@@ -65,9 +64,9 @@ __global__ __launch_bounds__(256) void tcn_prepare_k(const float* raw, long long
   s1 = block_sum_256(s1, s_tmp);
   s2 = block_sum_256(s2, s_tmp);
   if (threadIdx.x == 0) {
-    double* o = x_stats + ((long long)n * C + c) * 2;
-    o[0] = s1;
-    o[1] = s2;
+    dstat_t* o = x_stats + ((long long)n * C + c) * (2 * DS_NL);
+    dstat_add(o, s1);
+    dstat_add(o + DS_NL, s2);
   }
 }
 
@@ -80,8 +79,8 @@ __global__ __launch_bounds__(256) void tcn_prepare_k(const float* raw, long long
 constexpr int DW_MAXT = 2048;                      // frames per row kept in LDS (4 rows x 8 KB)
 constexpr int DW_HALO = 64;                        // largest dilation of TemporalConvNet(2, 7, ...): 2^6
 constexpr int DW_SEG = DW_MAXT - 2 * DW_HALO;      // output frames per segment
-__global__ __launch_bounds__(256) void tcn_dw_k(const float* x, const double* x_stats, const float* wdw,
-                                                const float* prelu, float* d, double* gln_stats, int C, int T,
+__global__ __launch_bounds__(256) void tcn_dw_k(const float* x, const dstat_t* x_stats, const float* wdw,
+                                                const float* prelu, float* d, dstat_t* gln_stats, int C, int T,
                                                 int Tp, int dil, int seg_f) {
   __shared__ double s_tmp[4][2];
   extern __shared__ __align__(16) float s_a_dyn[];             // [4 rows][row_f]: row_f = frames of a segment + 2 halos
@@ -89,7 +88,7 @@ __global__ __launch_bounds__(256) void tcn_dw_k(const float* x, const double* x_
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 4 + wave, n = blockIdx.y;
   float mean, rstd;
-  in_params(x_stats + ((long long)n * C + c) * 2, T, mean, rstd);
+  in_params(x_stats + ((long long)n * C + c) * (2 * DS_NL), T, mean, rstd);
   const float sc = rstd, sh = -mean * rstd;
   const float w0 = wdw[c * 3 + 0], w1 = wdw[c * 3 + 1], w2 = wdw[c * 3 + 2];
   const float slope = prelu[0];
@@ -144,7 +143,7 @@ __global__ __launch_bounds__(256) void tcn_dw_k(const float* x, const double* x_
   __syncthreads();
   if (threadIdx.x < 2) {
     const double tot = s_tmp[0][threadIdx.x] + s_tmp[1][threadIdx.x] + s_tmp[2][threadIdx.x] + s_tmp[3][threadIdx.x];
-    unsafeAtomicAdd(gln_stats + (long long)n * 2 + threadIdx.x, tot);
+    dstat_add(gln_stats + ((long long)n * 2 + threadIdx.x) * DS_NL, tot);
   }
 }
 
@@ -165,17 +164,17 @@ constexpr int PW_KC = 16;
 // kernel is bound by the matrix pipe otherwise (3.2 GFLOP per launch at 52 TF/s).  The split of the normalised input
 // happens once per workgroup on the way into the LDS, the split of a wave's weight fragment in its registers.
 template <bool Y_OCT3, bool X6>
-__global__ __launch_bounds__(256) void tcn_pw_k(const float* d, const double* gln_stats, const float* gamma,
+__global__ __launch_bounds__(256) void tcn_pw_k(const float* d, const dstat_t* gln_stats, const float* gamma,
                                                 const float* beta, const float* wt /*[ci][co]*/,
                                                 const float* residual, float* y, long long y_bstride, int y_c0,
-                                                double* y_stats, int T, int Tp, int y_cbuf) {
+                                                dstat_t* y_stats, int T, int Tp, int y_cbuf) {
   constexpr int C = 128;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int t0 = blockIdx.x * PW_TT, n = blockIdx.y;
   const double cnt = (double)C * (double)T;
-  const double gm = gln_stats[(long long)n * 2] / cnt;
-  double gv = gln_stats[(long long)n * 2 + 1] / cnt - gm * gm;
+  const double gm = dstat_read(gln_stats + (long long)n * (2 * DS_NL)) / cnt;
+  double gv = dstat_read(gln_stats + (long long)n * (2 * DS_NL) + DS_NL) / cnt - gm * gm;
   gv = gv > 0.0 ? gv : 0.0;
   const float mean = (float)gm;
   const float rstd = (float)(1.0 / sqrt(gv + (double)GLN_EPS));
@@ -384,23 +383,23 @@ __global__ __launch_bounds__(256) void tcn_pw_k(const float* d, const double* gl
     if ((lane & 16) == 0) {
       const int q = lane & 15;
       const int co = wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
-      double* o = y_stats + ((long long)n * C + co) * 2;
-      unsafeAtomicAdd(o + 0, (double)x1);
-      unsafeAtomicAdd(o + 1, (double)x2);
+      dstat_t* o = y_stats + ((long long)n * C + co) * (2 * DS_NL);
+      dstat_add(o, (double)x1);
+      dstat_add(o + DS_NL, (double)x2);
     }
   }
 }
 
-hipError_t launch_tcn_prepare(const float* raw, long long raw_bstride, int raw_c0, const double* raw_stats,
-                              int raw_sstride, float* x, double* x_stats, int C, int T, int Tp, int n_samples,
+hipError_t launch_tcn_prepare(const float* raw, long long raw_bstride, int raw_c0, const dstat_t* raw_stats,
+                              int raw_sstride, float* x, dstat_t* x_stats, int C, int T, int Tp, int n_samples,
                               hipStream_t s, int raw_oct3) {
   hipLaunchKernelGGL(tcn_prepare_k, dim3(C, n_samples), dim3(256), 0, s, raw, raw_bstride, raw_c0, raw_stats,
                      raw_sstride, x, x_stats, C, T, Tp, raw_oct3);
   return hipGetLastError();
 }
 
-hipError_t launch_tcn_dw(const float* x, const double* x_stats, const float* wdw, const float* prelu, float* d,
-                         double* gln_stats, int C, int T, int Tp, int dilation, int n_samples, hipStream_t s) {
+hipError_t launch_tcn_dw(const float* x, const dstat_t* x_stats, const float* wdw, const float* prelu, float* d,
+                         dstat_t* gln_stats, int C, int T, int Tp, int dilation, int n_samples, hipStream_t s) {
   if (dilation < 1 || dilation > DW_HALO) return hipErrorInvalidValue;
   if (C % 4) return hipErrorInvalidValue;
   // LDS row = the frames of one segment + two halos: a 4-second utterance (T = 1001) takes 18 KB per workgroup instead
@@ -412,9 +411,9 @@ hipError_t launch_tcn_dw(const float* x, const double* x_stats, const float* wdw
   return hipGetLastError();
 }
 
-hipError_t launch_tcn_pw(const float* d, const double* gln_stats, const float* gamma, const float* beta,
+hipError_t launch_tcn_pw(const float* d, const dstat_t* gln_stats, const float* gamma, const float* beta,
                          const float* wpw, const float* residual, float* y, long long y_bstride, int y_c0,
-                         double* y_stats, int C, int T, int Tp, int n_samples, hipStream_t s, int y_oct3_cbuf, int x6) {
+                         dstat_t* y_stats, int C, int T, int Tp, int n_samples, hipStream_t s, int y_oct3_cbuf, int x6) {
   if (C != 128) return hipErrorInvalidValue;
   const dim3 g((T + PW_TT - 1) / PW_TT, n_samples);
   if (y_oct3_cbuf) {

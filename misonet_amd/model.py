@@ -46,7 +46,8 @@ class _Trunk:
         self._device: Optional[torch.device] = None
         self._ws: Dict[tuple, torch.Tensor] = {}
         self.training = True
-        self.precision = "f32"
+        self._keep = False
+        self.precision = "bf16x6"      # the library's default (misonet_net.precision in csrc/net.hip): fp32-faithful, the bench's mode
         L = _lib.lib()
         cfg = _lib.Cfg(self.in_ch, self.out_ch, (C.c_int * 7)(*self.en_ch), (C.c_int * 7)(*self.de_ch), W.N_FREQ)
         _lib.check(L.misonet_net_create(C.byref(cfg), C.byref(self._net)))
@@ -92,9 +93,9 @@ class _Trunk:
     PRECISIONS = {"f32": 0, "bf16x3p": 1, "bf16x3": 2, "bf16x6": 3, "f16x3": 4}
 
     def set_precision(self, mode: str):
-        """Arithmetic of the 3x3 convolutions: "f32" (exact float32 matrix cores, default), "bf16x6" (fp32-faithful:
-        both operands split EXACTLY into three bf16 pieces, the six leading partial products on the bf16 matrix cores
-        with f32 accumulation -- same accuracy class as "f32" at 2.67x its matrix rate, conv_bf16x6.hip), "f16x3"
+        """Arithmetic of the 3x3 convolutions: "bf16x6" (the default; fp32-faithful: both operands split EXACTLY into
+        three bf16 pieces, the six leading partial products on the bf16 matrix cores with f32 accumulation -- same
+        accuracy class as "f32" at 2.67x its matrix rate, conv_bf16x6.hip), "f32" (exact float32 matrix cores), "f16x3"
         (operands rounded to two fp16 pieces = 22 bits, three terms, f32 accumulation: the "3xTF32" scheme; measured at the
         f32 mode's error level, at the cost of "bf16x3"; activations must stay inside fp16's range), "bf16x3" (three-term bf16
         split on the bf16 matrix cores, f32 accumulation, ~1e-5 relative per layer; activations travel pre-split in the
@@ -106,6 +107,14 @@ class _Trunk:
         if mode != self.precision:
             self._ws.clear()           # the workspace layout (and size) depends on the arithmetic mode
         self.precision = mode
+        return self
+
+    def keep_activations(self, keep: bool = True):
+        """Diagnostics: give every activation buffer its own memory so that :meth:`tap` can read any stage after a
+        forward.  By default buffers with disjoint lifetimes share memory (0.26 instead of 0.55 GB per forward-sample)."""
+        _lib.check(_lib.lib().misonet_net_keep_activations(self._net, 1 if keep else 0))
+        self._ws.clear()
+        self._keep = bool(keep)
         return self
 
     def train(self, mode=True):

@@ -116,7 +116,8 @@ class Enhancer:
         return x.to(torch.complex64).contiguous()
 
     def workspace(self, B, T):
-        key = (B, T, self.model_sep.precision, self.model.precision)   # the layout depends on the arithmetic modes
+        # the layout depends on the arithmetic modes and on whether buffers may share memory
+        key = (B, T, self.model_sep.precision, self.model.precision, self.model_sep._keep, self.model._keep)
         ws = self._ws.get(key)
         if ws is None:
             self._ws.clear()

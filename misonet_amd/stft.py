@@ -96,24 +96,33 @@ def stitch_int16(chunks: List[np.ndarray], gap: int) -> np.ndarray:
 
 def write_wav_pcm24(path: str, samples_int16: np.ndarray, fs: int) -> None:
     """tester.py:972-974: ``sf.write(path, int16_array.T, fs, 'PCM_24')``.  libsndfile widens int16 to 24-bit PCM by a
-    left shift of 8 bits, so each sample is written as the 3 little-endian bytes of ``int16 << 8``.
+    left shift of 8 bits, so each sample is written as the 3 little-endian bytes of ``int16 << 8``, behind the plain
+    44-byte RIFF/WAVE header it writes for PCM (fmt chunk of 16 bytes, format tag 1); a data chunk of odd length is
+    followed by one zero pad byte that the RIFF size counts and the data size does not -- byte for byte the layout of
+    the reference's own outputs (sample/MISO3/*.wav: 64059 mono samples -> data 192177, RIFF 192214, file 192222).
     samples_int16: [n_samples] (mono) or [n_samples, n_channels]."""
-    import wave
+    import struct
     x = np.asarray(samples_int16)
     if x.dtype != np.int16:
         raise TypeError("expected int16 samples (tester.py:952 casts before writing)")
     if x.ndim == 1:
         x = x[:, None]
+    n, ch = x.shape
     v = (x.astype(np.int32) << 8)
     b = np.empty(x.shape + (3,), dtype=np.uint8)
     b[..., 0] = v & 0xFF
     b[..., 1] = (v >> 8) & 0xFF
     b[..., 2] = (v >> 16) & 0xFF
-    with wave.open(path, "wb") as w:
-        w.setnchannels(x.shape[1])
-        w.setsampwidth(3)
-        w.setframerate(int(fs))
-        w.writeframes(b.tobytes())
+    data = b.tobytes()
+    pad = len(data) & 1
+    hdr = (b"RIFF" + struct.pack("<I", 36 + len(data) + pad) + b"WAVE" +
+           b"fmt " + struct.pack("<IHHIIHH", 16, 1, ch, int(fs), int(fs) * ch * 3, ch * 3, 24) +
+           b"data" + struct.pack("<I", len(data)))
+    with open(path, "wb") as f:
+        f.write(hdr)
+        f.write(data)
+        if pad:
+            f.write(b"\x00")
 
 
 def read_wav_pcm24(path: str):

@@ -24,6 +24,9 @@ class Tester_Enhance(object):
                  device, num_spks, chunk_time, save_rootDir, ref_ch, cuda_flag, **ISTFT_args):
         if not isinstance(model_sep, MISO_1) or not isinstance(model, MISO_3):
             raise TypeError("Tester_Enhance needs misonet_amd.MISO_1 / misonet_amd.MISO_3 (INTEGRATION.md section 2)")
+        if enhance_mode != "MISO3":                                                # tester.py:935-945: anything else runs
+            raise ValueError(f"enhance_mode = {enhance_mode!r}: only 'MISO3' is implemented (the reference's other "
+                             "branch, MISO2_inference, needs model.MISO_2, which is out of scope: SURVEY.md section 2)")
         self.dataset, self.enhance_mode = dataset, enhance_mode                    # tester.py:802,810
         self.dt_loader, self.test_loader = dt_loader, test_loader
         self.model_sep, self.model = model_sep, model

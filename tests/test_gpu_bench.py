@@ -27,6 +27,7 @@ def test_bench_single_process_line():
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 12.5          # north_star: >= 50x real time
+    assert d["config"]["workload"].startswith("BASELINE configs[3]")
     assert d["fp32_faithful"] is True, "the headline must run fp32-faithful arithmetic (reference model.py:77-80)"
     rf = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
@@ -39,12 +40,18 @@ def test_bench_two_ranks_on_one_device():
     # plain ``python bench.py --gpus 2``: the script starts its own ranks (torch.distributed.run on 127.0.0.1)
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
     cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-alt",
-           "--batch", "4"]
+           "--batch", "4", "--verify-gather"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
     assert d["config"]["batch_per_gpu"] == 4
     assert d["rccl_ranks"] == 2 and len(d["per_rank_utt_per_s"]) == 2
+    assert "configs[4]" in d["config"]["workload"] and d["config"]["global_batch"] == 8
+    # --verify-gather: the all_gather of the results (the path's only collective), one utterance of the LAST rank's shard
+    # checked by the oracle on rank 0
+    assert d["gathered_shape"] == [8, 2, 1001, 129] and d["gather_ms"] > 0
+    gp = d["gather_parity"]
+    assert gp["from_rank"] == 1 and gp["utterance"] == 4 and gp["ok"] and gp["rel_l2_magnitudes_vs_oracle"] < 1e-3
     # whole-job aggregate: 2 ranks x 4 utterances x 2 steps over the max-over-ranks time
     assert abs(d["value"] - 2 * 4 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-2

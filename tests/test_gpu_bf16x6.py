@@ -34,9 +34,8 @@ def _cmp(what, got6, got32, ref, single_forward):
     d = rel_l2(got6, got32)
     print(f"[bf16x6] {what}: vs oracle  bf16x6 {e6:.3e}  f32 {e32:.3e}   bf16x6 vs f32 {d:.3e}")
     assert np.isfinite(e6)
-    # (a 5-frame utterance has 5-sample statistics in the bottleneck: the f32 mode itself lands anywhere in 0.7-1.2e-5 there
-    # from run to run -- the float64 statistics atomics arrive in a different order -- so only the looser bound below
-    # is asserted for it)
+    # (a 5-frame utterance has 5-sample statistics in the bottleneck: the f32 mode itself sits at ~1e-5 there, so only the
+    # looser bound below is asserted for it)
     if single_forward and got6.shape[2] >= 16:
         assert e6 <= max(5e-6, 1.25 * e32), f"{what}: {e6:.3e} > 5e-6 and > 1.25 x f32's {e32:.3e}"
     assert e6 <= 3.0 * e32 + 3e-6, f"{what}: bf16x6 {e6:.3e} vs f32 {e32:.3e}"
@@ -67,9 +66,13 @@ def test_bf16x6_stage_taps(pair, sd1):
     got = {}
     for mode in ("f32", "bf16x6"):
         m1 = pair[mode][0]
-        m1(x.cuda())
-        got[mode] = {nm: m1.tap(nm, 1, 32).cpu().numpy() for nm in
-                     ["enc0_conv"] + [f"enc{b}" for b in range(7)] + ["tcn_out"] + [f"dec{b}" for b in range(7)]}
+        m1.keep_activations(True)                      # taps need un-shared activation buffers
+        try:
+            m1(x.cuda())
+            got[mode] = {nm: m1.tap(nm, 1, 32).cpu().numpy() for nm in
+                         ["enc0_conv"] + [f"enc{b}" for b in range(7)] + ["tcn_out"] + [f"dec{b}" for b in range(7)]}
+        finally:
+            m1.keep_activations(False)
     for nm in got["f32"]:
         ref = taps[nm].numpy()
         ref = ref[..., None] if ref.ndim == 3 else ref
@@ -122,8 +125,8 @@ def test_bf16x6_batch_invariance(pair):
     y1 = m1(x).cpu().numpy()
     xb = torch.cat([x * (1.0 + 0.25 * i) for i in range(8)] + [x], dim=0)
     yb = m1(xb).cpu().numpy()
-    assert rel_l2(yb[8], y1[0]) < 1e-6
-    assert rel_l2(yb[0], y1[0]) < 1e-6
+    assert np.array_equal(yb[8], y1[0])        # bit for bit (exact statistics accumulation, csrc/det_stats.hpp)
+    assert np.array_equal(yb[0], y1[0])
 
 
 def test_f16x3_is_at_the_f32_error_level(pair, sd1):

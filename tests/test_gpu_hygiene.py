@@ -10,7 +10,8 @@ from test_gpu_parity import _assert_parity, _utt_inputs, _need_gpu
 pytestmark = pytest.mark.gpu
 
 
-def test_three_speaker_separation_vs_reference_golden(sd3):
+@pytest.mark.parametrize("mode", ["f32", "bf16x6"])
+def test_three_speaker_separation_vs_reference_golden(sd3, mode):
     """Enhancer.separate with num_spks = 3 against G10 (Tester_Enhance.MISO1_Inference of the real reference)."""
     _need_gpu()
     import misonet_amd as mz
@@ -21,7 +22,7 @@ def test_three_speaker_separation_vs_reference_golden(sd3):
     m1.load_state_dict(sd)
     m3 = mz.MISO_3(1, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN").cuda(0)
     m3.load_state_dict(sd3)
-    enh = mz.Enhancer(m1.eval(), m3.eval(), num_spks=3, ref_ch=0)
+    enh = mz.Enhancer(m1.eval().set_precision(mode), m3.eval().set_precision(mode), num_spks=3, ref_ch=0)
     est = enh.separate(torch.from_numpy(g["x"]).cuda(), None)[0].cpu().numpy()          # [S,M,T,F]
     assert est.shape == (3, 6, 32, 129)
     _assert_parity(est[:, :, ::2], g["est_even"], "3-speaker MISO1_Inference vs reference golden")
@@ -60,6 +61,7 @@ def test_long_utterance_no_frame_limit(sd1):
     m1 = mz.MISO_1(2, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN").cuda(0)
     m1.load_state_dict(sd1)
     mx, _ = _utt_inputs(2, 2500)
+    m1.keep_activations(True)                          # for the tcn_out tap below
     y = m1.eval()(torch.from_numpy(mx[None]).cuda())
     y_ref = miso_oracle.miso1_forward(torch.from_numpy(mx[None]), sd1).numpy()
     _assert_parity(y.cpu().numpy(), y_ref, "miso1 T=2500 vs oracle")

@@ -61,9 +61,17 @@ def test_tensor_registry_matches_reference_keys():
 def test_workspace_and_validation():
     L, rc, h = _make()
     lib = L.lib()
+    # default (bf16x6, 6 bytes per element in the dense-block buffers): buffers with disjoint lifetimes share memory
     w1 = lib.misonet_net_workspace_bytes(h, 1, 1001)
     w2 = lib.misonet_net_workspace_bytes(h, 2, 1001)
-    assert 300e6 < w1 < 450e6 and 1.9 < w2 / w1 < 2.1           # ~0.37 GB of activations per sample at T = 1001
+    assert 200e6 < w1 < 300e6 and 1.9 < w2 / w1 < 2.1           # 0.27 GB per forward-sample at T = 1001 ...
+    assert lib.misonet_net_keep_activations(h, 1) == 0
+    wk = lib.misonet_net_workspace_bytes(h, 1, 1001)
+    assert 500e6 < wk < 600e6                                    # ... 0.55 GB when every tap must stay readable
+    assert lib.misonet_net_keep_activations(h, 0) == 0 and lib.misonet_net_workspace_bytes(h, 1, 1001) == w1
+    assert lib.misonet_net_set_precision(h, 0) == 0              # exact f32: 4 bytes per element
+    assert 120e6 < lib.misonet_net_workspace_bytes(h, 1, 1001) < 200e6
+    assert lib.misonet_net_set_precision(h, 3) == 0
     assert lib.misonet_net_workspace_bytes(h, 0, 10) == -1
     # set_tensor validation
     v = np.zeros(10, np.float32)
@@ -121,14 +129,14 @@ def test_product_does_not_import_oracle():
 def test_precision_switch_host_side():
     L, rc, h = _make()
     lib = L.lib()
-    assert lib.misonet_net_get_precision(h) == 0                 # exact f32 by default
+    assert lib.misonet_net_get_precision(h) == 3                 # bf16x6 (fp32-faithful, the bench's mode) by default
     assert lib.misonet_net_set_precision(h, 1) == 0 and lib.misonet_net_get_precision(h) == 1
     assert lib.misonet_net_set_precision(h, 7) == L.EINVAL
     lib.misonet_net_destroy(h)
     import misonet_amd as mz
     from misonet_amd import weights as W
     m = mz.MISO_3(1, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN")
-    assert m.precision == "f32"
+    assert m.precision == "bf16x6"
     m.set_precision("bf16x3")
     assert m.precision == "bf16x3"
     with pytest.raises(ValueError):

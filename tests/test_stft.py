@@ -57,3 +57,33 @@ def test_pcm24_writer_roundtrip(tmp_path):
     import pytest
     with pytest.raises(TypeError):
         S.write_wav_pcm24(p, x.astype(np.float32), 8000)
+
+
+def test_pcm24_writer_bytes_match_the_reference_writer(tmp_path):
+    """tester.py:972-974 writes through libsndfile: sf.write(path, int16, fs, 'PCM_24').  Expected file assembled by hand
+    from the layout of the reference's OWN outputs (sample/MISO3/3_441c040w_445c040o_0.wav, read in the build container:
+    'RIFF' 192214 'WAVE' 'fmt ' 16 | tag 1, 1 ch, 8000 Hz, 24000 B/s, align 3, 24 bit | 'data' 192177, file 192222 bytes
+    = 44 + 64059 * 3 + 1 pad byte, low byte of every sample 0 = int16 << 8)."""
+    x = np.array([1, -2, 32767], dtype=np.int16)                       # odd data length: pad byte
+    p = str(tmp_path / "utt_0.wav")
+    S.write_wav_pcm24(p, x, 8000)
+    want = (b"RIFF" + (36 + 9 + 1).to_bytes(4, "little") + b"WAVE" +
+            b"fmt " + (16).to_bytes(4, "little") + (1).to_bytes(2, "little") + (1).to_bytes(2, "little") +
+            (8000).to_bytes(4, "little") + (24000).to_bytes(4, "little") + (3).to_bytes(2, "little") + (24).to_bytes(2, "little") +
+            b"data" + (9).to_bytes(4, "little") +
+            bytes([0x00, 0x01, 0x00]) +                                # 1 << 8
+            bytes([0x00, 0xFE, 0xFF]) +                                # -2 << 8 = 0xFFFE00
+            bytes([0x00, 0xFF, 0x7F]) +                                # 32767 << 8
+            b"\x00")                                                   # pad to an even chunk length
+    assert open(p, "rb").read() == want
+    # two channels, 16 kHz, even length: no pad
+    y = np.array([[-32768, 256], [0, -1]], dtype=np.int16)
+    S.write_wav_pcm24(p, y, 16000)
+    want2 = (b"RIFF" + (36 + 12).to_bytes(4, "little") + b"WAVEfmt " + (16).to_bytes(4, "little") +
+             (1).to_bytes(2, "little") + (2).to_bytes(2, "little") + (16000).to_bytes(4, "little") +
+             (96000).to_bytes(4, "little") + (6).to_bytes(2, "little") + (24).to_bytes(2, "little") +
+             b"data" + (12).to_bytes(4, "little") +
+             bytes([0x00, 0x00, 0x80, 0x00, 0x00, 0x01, 0x00, 0x00, 0x00, 0x00, 0xFF, 0xFF]))
+    assert open(p, "rb").read() == want2
+    v, fs = S.read_wav_pcm24(p)
+    assert fs == 16000 and np.array_equal(v, y.astype(np.int32) << 8)
