@@ -22,7 +22,21 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
 // ELU(alpha = 1) = x > 0 ? x : exp(x) - 1 (reference model.py:412,429,444) on the hardware exp2: absolute error
 // ~1e-7, far below the path's tolerance; ocml expm1f costs ~50 instructions per element.
-__device__ __forceinline__ float elu_fast(float v) { return v > 0.f ? v : (__expf(v) - 1.f); }
+// x >= +0 ? x : e  as a bit select on the sign of x (v_ashrrev_i32 + v_bfi_b32): no compare, so no VCC / SGPR round
+// trip between the two VALU instructions (v_cmp -> v_cndmask costs 2 wait states on gfx950, ~30 s_nops per 16-value
+// row in the tile epilogue), and NaN-transparent like the compare form (x = NaN selects x or e = NaN): a v_med3_f32
+// would be one instruction but returns min3 = 0 for NaN inputs, i.e. it would swallow a NaN instead of handing it on to
+// the output check (reference model.py:109-110).  x = -0 selects e = exp(-0) - 1 = 0.
+__device__ __forceinline__ float elu_select(float x, float e) {
+  const int m = __builtin_bit_cast(int, x) >> 31;
+  float r;
+  // (e & m) | (x & ~m) as ONE v_bfi_b32.  Inline asm: written in C, LLVM folds any form of it back into a select on
+  // x < 0, i.e. into the v_cmp + v_cndmask pair this function is here to avoid.
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(e), "v"(x));
+  return r;
+}
+
+__device__ __forceinline__ float elu_fast(float v) { return elu_select(v, __expf(v) - 1.f); }
 
 // sum over the 32 lanes of each half-wave; the result is valid in lanes 16..31 (lower half) and 48..63 (upper half)
 __device__ __forceinline__ float half_wave_sum(float v) {
@@ -142,6 +156,30 @@ __device__ __forceinline__ void split3_pair_t(float x0, float x1, unsigned& hi, 
   lo = __builtin_bit_cast(unsigned, l);
 }
 
+// split3_pair_t for two pairs at once, the two dependency chains interleaved statement by statement: every link of a chain
+// (v_cvt_pk_bf16_f32 -> shift/and -> v_pk_add_f32 -> v_cvt_pk_bf16_f32 ...) needs one independent instruction before its
+// consumer on gfx950, and written pair after pair the compiler pads the links with s_nops.
+__device__ __forceinline__ void split3_quad_t(float x0, float x1, float x2, float x3, unsigned (&hi)[2], unsigned (&mid)[2],
+                                              unsigned (&lo)[2]) {
+  const f32x2_t xa = {x0, x1}, xb = {x2, x3};
+  const unsigned ha = __builtin_bit_cast(unsigned, __builtin_convertvector(xa, bf16x2_t));
+  const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(xb, bf16x2_t));
+  const f32x2_t haf = {__builtin_bit_cast(float, ha << 16), __builtin_bit_cast(float, ha & 0xffff0000u)};
+  const f32x2_t hbf = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
+  const f32x2_t ra = xa - haf;
+  const f32x2_t rb = xb - hbf;
+  const unsigned ma = __builtin_bit_cast(unsigned, __builtin_convertvector(ra, bf16x2_t));
+  const unsigned mb = __builtin_bit_cast(unsigned, __builtin_convertvector(rb, bf16x2_t));
+  const f32x2_t maf = {__builtin_bit_cast(float, ma << 16), __builtin_bit_cast(float, ma & 0xffff0000u)};
+  const f32x2_t mbf = {__builtin_bit_cast(float, mb << 16), __builtin_bit_cast(float, mb & 0xffff0000u)};
+  const f32x2_t qa = ra - maf;
+  const f32x2_t qb = rb - mbf;
+  hi[0] = ha; hi[1] = hb;
+  mid[0] = ma; mid[1] = mb;
+  lo[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(qa, bf16x2_t));
+  lo[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(qb, bf16x2_t));
+}
+
 // One accumulator row (16 values of one lane: channel (i&3) + 8*(i>>2) + 4*half of a 32-channel group at one frame)
 // -> NP bf16 parts in the oct layout: part p of octet pair k is one 16-byte store per lane (lanes 0-31 store octet 2k,
 // lanes 32-63 octet 2k + 1, after a half-wave swap).  rs[p]: descriptor of part p; vo: byte offset of (row, frame) in
@@ -153,8 +191,7 @@ __device__ __forceinline__ void store_oct_row(const float (&v)[16], const __amdg
 #pragma unroll
   for (int o = 0; o < 4; ++o) {
     if (NP == 3) {
-      split3_pair_t(v[4 * o + 0], v[4 * o + 1], P[0][o][0], P[1][o][0], P[2][o][0]);
-      split3_pair_t(v[4 * o + 2], v[4 * o + 3], P[0][o][1], P[1][o][1], P[2][o][1]);
+      split3_quad_t(v[4 * o + 0], v[4 * o + 1], v[4 * o + 2], v[4 * o + 3], P[0][o], P[1][o], P[2][o]);
     } else {
       split_pair_x<F16>(v[4 * o + 0], v[4 * o + 1], P[0][o][0], P[1][o][0]);
       split_pair_x<F16>(v[4 * o + 2], v[4 * o + 3], P[0][o][1], P[1][o][1]);
@@ -585,29 +622,46 @@ __device__ __forceinline__ void conv_epilogue_rows_nb_impl(const ConvArgs& a, f3
     const float mf = ok ? 1.f : 0.f;
     const f32x2_e m2 = {mf, mf};
     float v[16];
+    // two element pairs (A, B) per step, their instructions interleaved: on gfx950 a v_pk_*_f32 or v_exp_f32 result
+    // needs one independent instruction before its consumer, and a dependent chain written pair by pair is padded with an
+    // s_nop at every link (~30 wasted issue slots per 16-value row; the tile epilogue is VALU-issue bound)
 #pragma unroll
-    for (int i2 = 0; i2 < 8; ++i2) {
-      f32x2_e x = {acc[r][2 * i2], acc[r][2 * i2 + 1]};
-      if (F16) x = x * f32x2_e{a.descale, a.descale};      // f16x3: the weights carry a power-of-two scale
+    for (int i4 = 0; i4 < 4; ++i4) {
+      f32x2_e xa = {acc[r][4 * i4], acc[r][4 * i4 + 1]};
+      f32x2_e xb = {acc[r][4 * i4 + 2], acc[r][4 * i4 + 3]};
+      if (F16) { xa = xa * f32x2_e{a.descale, a.descale}; xb = xb * f32x2_e{a.descale, a.descale}; }
       if (ACT) {                                   // compile-time: a run-time test here becomes a branch per pair and
                                                    // serialises the exp latency of the eight pairs
-        f32x2_e e = x * kl2e;
-        e.x = __builtin_amdgcn_exp2f(e.x);
-        e.y = __builtin_amdgcn_exp2f(e.y);
-        e = e - kone;
-        x.x = x.x > 0.f ? x.x : e.x;
-        x.y = x.y > 0.f ? x.y : e.y;
+        f32x2_e ea = xa * kl2e;
+        f32x2_e eb = xb * kl2e;
+        ea.x = __builtin_amdgcn_exp2f(ea.x);
+        ea.y = __builtin_amdgcn_exp2f(ea.y);
+        eb.x = __builtin_amdgcn_exp2f(eb.x);
+        eb.y = __builtin_amdgcn_exp2f(eb.y);
+        ea = ea - kone;
+        eb = eb - kone;
+        xa.x = elu_select(xa.x, ea.x);
+        xa.y = elu_select(xa.y, ea.y);
+        xb.x = elu_select(xb.x, eb.x);
+        xb.y = elu_select(xb.y, eb.y);
       }
-      x = x - ctr[i2];                                 // stored centred (zeros without s_ctr)
-      v[2 * i2] = x.x; v[2 * i2 + 1] = x.y;
-      const f32x2_e vm = MASKED ? x * m2 : x;
-      s1[i2] = s1[i2] + vm;
-      s2[i2] = __builtin_elementwise_fma(vm, vm, s2[i2]);   // one v_pk_fma_f32 (the two fused multiply-adds, bit for bit)
+      xa = xa - ctr[2 * i4];                           // stored centred (zeros without s_ctr)
+      xb = xb - ctr[2 * i4 + 1];
+      v[4 * i4] = xa.x; v[4 * i4 + 1] = xa.y; v[4 * i4 + 2] = xb.x; v[4 * i4 + 3] = xb.y;
+      const f32x2_e va = MASKED ? xa * m2 : xa;
+      const f32x2_e vb = MASKED ? xb * m2 : xb;
+      s1[2 * i4] = s1[2 * i4] + va;
+      s1[2 * i4 + 1] = s1[2 * i4 + 1] + vb;
+      s2[2 * i4] = __builtin_elementwise_fma(va, va, s2[2 * i4]);   // one v_pk_fma_f32 (the two fused multiply-adds, bit for bit)
+      s2[2 * i4 + 1] = __builtin_elementwise_fma(vb, vb, s2[2 * i4 + 1]);
     }
     if (a.dbg & 8) continue;
     if (a.out_oct) {
       const unsigned vo = (unsigned)(f * Tp + t) * 16u + (unsigned)half * P16 + (unsigned)(cbase >> 3) * P16;
-      store_oct_row<NP, F16>(v, rs, vo, P16, ok && oct_ok0, ok && oct_ok1);
+      // un-masked tiles: no predicates at all -- octets past Cout lie outside num_records of the part descriptors and
+      // are dropped by the hardware (the masked path still needs the per-lane frame / row test)
+      if (MASKED) store_oct_row<NP, F16>(v, rs, vo, P16, ok && oct_ok0, ok && oct_ok1);
+      else store_oct_row<NP, F16>(v, rs, vo, P16, true, true);
     } else {
       const unsigned vo = ok ? ((unsigned)(f * Tp + t) * 4u + (unsigned)(4 * half) * P4) : 0x80000000u;
 #pragma unroll

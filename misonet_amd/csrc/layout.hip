@@ -42,9 +42,10 @@ __global__ __launch_bounds__(256) void pack_k(const float2* src, int Mseg, int T
   }
 }
 
-// mode 0: output o = n*S + s reads planes (n*Cbuf + c_re0 + s, n*Cbuf + c_im0 + s)
+// bstride: floats between consecutive samples of the source buffer (the activation arena is sample-major: net.hip)
+// mode 0: output o = n*S + s reads planes (c_re0 + s, c_im0 + s) of sample n
 // mode 1: aligned MISO1 estimates: o = (b*S + j)*M + m reads sample b*M + m, speaker q = sel[(b*M + m)*S + j]
-__global__ __launch_bounds__(256) void unpack_k(const float* src, int Cbuf, int Tp, int S, int T, int F,
+__global__ __launch_bounds__(256) void unpack_k(const float* src, long long bstride, int Tp, int S, int T, int F,
                                                 int c_re0, int c_im0, int mode, int M, const int* sel, float2* dst,
                                                 int* nan_flag) {
   __shared__ float s_re[LFMAX][LT + 1];
@@ -54,17 +55,17 @@ __global__ __launch_bounds__(256) void unpack_k(const float* src, int Cbuf, int 
   long long pre, pim;
   if (mode == 0) {
     const int n = o / S, s = o - n * S;
-    pre = (long long)n * Cbuf + c_re0 + s;
-    pim = (long long)n * Cbuf + c_im0 + s;
+    pre = (long long)n * bstride + (long long)(c_re0 + s) * F * Tp;
+    pim = (long long)n * bstride + (long long)(c_im0 + s) * F * Tp;
   } else {
     const int m = o % M, bj = o / M, j = bj % S, b = bj / S;
     const int n = b * M + m;
     const int q = sel[n * S + j];
-    pre = (long long)n * Cbuf + c_re0 + q;
-    pim = (long long)n * Cbuf + c_im0 + q;
+    pre = (long long)n * bstride + (long long)(c_re0 + q) * F * Tp;
+    pim = (long long)n * bstride + (long long)(c_im0 + q) * F * Tp;
   }
-  const float* sre = src + pre * F * Tp + t0;
-  const float* sim = src + pim * F * Tp + t0;
+  const float* sre = src + pre + t0;
+  const float* sim = src + pim + t0;
   const int nt = min(LT, T - t0);
   const int tl = tid & 31, fr = tid >> 5;
   for (int f = fr; f < F; f += 8) {
@@ -143,18 +144,17 @@ hipError_t launch_pack(const float2* src, int B, int Mseg, int T, int F, float* 
   return hipGetLastError();
 }
 
-hipError_t launch_unpack_ex(const float* src, int Cbuf, int Tp, int S, int T, int F, int c_re0, int c_im0, int mode,
+hipError_t launch_unpack_ex(const float* src, long long src_bstride, int Tp, int S, int T, int F, int c_re0, int c_im0, int mode,
                             int M, const int* sel, float2* dst, int n_out, int* nan_flag, hipStream_t s) {
   if (F > LFMAX) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(unpack_k, dim3((T + LT - 1) / LT, n_out), dim3(256), 0, s, src, Cbuf, Tp, S, T, F, c_re0, c_im0,
+  hipLaunchKernelGGL(unpack_k, dim3((T + LT - 1) / LT, n_out), dim3(256), 0, s, src, src_bstride, Tp, S, T, F, c_re0, c_im0,
                      mode, M, sel, dst, nan_flag);
   return hipGetLastError();
 }
 
 hipError_t launch_unpack(const float* src, long long src_bstride, int Tp, int S, int T, int F, float2* dst,
                          int n_samples, int* nan_flag, hipStream_t s) {
-  const int Cbuf = (int)(src_bstride / ((long long)F * Tp));
-  return launch_unpack_ex(src, Cbuf, Tp, S, T, F, 0, S, 0, 1, nullptr, dst, n_samples * S, nan_flag, s);
+  return launch_unpack_ex(src, src_bstride, Tp, S, T, F, 0, S, 0, 1, nullptr, dst, n_samples * S, nan_flag, s);
 }
 
 hipError_t launch_export(const float* src, long long src_bstride, int c0, int C, int Fq, int T, int Tp,

@@ -15,7 +15,7 @@
 #include <vector>
 
 namespace mn {
-hipError_t launch_unpack_ex(const float* src, int Cbuf, int Tp, int S, int T, int F, int c_re0, int c_im0, int mode,
+hipError_t launch_unpack_ex(const float* src, long long src_bstride, int Tp, int S, int T, int F, int c_re0, int c_im0, int mode,
                             int M, const int* sel, float2* dst, int n_out, int* nan_flag, hipStream_t s);
 hipError_t launch_compose_sel(const int* shift_sel, const int* clean_sel, int B, int M, int S, int* out, hipStream_t s);
 hipError_t launch_assemble3(const float* in1, long long in1_bstride, const float* out1, long long out1_bstride,
@@ -1078,11 +1078,11 @@ static int pipeline_run_impl(misonet_pipeline* p, const void* mix, const void* c
     HIPCHK(launch_unpack(buf_ptr(P.L3, ws3, B_OUT), bstride(n3, P.L3, B_OUT), Tp, 1, T, F, reinterpret_cast<float2*>(out),
                          B * S, reinterpret_cast<int*>(base), s));
     if (bf_out)
-      HIPCHK(launch_unpack_ex(in3, n3->cfg.in_ch, Tp, 1, T, F, M, 2 * M + 2, 0, 1, nullptr,
+      HIPCHK(launch_unpack_ex(in3, in3_bs, Tp, 1, T, F, M, 2 * M + 2, 0, 1, nullptr,
                               reinterpret_cast<float2*>(bf_out), B * S, reinterpret_cast<int*>(base), s));
   }
   if (miso1_out)
-    HIPCHK(launch_unpack_ex(out1, n1->cfg.out_ch, Tp, S, T, F, 0, S, 1, M, sel_final, reinterpret_cast<float2*>(miso1_out),
+    HIPCHK(launch_unpack_ex(out1, out1_bs, Tp, S, T, F, 0, S, 1, M, sel_final, reinterpret_cast<float2*>(miso1_out),
                             B * S * M, reinterpret_cast<int*>(base), s));
   return MISONET_OK;
 }
