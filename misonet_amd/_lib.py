@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmisonet_hip.so")
+# MISONET_LIB_PATH: A/B measurements of two builds on one box (tools/gpu_ab_lib.sh); normal use never sets it
+LIB_PATH = os.environ.get("MISONET_LIB_PATH") or os.path.join(_HERE, "libmisonet_hip.so")
 
 OK, EINVAL, ESTATE, EHIP, ENOMEM, ENAN = 0, -1, -2, -3, -4, -5
 

@@ -126,6 +126,86 @@ __device__ __forceinline__ void chunk_mfma6(f32x16 (&acc)[NROW], const bf16x8* s
   }
 }
 
+// MODE 3, "rows in M": a stride-1 layer with Cout <= 4 -- the network's last transposed conv, 48 -> 2 * num_spks channels at
+// F = 129 (reference model.py:418-423, 64).  With channels on the 32 MFMA rows it uses 4 of them.  Here the rows are
+// (output row d = 0..7) x (channel co = 0..3): ONE accumulator tile holds a wave's whole 8-row x 4-channel x 32-frame
+// output, and a staged input row R is multiplied ONCE per chunk (9 MFMAs: 6 for the paired time taps 0|1, 3 for tap 2)
+// by the BANDED weight fragment A_R[(d, co)] = W[kf = R - d][co] (zero outside 0 <= kf <= 2): 90 MFMAs per chunk and wave
+// instead of 216 -- the layer becomes bound by its input bytes (6 per element, read once), as a 4-channel layer should be.
+//   sw: COMPACT weight image of the chunk: unit ((kf * 3 + p) * 3 + kt) * 4 + co, 108 units (gathered by two LDS-DMA
+//       instructions); a lane whose output row is outside the band of R zeroes its fragment in registers.
+constexpr int X6_RM_UNITS = 3 * 3 * 3 * 4;
+template <int NR>
+__device__ __forceinline__ void chunk_mfma6_rm(f32x16& acc, const bf16x8* sx, const bf16x8* sw, int wave, int half, int l31) {
+  constexpr int XN = NR * X6_TW;
+  const int d = l31 >> 2, co = l31 & 3;
+  const int a0 = half * 4 + co - d * 36;                   // + R * 36 + p * 12: unit of (kf = R - d, p, kt = half, co)
+  const int a2 = 2 * 4 + co - d * 36;                      // kt = 2
+  const int p2 = half ? 2 : 0;
+  const int xa = 32 * wave + l31 + half;                   // + p * XN + R * X6_TW     (kt = half)
+  const int xb0 = (half ? XN : 0) + 32 * wave + l31 + 2;
+  const int xb1 = (half ? 0 : 2 * XN) + 32 * wave + l31 + 2;
+  bf16x8 A[2][3], A2[2][3], B[2][3], B2[2][2];
+#pragma unroll
+  for (int R = -1; R < NR; ++R) {
+    if (R + 1 < NR) {
+      const int nx = (R + 1) & 1;
+      const bool in_band = (unsigned)(R + 1 - d) < 3u;     // 0 <= kf <= 2 for this lane's output row
+      const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+      const int ar = in_band ? a0 + (R + 1) * 36 : half * 4 + co;           // out of the band: any valid unit, then zeroed
+      const int ar2 = in_band ? a2 + (R + 1) * 36 : 2 * 4 + co;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const bf16x8 w = sw[ar + p * 12];
+        A[nx][p] = in_band ? w : zero;
+        B[nx][p] = sx[p * XN + (R + 1) * X6_TW + xa];
+      }
+      {
+        const bf16x8 w0 = sw[ar2], w1 = sw[ar2 + 12], w2 = sw[ar2 + p2 * 12];
+        A2[nx][0] = in_band ? w0 : zero;                                       // [w_h | w_h]
+        A2[nx][1] = in_band ? w1 : zero;                                       // [w_m | w_m]
+        A2[nx][2] = in_band ? w2 : zero;                                       // [w_h | w_l]
+      }
+      B2[nx][0] = sx[xb0 + (R + 1) * X6_TW];                                   // [x_h | x_m]
+      B2[nx][1] = sx[xb1 + (R + 1) * X6_TW];                                   // [x_l | x_h]
+    }
+    __builtin_amdgcn_sched_barrier(0);     // keep the next row's ds_reads AHEAD of this row's MFMAs
+    if (R >= 0) {
+      const int cur = R & 1;
+      // small terms first: time tap 2 (hl + lh, mh + mm), then lh, hl, mm, mh, hm of taps 0|1, the large ones last
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2[cur][2], B2[cur][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cur][2], B[cur][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cur][0], B[cur][2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2[cur][1], B2[cur][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cur][1], B[cur][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cur][1], B[cur][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cur][0], B[cur][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2[cur][0], B2[cur][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cur][0], B[cur][0], acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// tile epilogue of MODE 3: raw planar float32 output (act = 0, no statistics): register i of half-wave h holds channel
+// i & 3 of output row f0 + 2 * (i >> 2) + h; rows / frames / channels that do not exist get an out-of-range offset.
+__device__ __forceinline__ void conv_epilogue_rm(const ConvArgs& a, const f32x16& acc, int n, int f0, int tw, int lane) {
+  const int half = lane >> 5, l31 = lane & 31;
+  const int t = tw + l31;
+  const unsigned P4 = (unsigned)a.Fout * (unsigned)a.Tp * 4u;
+  const __amdgpu_buffer_rsrc_t rs = make_rsrc_e(
+      reinterpret_cast<unsigned long long>(a.out + (long long)n * a.out_bstride + (long long)a.out_c0 * a.Fout * a.Tp),
+      (unsigned)a.Cout * P4);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int co = i & 3, f = f0 + 2 * (i >> 2) + half;
+    const bool ok = (t < a.T) && (f < a.Fout) && (co < a.Cout) && !(a.dbg & 8);
+    const unsigned vo = ok ? (unsigned)co * P4 + (unsigned)(f * a.Tp + t) * 4u : 0x80000000u;
+    const float v = acc[i];     // (a scalar temporary: __builtin_bit_cast on a vector-element lvalue reads element 0, hipcc 7.2)
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, vo, 0, 0);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // ONE persistent workgroup per CU, 8 waves: waves 0-3 = consumers (MFMAs + tile epilogue), waves 4-7 = producers (LDS-DMA,
 // epilogue tables of the coming tile, float64 statistics atomics of finished tiles).  Workgroup b belongs to XCD b & 7 and
@@ -175,8 +255,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
   constexpr int COP = 32;
   constexpr int SF = MODE == 1 ? 2 : 1;
   constexpr bool TR2 = MODE == 2;
+  constexpr bool RM = MODE == 3;                               // rows in M (chunk_mfma6_rm): Cout <= 4, act = 0, planar output
   static_assert(FTR == 4 || (FTR == 8 && MODE != 1), "8-row tiles: not for the stride-2 layers (17 staged rows)");
-  constexpr int NR = MODE == 0 ? FTR + 2 : (MODE == 1 ? 9 : FTR / 2 + 1);   // staged input rows of an FTR-row tile
+  static_assert(!RM || FTR == 8, "rows-in-M tiles are 8 output rows x 4 channels");
+  constexpr int NR = (MODE == 0 || RM) ? FTR + 2 : (MODE == 1 ? 9 : FTR / 2 + 1);   // staged input rows of an FTR-row tile
   constexpr int NS = 2;                                        // stages
   constexpr int XN = NR * X6_TW;                               // units per input part image
   constexpr int SN = 3 * XN + X6_WU;                           // units per stage: [x_h | x_m | x_l | w]
@@ -240,6 +322,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
     const unsigned long long part_b = (unsigned long long)(a.in_sstride >> 3) * P16;   // bytes between the parts
     const unsigned wbytes = (unsigned)nchunk * (unsigned)X6_WU * 16u;        // one (sample, group) weight image set
     const unsigned wo = (unsigned)(tid & 255) * 16u;
+    unsigned wo_rm = 0x80000000u;                              // MODE 3: byte offset of this lane's compact unit in the image
+    if (RM) {
+      const int c = rw * 64 + lane;                            // ((kf * 3 + p) * 3 + kt) * 4 + co
+      if (rw < 2 && c < X6_RM_UNITS) {
+        const int co = c & 3, kt = (c >> 2) % 3, kfp = c / 12;
+        wo_rm = (unsigned)(kt < 2 ? (kfp * 2 + kt) * 32 + co : X6_WPAIR + kfp * 32 + co) * 16u;
+      }
+    }
     const int btab_parts = nchunk >= 8 ? 4 : (nchunk >= 4 ? 2 : 1);          // conv_bf16x6_btab_parts
     __amdgpu_buffer_rsrc_t rs_x0, rs_x1, rs_x2, rs_w;
     unsigned xo[NXI];
@@ -285,6 +375,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
       if (xo[i] != 0x80000000u) xo[i] += P16;                                                                   \
     }                                                                                                           \
     const unsigned wsoff_ = (unsigned)(KC) * (unsigned)X6_WU * 16u;                                             \
+    if (RM) {   /* gather the 108 units of the 4 channels into the compact image; lanes past it fetch zeros */   \
+      if (rw < 2 && !(a.dbg & 128))                                                                             \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, MN_LDS(st_ + 3 * XN + rw * 64), 16, wo_rm, wsoff_, 0, 0); \
+    } else                                                                                                      \
     _Pragma("unroll") for (int i = 0; i < NWI; ++i) {                                                           \
       const int ub = (i * 4 + rw) * 64;                                                                         \
       if (ub < X6_WU && !(a.dbg & 128)) {                                                                       \
@@ -344,7 +438,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
       }                                                                                                         \
       b3[1] += tbias_;                                                                                          \
       /* accumulator order: channel co = (i&3) + 8*(i>>2) + 4*h  ->  h = (co>>2)&1, i = (co&3) + 4*(co>>3) */    \
-      const int slot_ = (rr_ * 2 + ((lc_ >> 2) & 1)) * 16 + (lc_ & 3) + 4 * (lc_ >> 3);                         \
+      /* (MODE 3: ONE tile, register i of half h = channel i & 3 of row 2 * (i >> 2) + h; channels >= 4 go to a    */ \
+      /* scratch slot of the second row set, which that mode never reads)                                          */ \
+      const int slot_ = RM ? (lc_ < 4 ? (rr_ & 1) * 16 + lc_ + 4 * (rr_ >> 1) : COP + lc_)                      \
+                           : (rr_ * 2 + ((lc_ >> 2) & 1)) * 16 + (lc_ & 3) + 4 * (lc_ >> 3);                    \
       float* tb_ = s_tab + (TS) * (3 * FTR * COP);                                                              \
       tb_[slot_] = b3[0] + b3[1] + b3[2];                                                                       \
       tb_[FTR * COP + slot_] = b3[0];                                                                           \
@@ -352,7 +449,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
       /* centre of the stored activations per channel: ELU(bias) -- the pre-activation of normalised inputs has mean   */ \
       /* bias exactly.  (NOT the accumulator start value: bias - sum W' mean_in is far from the output when |mean_in|  */ \
       /* >> std_in.)                                                                                                    */ \
-      if (rr_ == 0) s_ctr[(CS) * COP + slot_] = elu_fast(tbias_);                                               \
+      if (rr_ == 0 && !RM) s_ctr[(CS) * COP + slot_] = elu_fast(tbias_);                                        \
     }                                                                                                           \
   }
 #define TILE_TABLES(TS, CS) { TABLES_LOAD() TABLES_FINISH(TS, CS) }
@@ -453,7 +550,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
     unsigned g = 0, ti = 0;
     __syncthreads();                                           // barrier 0: chunk 0 has landed
     for (;;) {
-      f32x16 acc[FTR];
+      f32x16 acc[RM ? 1 : FTR];
       const bool wave_live = (t0 + 32 * wave < T) && !(a.dbg & 1);   // this consumer's frames exist (ragged last tile)
       {
         const float* tb = s_tab + (ti % NS) * (3 * FTR * COP);  // accumulators start at bias + folded shift
@@ -463,14 +560,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
         if (wave_live) {
           const bf16x8* st = s_stage + (g % NS) * SN;
           __builtin_amdgcn_s_setprio(1);
-          chunk_mfma6<NR, SF, TR2, FTR>(acc, st, st + 3 * XN, wave, half, l31);
+          if constexpr (RM) chunk_mfma6_rm<NR>(acc[0], st, st + 3 * XN, wave, half, l31);
+          else chunk_mfma6<NR, SF, TR2, FTR>(acc, st, st + 3 * XN, wave, half, l31);
           __builtin_amdgcn_s_setprio(0);
         }
         STAMP(ti);
         __syncthreads();                                       // barrier g + 1: done reading chunk g
         STAMP(ti);
       }
-      if (!(a.dbg & 4))
+      if constexpr (RM) {
+        if (!(a.dbg & 4)) conv_epilogue_rm(a, acc[0], n, f0, t0 + 32 * wave, lane);
+      } else if (!(a.dbg & 4))
         conv_epilogue_rows_nb<3>(a, acc, n, cg, f0, t0 + 32 * wave, lane, s_red + (ti & 1) * (4 * COP * 2) + wave * (COP * 2), FTR,
                                  a.act ? s_ctr + (ti & 3) * COP : nullptr);
       ++ti;
@@ -586,6 +686,7 @@ hipError_t conv_bf16x6_init() {
   if ((e = x6_set_attr<0, 8>()) != hipSuccess) return e;
   if ((e = x6_set_attr<1, 4>()) != hipSuccess) return e;
   if ((e = x6_set_attr<2, 8>()) != hipSuccess) return e;
+  if ((e = x6_set_attr<3, 8>()) != hipSuccess) return e;
   return x6_set_attr<2, 4>();
 }
 
@@ -631,7 +732,10 @@ hipError_t launch_conv_bf16x6(const ConvArgs& a_in, int n_samples, hipStream_t s
   // tile geometry: 128 frames x 8 rows for the stride-1 layers with more than 4 rows (10 staged rows per 8 instead of
   // 6 per 4 and one weight image per 216 instead of 108 MFMAs: 25 % fewer staged bytes per MFMA), else x 4 rows
   static const int ft8 = [] { const char* e = getenv("MISONET_X6_ROWS8"); return e ? atoi(e) : 3; }();   // bit 0: stride-1, bit 1: transposed
-  const int ftr = (mode != 1 && a.Fout > 4 && (ft8 & (mode == 0 ? 1 : 2))) ? 8 : 4;
+  // rows-in-M tiles (MODE 3) for the raw 4-channel output layer (MISONET_X6_RM=0: the 32-channel tiles, for A/B runs)
+  static const int rm_env = [] { const char* e = getenv("MISONET_X6_RM"); return e ? atoi(e) : 1; }();
+  const bool rows_in_m = rm_env && mode == 0 && a.padf == 2 && !a.act && !a.out_oct && a.Cout <= 4 && a.ncg == 1 && a.Fout > 4;
+  const int ftr = rows_in_m ? 8 : ((mode != 1 && a.Fout > 4 && (ft8 & (mode == 0 ? 1 : 2))) ? 8 : 4);
   (void)conv_grid(a, n_samples, TT, ftr, 1);
   if (n_samples % 8) a.xcd = 2;                                    // columns, not samples, are dealt to the XCDs
   const int g_cus = device_cus();
@@ -647,7 +751,8 @@ hipError_t launch_conv_bf16x6(const ConvArgs& a_in, int n_samples, hipStream_t s
     if (cap > 0 && nslots > cap) nslots = cap;
   }
   const dim3 pgrid((unsigned)(8 * nslots), 1, 1);
-  if (mode == 0 && ftr == 8) hipLaunchKernelGGL((conv3x3_bf16x6<0, 8>), pgrid, dim3(512), x6_lds_bytes(10, 8), s, a, nslots);
+  if (rows_in_m) hipLaunchKernelGGL((conv3x3_bf16x6<3, 8>), pgrid, dim3(512), x6_lds_bytes(10, 8), s, a, nslots);
+  else if (mode == 0 && ftr == 8) hipLaunchKernelGGL((conv3x3_bf16x6<0, 8>), pgrid, dim3(512), x6_lds_bytes(10, 8), s, a, nslots);
   else if (mode == 0) hipLaunchKernelGGL((conv3x3_bf16x6<0, 4>), pgrid, dim3(512), x6_lds_bytes(6, 4), s, a, nslots);
   else if (mode == 1) hipLaunchKernelGGL((conv3x3_bf16x6<1, 4>), pgrid, dim3(512), x6_lds_bytes(9, 4), s, a, nslots);
   else if (ftr == 8) hipLaunchKernelGGL((conv3x3_bf16x6<2, 8>), pgrid, dim3(512), x6_lds_bytes(5, 8), s, a, nslots);
