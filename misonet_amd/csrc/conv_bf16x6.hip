@@ -134,7 +134,7 @@ __device__ __forceinline__ void chunk_mfma6(f32x16 (&acc)[NROW], const bf16x8* s
 // instead of 216 -- the layer becomes bound by its input bytes (6 per element, read once), as a 4-channel layer should be.
 //   sw: COMPACT weight image of the chunk: unit ((kf * 3 + p) * 3 + kt) * 4 + co, 108 units (gathered by two LDS-DMA
 //       instructions); a lane whose output row is outside the band of R zeroes its fragment in registers.
-constexpr int X6_RM_UNITS = 3 * 3 * 3 * 4;
+[[maybe_unused]] constexpr int X6_RM_UNITS = 3 * 3 * 3 * 4;
 template <int NR>
 __device__ __forceinline__ void chunk_mfma6_rm(f32x16& acc, const bf16x8* sx, const bf16x8* sw, int wave, int half, int l31) {
   constexpr int XN = NR * X6_TW;

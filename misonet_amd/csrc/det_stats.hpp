@@ -30,7 +30,9 @@ __device__ __forceinline__ void dstat_add(dstat_t* p, double v) {
   for (int i = DS_NL - 1; i >= 0; --i) {
     const double q = trunc(v * dn[i]);       // |q| < 2^40 (top limb: < 2^38); exact
     v = fma(-q, up[i], v);                   // exact: removes the leading bits
-    const long long qi = (long long)q;
+    // q is an integer below 2^40 in magnitude: its two's-complement value sits in the low mantissa bits of q + 1.5 * 2^52
+    // (2 instructions; a double -> int64 conversion is emulated with ~20)
+    const long long qi = __double_as_longlong(q + 0x1.8p52) - 0x4338000000000000ll;
     if (qi) atomicAdd(p + i, (unsigned long long)qi);
   }
 }

@@ -112,17 +112,21 @@ hipError_t conv_bf16x6_init();
 long long conv_bf16x6_wps_bytes(int Cin, int Cout);   // per-sample folded-weight bytes of one layer
 
 // ---- TCN (reference model.py:486-632) -----------------------------------------------------------------------------
+// Statistics travel as float64 (sum, sum of squares) PARTIALS, one per producing workgroup, added by the consumer in index
+// order (no atomics, bit-reproducible): IN1d [n][C][tcn_part_slots(T)] (one per 128-frame tile; tcn_prepare writes slot 0
+// only), gLN [n][C / 4] (one per 4-channel group).
+int tcn_part_slots(int T);
 // x0 = IN2d(raw) materialised as the residual stream + its per-(n,c) statistics
 hipError_t launch_tcn_prepare(const float* raw, long long raw_bstride, int raw_c0, const dstat_t* raw_stats, int raw_sstride,
-                              float* x, dstat_t* x_stats, int C, int T, int Tp, int n_samples, hipStream_t s,
+                              float* x, double2* x_part, int C, int T, int Tp, int n_samples, hipStream_t s,
                               int raw_oct3 = 0);   // raw_oct3: source in the bf16x6 oct3 layout
-// d = PReLU(dwconv_dilated(ELU(IN1d(x)))) ; accumulates gLN statistics (per sample) of d
-hipError_t launch_tcn_dw(const float* x, const dstat_t* x_stats, const float* wdw /*[C][3]*/, const float* prelu /*[1]*/,
-                         float* d, dstat_t* gln_stats /*[n][2][DS_NL]*/, int C, int T, int Tp, int dilation, int n_samples, hipStream_t s);
-// y = pwconv(gLN(d)) (+ residual) ; accumulates IN statistics of y
-hipError_t launch_tcn_pw(const float* d, const dstat_t* gln_stats, const float* gamma, const float* beta,
+// d = PReLU(dwconv_dilated(ELU(IN1d(x)))) ; gLN partials of d.  x_np: partials per row of x_part (1 or tcn_part_slots(T))
+hipError_t launch_tcn_dw(const float* x, const double2* x_part, int x_np, const float* wdw /*[C][3]*/, const float* prelu /*[1]*/,
+                         float* d, double2* gln_part /*[n][C/4]*/, int C, int T, int Tp, int dilation, int n_samples, hipStream_t s);
+// y = pwconv(gLN(d)) (+ residual) ; IN partials of y
+hipError_t launch_tcn_pw(const float* d, const double2* gln_part, const float* gamma, const float* beta,
                          const float* wpw /*packed [C/CK... see tcn.hip]*/, const float* residual /*or nullptr*/,
-                         float* y, long long y_bstride, int y_c0, dstat_t* y_stats /*[n][C][2][DS_NL]*/, int C, int T, int Tp,
+                         float* y, long long y_bstride, int y_c0, double2* y_part /*[n][C][slots]*/, int C, int T, int Tp,
                          int n_samples, hipStream_t s,
                          int y_oct3_cbuf = 0, int x6 = 0);   // != 0: y is an oct3 buffer with that many channels (bf16x6 mode)
 

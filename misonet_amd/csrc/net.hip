@@ -119,7 +119,7 @@ struct Layout {
                                  // at + n * sample_stride); TCN buffers: offset of the whole [N][128][Tp] block
   long long sample_stride;       // floats per sample of the activation arena
   long long stats_off[NBUF];     // 8-byte words (dstat_t): [N][C][2][DS_NL] per buffer
-  long long tcn_xs, tcn_ps, tcn_gln;   // words: [15][N*128*2*DS_NL], [14][N*128*2*DS_NL], [28][N*2*DS_NL]
+  long long tcn_xs, tcn_ps, tcn_gln;   // words (2 per double2 partial): [15][N*128*slots], [14][N*128*slots], [28][N*32]
   long long stats_doubles;       // words in all
   long long data_base;           // bytes from ws start to the float arena
   long long wps_base, wps_nstride;   // bytes: per-sample folded weights of the layer in flight (DMA dataflow)
@@ -340,9 +340,11 @@ static Layout make_layout(const misonet_net* n, int N, int T) {
     L.stats_off[b] = so;
     so += (long long)N * n->bufs[b].C * 2 * DS_NL;
   }
-  L.tcn_xs = so;  so += 15LL * N * 128 * 2 * DS_NL;
-  L.tcn_ps = so;  so += 14LL * N * 128 * 2 * DS_NL;
-  L.tcn_gln = so; so += 28LL * N * 2 * DS_NL;
+  const long long tslots = tcn_part_slots(T);          // TCN statistics: plain double2 partials (tcn.hip), never zeroed
+  so = (so + 1) & ~1LL;                                // 16-byte alignment of the double2 arrays
+  L.tcn_xs = so;  so += 15LL * N * 128 * tslots * 2;
+  L.tcn_ps = so;  so += 14LL * N * 128 * tslots * 2;
+  L.tcn_gln = so; so += 28LL * N * 32 * 2;
   L.stats_doubles = so;
   L.data_base = align_up(256 + so * 8, 256);
   // ---- activation arena: per-sample offsets by first fit over (lifetime x address) rectangles, largest buffer first ----
@@ -491,7 +493,8 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
 
 // IN buffer already filled (planar).  Leaves the result (raw) in B_OUT.
 static int forward_planar(misonet_net* n, const Layout& L, void* ws, hipStream_t s) {
-  HIPCHK(hipMemsetAsync(ws, 0, (size_t)(256 + L.stats_doubles * 8), s));
+  // the nan flag + the conv statistics (integer limbs are ACCUMULATED); the TCN partial arrays behind them are plainly written
+  HIPCHK(hipMemsetAsync(ws, 0, (size_t)(256 + L.tcn_xs * 8), s));
   // Optional sample sub-batching of the conv stacks (MISONET_SUBBATCH = samples per pass at F = 127; deeper levels take
   // proportionally more): keeps a level's producer->consumer traffic inside the 256 MiB Infinity Cache.
   static const int sub_env = [] { const char* e = getenv("MISONET_SUBBATCH"); return e ? atoi(e) : 0; }();
@@ -521,11 +524,12 @@ static int forward_planar(misonet_net* n, const Layout& L, void* ws, hipStream_t
   {
     ProfScope ps_tcn(s, PK_TCN);
     const int N = L.N, T = L.T, Tp = L.Tp;
-    dstat_t* xs = stats_base(ws) + L.tcn_xs;
-    dstat_t* ps = stats_base(ws) + L.tcn_ps;
-    dstat_t* gl = stats_base(ws) + L.tcn_gln;
-    const long long per = (long long)N * 128 * 2 * DS_NL;
-    const long long gper = (long long)N * 2 * DS_NL;
+    double2* xs = reinterpret_cast<double2*>(stats_base(ws) + L.tcn_xs);
+    double2* ps = reinterpret_cast<double2*>(stats_base(ws) + L.tcn_ps);
+    double2* gl = reinterpret_cast<double2*>(stats_base(ws) + L.tcn_gln);
+    const int tslots = tcn_part_slots(T);
+    const long long per = (long long)N * 128 * tslots;
+    const long long gper = (long long)N * 32;
     float* xa = buf_ptr(L, ws, B_TXA);
     float* xb = buf_ptr(L, ws, B_TXB);
     float* td = buf_ptr(L, ws, B_TD);
@@ -541,11 +545,11 @@ static int forward_planar(misonet_net* n, const Layout& L, void* ws, hipStream_t
     for (int k = 0; k < 14; ++k) {
       const TcnBlock& tb = n->tcn[k];
       const float* W = n->w_dev;
-      HIPCHK(launch_tcn_dw(cur, xs + k * per, W + tb.h[0].o_dw, W + tb.h[0].o_prelu, td, gl + (2 * k) * gper,
+      HIPCHK(launch_tcn_dw(cur, xs + k * per, k == 0 ? 1 : tslots, W + tb.h[0].o_dw, W + tb.h[0].o_prelu, td, gl + (2 * k) * gper,
                            128, T, Tp, tb.dilation, N, s));
       HIPCHK(launch_tcn_pw(td, gl + (2 * k) * gper, W + tb.h[0].o_gamma, W + tb.h[0].o_beta, W + tb.h[0].o_pw,
                            nullptr, tp, 128LL * Tp, 0, ps + k * per, 128, T, Tp, N, s, 0, tcn_x6));
-      HIPCHK(launch_tcn_dw(tp, ps + k * per, W + tb.h[1].o_dw, W + tb.h[1].o_prelu, td,
+      HIPCHK(launch_tcn_dw(tp, ps + k * per, tslots, W + tb.h[1].o_dw, W + tb.h[1].o_prelu, td,
                            gl + (2 * k + 1) * gper, 128, T, Tp, tb.dilation, N, s));
       const bool last = (k == 13);
       float* y = last ? buf_ptr(L, ws, B_D0) : nxt;

@@ -5,7 +5,9 @@
 // utterance (IN1d: per (n,c) over T; gLN: per n over (C,T)), so a DS conv is two launches:
 //   tcn_dw : a = ELU(IN1d(x)) on the fly -> depth-wise dilated conv -> PReLU -> d ; gLN sums of d
 //   tcn_pw : g = gLN(d) on the fly -> 128x128 point-wise conv on the fp32 matrix cores (+ residual) ; IN1d sums
-// All sums are float64.  Activations are planar [n][c][Tp] (F = 1).
+// All sums are float64 and bit-reproducible WITHOUT atomics: a producer writes one partial (sum, sum of squares) per
+// workgroup -- IN1d: one per 128-frame tile of a (n, c) row, gLN: one per 4-channel group of a sample -- and the consumer
+// adds the partials of its row / sample in index order (tpart_sum).  Activations are planar [n][c][Tp] (F = 1).
 #include "kernels.hpp"
 #include "conv_epilogue.hpp"
 
@@ -23,9 +25,16 @@ __device__ inline double block_sum_256(double v, double* s_tmp /*[4]*/) {
   return s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
 }
 
-__device__ inline void in_params(const dstat_t* st, int T, float& mean, float& rstd) {
-  const double m = dstat_read(st) / (double)T;
-  double var = dstat_read(st + DS_NL) / (double)T - m * m;
+// fixed-order sum of the np partials of one statistic pair
+__device__ inline double2 tpart_sum(const double2* p, int np) {
+  double2 s = p[0];
+  for (int i = 1; i < np; ++i) { const double2 q = p[i]; s.x += q.x; s.y += q.y; }
+  return s;
+}
+
+__device__ inline void in_params(double2 st, int T, float& mean, float& rstd) {
+  const double m = st.x / (double)T;
+  double var = st.y / (double)T - m * m;
   var = var > 0.0 ? var : 0.0;
   mean = (float)m;
   rstd = (float)(1.0 / sqrt(var + (double)IN_EPS));
@@ -36,11 +45,14 @@ __device__ inline void in_params(const dstat_t* st, int T, float& mean, float& r
 // exact sum); raw_sstride = channels of that buffer.
 __global__ __launch_bounds__(256) void tcn_prepare_k(const float* raw, long long raw_bstride, int raw_c0,
                                                      const dstat_t* raw_stats, int raw_sstride, float* x,
-                                                     dstat_t* x_stats, int C, int T, int Tp, int raw_oct3) {
+                                                     double2* x_part, int nps, int C, int T, int Tp, int raw_oct3) {
   __shared__ double s_tmp[4];
   const int c = blockIdx.x, n = blockIdx.y;
   float mean, rstd;
-  in_params(raw_stats + ((long long)n * raw_sstride + raw_c0 + c) * (2 * DS_NL), T, mean, rstd);
+  {
+    const dstat_t* st = raw_stats + ((long long)n * raw_sstride + raw_c0 + c) * (2 * DS_NL);
+    in_params(make_double2(dstat_read(st), dstat_read(st + DS_NL)), T, mean, rstd);
+  }
   const float* src = raw + (long long)n * raw_bstride + (long long)(raw_c0 + c) * Tp;
   const unsigned short* so = reinterpret_cast<const unsigned short*>(raw + (long long)n * raw_bstride);
   const int ch = raw_c0 + c;
@@ -63,11 +75,7 @@ __global__ __launch_bounds__(256) void tcn_prepare_k(const float* raw, long long
   }
   s1 = block_sum_256(s1, s_tmp);
   s2 = block_sum_256(s2, s_tmp);
-  if (threadIdx.x == 0) {
-    dstat_t* o = x_stats + ((long long)n * C + c) * (2 * DS_NL);
-    dstat_add(o, s1);
-    dstat_add(o + DS_NL, s2);
-  }
+  if (threadIdx.x == 0) x_part[((long long)n * C + c) * nps] = make_double2(s1, s2);     // the row's only partial
 }
 
 // d = PReLU(dwconv(ELU(IN1d(x)))), kernel 3, dilation = padding = dil, no bias (model.py:556-558)
@@ -75,20 +83,20 @@ __global__ __launch_bounds__(256) void tcn_prepare_k(const float* raw, long long
 // into the wave's LDS row (zero outside [0, T): Conv1d pads its input, i.e. the ELU output), then every lane produces
 // 4 consecutive frames per pass from LDS.  Rows longer than the LDS row are walked in segments of DW_SEG frames with a
 // DW_HALO-frame halo on both sides (dil <= DW_HALO), so there is no limit on T; T = 1001 is one segment.  One float64
-// atomic pair per workgroup for the gLN sums.
+// partial pair per workgroup for the gLN sums.
 constexpr int DW_MAXT = 2048;                      // frames per row kept in LDS (4 rows x 8 KB)
 constexpr int DW_HALO = 64;                        // largest dilation of TemporalConvNet(2, 7, ...): 2^6
 constexpr int DW_SEG = DW_MAXT - 2 * DW_HALO;      // output frames per segment
-__global__ __launch_bounds__(256) void tcn_dw_k(const float* x, const dstat_t* x_stats, const float* wdw,
-                                                const float* prelu, float* d, dstat_t* gln_stats, int C, int T,
-                                                int Tp, int dil, int seg_f) {
+__global__ __launch_bounds__(256) void tcn_dw_k(const float* x, const double2* x_part, int x_np, int nps,
+                                                const float* wdw, const float* prelu, float* d, double2* gln_part,
+                                                int C, int T, int Tp, int dil, int seg_f) {
   __shared__ double s_tmp[4][2];
   extern __shared__ __align__(16) float s_a_dyn[];             // [4 rows][row_f]: row_f = frames of a segment + 2 halos
   const int row_f = seg_f + 2 * DW_HALO;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 4 + wave, n = blockIdx.y;
   float mean, rstd;
-  in_params(x_stats + ((long long)n * C + c) * (2 * DS_NL), T, mean, rstd);
+  in_params(tpart_sum(x_part + ((long long)n * C + c) * nps, x_np), T, mean, rstd);
   const float sc = rstd, sh = -mean * rstd;
   const float w0 = wdw[c * 3 + 0], w1 = wdw[c * 3 + 1], w2 = wdw[c * 3 + 2];
   const float slope = prelu[0];
@@ -141,10 +149,9 @@ __global__ __launch_bounds__(256) void tcn_dw_k(const float* x, const dstat_t* x
   }
   if (lane == 0) { s_tmp[wave][0] = r1; s_tmp[wave][1] = r2; }
   __syncthreads();
-  if (threadIdx.x < 2) {
-    const double tot = s_tmp[0][threadIdx.x] + s_tmp[1][threadIdx.x] + s_tmp[2][threadIdx.x] + s_tmp[3][threadIdx.x];
-    dstat_add(gln_stats + ((long long)n * 2 + threadIdx.x) * DS_NL, tot);
-  }
+  if (threadIdx.x == 0)      // this 4-channel group's gLN partial; tcn_pw_k adds the C / 4 of a sample in group order
+    gln_part[(long long)n * gridDim.x + blockIdx.x] = make_double2((s_tmp[0][0] + s_tmp[1][0]) + (s_tmp[2][0] + s_tmp[3][0]),
+                                                                   (s_tmp[0][1] + s_tmp[1][1]) + (s_tmp[2][1] + s_tmp[3][1]));
 }
 
 // y[co][t] = sum_ci W[co][ci] * (gamma[ci] * (d[ci][t] - mean_n) * rstd_n + beta[ci])  (+ residual[co][t])
@@ -164,17 +171,18 @@ constexpr int PW_KC = 16;
 // kernel is bound by the matrix pipe otherwise (3.2 GFLOP per launch at 52 TF/s).  The split of the normalised input
 // happens once per workgroup on the way into the LDS, the split of a wave's weight fragment in its registers.
 template <bool Y_OCT3, bool X6>
-__global__ __launch_bounds__(256) void tcn_pw_k(const float* d, const dstat_t* gln_stats, const float* gamma,
+__global__ __launch_bounds__(256) void tcn_pw_k(const float* d, const double2* gln_part, const float* gamma,
                                                 const float* beta, const float* wt /*[ci][co]*/,
                                                 const float* residual, float* y, long long y_bstride, int y_c0,
-                                                dstat_t* y_stats, int T, int Tp, int y_cbuf) {
+                                                double2* y_part, int nps, int T, int Tp, int y_cbuf) {
   constexpr int C = 128;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int t0 = blockIdx.x * PW_TT, n = blockIdx.y;
   const double cnt = (double)C * (double)T;
-  const double gm = dstat_read(gln_stats + (long long)n * (2 * DS_NL)) / cnt;
-  double gv = dstat_read(gln_stats + (long long)n * (2 * DS_NL) + DS_NL) / cnt - gm * gm;
+  const double2 gs = tpart_sum(gln_part + (long long)n * (C / 4), C / 4);
+  const double gm = gs.x / cnt;
+  double gv = gs.y / cnt - gm * gm;
   gv = gv > 0.0 ? gv : 0.0;
   const float mean = (float)gm;
   const float rstd = (float)(1.0 / sqrt(gv + (double)GLN_EPS));
@@ -377,29 +385,29 @@ __global__ __launch_bounds__(256) void tcn_pw_k(const float* d, const dstat_t* g
     if (Y_OCT3)     // octets 4 * wave + {0, 2} + half of this kernel's 16 octets, frame t
       store_oct_row<3>(vrow, rs_o, (unsigned)t * 16u + (unsigned)(4 * wave + half) * OP16, OP16, ok, ok);
   }
-  if (y_stats) {
+  if (y_part) {              // this 128-frame tile's partial of every output channel (tcn_dw_k adds a row's tiles in order)
     const float x1 = reduce16_halfwave(s1, lane);
     const float x2 = reduce16_halfwave(s2, lane);
     if ((lane & 16) == 0) {
       const int q = lane & 15;
       const int co = wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
-      dstat_t* o = y_stats + ((long long)n * C + co) * (2 * DS_NL);
-      dstat_add(o, (double)x1);
-      dstat_add(o + DS_NL, (double)x2);
+      y_part[((long long)n * C + co) * nps + blockIdx.x] = make_double2((double)x1, (double)x2);
     }
   }
 }
 
+int tcn_part_slots(int T) { return (T + PW_TT - 1) / PW_TT; }
+
 hipError_t launch_tcn_prepare(const float* raw, long long raw_bstride, int raw_c0, const dstat_t* raw_stats,
-                              int raw_sstride, float* x, dstat_t* x_stats, int C, int T, int Tp, int n_samples,
+                              int raw_sstride, float* x, double2* x_part, int C, int T, int Tp, int n_samples,
                               hipStream_t s, int raw_oct3) {
   hipLaunchKernelGGL(tcn_prepare_k, dim3(C, n_samples), dim3(256), 0, s, raw, raw_bstride, raw_c0, raw_stats,
-                     raw_sstride, x, x_stats, C, T, Tp, raw_oct3);
+                     raw_sstride, x, x_part, tcn_part_slots(T), C, T, Tp, raw_oct3);
   return hipGetLastError();
 }
 
-hipError_t launch_tcn_dw(const float* x, const dstat_t* x_stats, const float* wdw, const float* prelu, float* d,
-                         dstat_t* gln_stats, int C, int T, int Tp, int dilation, int n_samples, hipStream_t s) {
+hipError_t launch_tcn_dw(const float* x, const double2* x_part, int x_np, const float* wdw, const float* prelu, float* d,
+                         double2* gln_part, int C, int T, int Tp, int dilation, int n_samples, hipStream_t s) {
   if (dilation < 1 || dilation > DW_HALO) return hipErrorInvalidValue;
   if (C % 4) return hipErrorInvalidValue;
   // LDS row = the frames of one segment + two halos: a 4-second utterance (T = 1001) takes 18 KB per workgroup instead
@@ -407,26 +415,27 @@ hipError_t launch_tcn_dw(const float* x, const dstat_t* x_stats, const float* wd
   const int tq = (T + 3) & ~3;
   const int seg_f = tq < DW_SEG ? tq : DW_SEG;
   hipLaunchKernelGGL(tcn_dw_k, dim3(C / 4, n_samples), dim3(256), (size_t)4 * (seg_f + 2 * DW_HALO) * sizeof(float), s, x,
-                     x_stats, wdw, prelu, d, gln_stats, C, T, Tp, dilation, seg_f);
+                     x_part, x_np, tcn_part_slots(T), wdw, prelu, d, gln_part, C, T, Tp, dilation, seg_f);
   return hipGetLastError();
 }
 
-hipError_t launch_tcn_pw(const float* d, const dstat_t* gln_stats, const float* gamma, const float* beta,
+hipError_t launch_tcn_pw(const float* d, const double2* gln_part, const float* gamma, const float* beta,
                          const float* wpw, const float* residual, float* y, long long y_bstride, int y_c0,
-                         dstat_t* y_stats, int C, int T, int Tp, int n_samples, hipStream_t s, int y_oct3_cbuf, int x6) {
+                         double2* y_part, int C, int T, int Tp, int n_samples, hipStream_t s, int y_oct3_cbuf, int x6) {
   if (C != 128) return hipErrorInvalidValue;
   const dim3 g((T + PW_TT - 1) / PW_TT, n_samples);
+  const int nps = tcn_part_slots(T);
   if (y_oct3_cbuf) {
     if ((y_c0 & 7) || (y_oct3_cbuf & 7)) return hipErrorInvalidValue;
-    if (x6) hipLaunchKernelGGL((tcn_pw_k<true, true>), g, dim3(256), 0, s, d, gln_stats, gamma, beta, wpw, residual, y,
-                               y_bstride, y_c0, y_stats, T, Tp, y_oct3_cbuf);
-    else hipLaunchKernelGGL((tcn_pw_k<true, false>), g, dim3(256), 0, s, d, gln_stats, gamma, beta, wpw, residual, y,
-                            y_bstride, y_c0, y_stats, T, Tp, y_oct3_cbuf);
+    if (x6) hipLaunchKernelGGL((tcn_pw_k<true, true>), g, dim3(256), 0, s, d, gln_part, gamma, beta, wpw, residual, y,
+                               y_bstride, y_c0, y_part, nps, T, Tp, y_oct3_cbuf);
+    else hipLaunchKernelGGL((tcn_pw_k<true, false>), g, dim3(256), 0, s, d, gln_part, gamma, beta, wpw, residual, y,
+                            y_bstride, y_c0, y_part, nps, T, Tp, y_oct3_cbuf);
   } else {
-    if (x6) hipLaunchKernelGGL((tcn_pw_k<false, true>), g, dim3(256), 0, s, d, gln_stats, gamma, beta, wpw, residual, y,
-                               y_bstride, y_c0, y_stats, T, Tp, 0);
-    else hipLaunchKernelGGL((tcn_pw_k<false, false>), g, dim3(256), 0, s, d, gln_stats, gamma, beta, wpw, residual, y,
-                            y_bstride, y_c0, y_stats, T, Tp, 0);
+    if (x6) hipLaunchKernelGGL((tcn_pw_k<false, true>), g, dim3(256), 0, s, d, gln_part, gamma, beta, wpw, residual, y,
+                               y_bstride, y_c0, y_part, nps, T, Tp, 0);
+    else hipLaunchKernelGGL((tcn_pw_k<false, false>), g, dim3(256), 0, s, d, gln_part, gamma, beta, wpw, residual, y,
+                            y_bstride, y_c0, y_part, nps, T, Tp, 0);
   }
   return hipGetLastError();
 }
