@@ -578,7 +578,7 @@ const char* misonet_strerror(int code) {
   }
 }
 const char* misonet_last_error(void) { return g_err; }
-int misonet_version(void) { return 200; }
+int misonet_version(void) { return 300; }
 
 int misonet_net_create(const misonet_cfg* cfg, misonet_net** out) {
   if (!cfg || !out) return fail(MISONET_EINVAL, "null argument");
