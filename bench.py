@@ -390,6 +390,21 @@ def main():
             torch.cuda.synchronize()
             b1 = {"batch": 1, "ms_per_utterance": round((time.perf_counter() - t1) / 10 * 1e3, 3),
                   "note": "MISO1 runs 6 samples, MISO3 2: frame-tile columns instead of samples are dealt to the 8 XCDs"}
+            try:                                                        # the same pass replayed from a HIP graph
+                m1c, c1c = mix[:1].clone(), clean[:1].clone()
+                gr, og = enh.capture_graph(m1c, c1c)
+                for _ in range(3):
+                    gr.replay()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(10):
+                    gr.replay()
+                torch.cuda.synchronize()
+                b1["ms_per_utterance_hip_graph"] = round((time.perf_counter() - t1) / 10 * 1e3, 3)
+                b1["graph_equals_eager"] = bool(torch.equal(og, o1))
+                del gr
+            except Exception as e:                                      # a graph is an optimisation, never a requirement
+                b1["hip_graph_error"] = str(e)[:200]
             enh.enhance(mix, clean, check_nan=False, out=out)            # restore the batch workspace / result
             torch.cuda.synchronize()
         cpu = None

@@ -171,3 +171,31 @@ def test_f16x3_overflow_fails_loudly(sd1):
     assert np.isfinite(y6).all() and rel_l2(y6, y32) < 1e-4
     with pytest.raises(FloatingPointError):
         m.set_precision("f16x3")(xd)
+
+
+def test_hip_graph_capture_replays_identical_bits(sd1, sd3):
+    """The whole MISO1 x6 -> PIT -> MVDR -> MISO3 x2 pass (about 450 launches) captured into a HIP graph: a replay returns
+    the bits of the eager pass, also after new inputs were copied into the captured tensors."""
+    _need_gpu()
+    import misonet_amd as mz
+    from misonet_amd import weights as W
+    m1 = mz.MISO_1(2, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN").cuda(0)
+    m1.load_state_dict(sd1)
+    m3 = mz.MISO_3(1, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN").cuda(0)
+    m3.load_state_dict(sd3)
+    enh = mz.Enhancer(m1.eval(), m3.eval(), num_spks=2, ref_ch=0)
+    a, b = _utt_inputs(7, 64), _utt_inputs(11, 64)
+    mix = torch.from_numpy(a[0][None]).cuda()
+    clean = torch.from_numpy(a[1][None]).cuda()
+    eager_a = enh.enhance(mix, clean).clone()
+    eager_b = enh.enhance(torch.from_numpy(b[0][None]).cuda(), torch.from_numpy(b[1][None]).cuda()).clone()
+    g, out = enh.capture_graph(mix, clean)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager_a)
+    mix.copy_(torch.from_numpy(b[0][None]))
+    clean.copy_(torch.from_numpy(b[1][None]))
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager_b)
+    enh.check(1, 64)
