@@ -10,38 +10,44 @@
 // resolution of 2^-80 (anything a float32 partial of finite data holds; what is below 2^-80 is far below the eps of the
 // norms and is truncated toward zero); a non-finite or larger partial poisons the statistic, which then reads as NaN.
 #pragma once
+#if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
+#define MN_HD __host__ __device__ __forceinline__
+#else                                        // plain C++ (tests/test_det_stats.py builds the limb arithmetic with g++)
+#include <math.h>
+#define MN_HD inline
+#endif
 
 namespace mn {
 
 typedef unsigned long long dstat_t;
 constexpr int DS_NL = 5;                     // limbs per statistic
+constexpr long long DS_POISON = 1ll << 62;   // added to the top limb by a non-finite / out-of-range partial
 
-// p: the DS_NL limbs of one statistic (zeroed at the start of a forward)
-__device__ __forceinline__ void dstat_add(dstat_t* p, double v) {
-  if (!(fabs(v) < 0x1p118)) {                // inf, NaN or out of range: poison (ds_read returns NaN)
-    atomicAdd(p + (DS_NL - 1), 1ull << 62);
-    return;
-  }
+// v -> q[0 .. DS_NL-1] with v = sum q[i] 2^(40 i - 80) + (a remainder below 2^-80, truncated toward zero); |q[i]| < 2^40.
+// Returns false (q untouched) when v is inf, NaN or >= 2^118 in magnitude.
+MN_HD bool dstat_split(double v, long long (&q)[DS_NL]) {
+  if (!(fabs(v) < 0x1p118)) return false;
   v *= 0x1p80;                               // exact: |v| < 2^198
   const double up[DS_NL] = {1.0, 0x1p40, 0x1p80, 0x1p120, 0x1p160};
   const double dn[DS_NL] = {1.0, 0x1p-40, 0x1p-80, 0x1p-120, 0x1p-160};
 #pragma unroll
   for (int i = DS_NL - 1; i >= 0; --i) {
-    const double q = trunc(v * dn[i]);       // |q| < 2^40 (top limb: < 2^38); exact
-    v = fma(-q, up[i], v);                   // exact: removes the leading bits
-    // q is an integer below 2^40 in magnitude: its two's-complement value sits in the low mantissa bits of q + 1.5 * 2^52
-    // (2 instructions; a double -> int64 conversion is emulated with ~20)
-    const long long qi = __double_as_longlong(q + 0x1.8p52) - 0x4338000000000000ll;
-    if (qi) atomicAdd(p + i, (unsigned long long)qi);
+    const double t = trunc(v * dn[i]);       // |t| < 2^40 (top limb: < 2^38); exact
+    v = fma(-t, up[i], v);                   // exact: removes the leading bits
+    // t is an integer below 2^40 in magnitude: its two's-complement value sits in the low mantissa bits of t + 1.5 * 2^52
+    // (2 instructions; a double -> int64 conversion is emulated with ~20 on the GPU)
+    q[i] = __builtin_bit_cast(long long, t + 0x1.8p52) - 0x4338000000000000ll;
   }
+  return true;
 }
 
-__device__ __forceinline__ double dstat_read(const dstat_t* p) {
+// the value of the limbs L (two's complement, un-normalised), NaN when poisoned
+MN_HD double dstat_combine(const long long (&Lin)[DS_NL]) {
   long long L[DS_NL];
 #pragma unroll
-  for (int i = 0; i < DS_NL; ++i) L[i] = (long long)p[i];
-  if (L[DS_NL - 1] >= (1ll << 61)) return __longlong_as_double(0x7ff8000000000000ll);
+  for (int i = 0; i < DS_NL; ++i) L[i] = Lin[i];
+  if (L[DS_NL - 1] >= (1ll << 61)) return __builtin_bit_cast(double, 0x7ff8000000000000ll);
   // carry-normalise limbs 0 .. DS_NL-2 into [0, 2^40): the value is then  L[4] 2^160 + ... + L[0]  with one sign
 #pragma unroll
   for (int i = 0; i < DS_NL - 1; ++i) {
@@ -55,10 +61,25 @@ __device__ __forceinline__ double dstat_read(const dstat_t* p) {
   return s * 0x1p-80;
 }
 
-// statistic `which` (0: sum, 1: sum of squares) of entity e in an array [entities][2][DS_NL]
-__device__ __forceinline__ dstat_t* dstat_at(dstat_t* base, long long e, int which) { return base + (e * 2 + which) * DS_NL; }
-__device__ __forceinline__ const dstat_t* dstat_at(const dstat_t* base, long long e, int which) {
-  return base + (e * 2 + which) * DS_NL;
+#if defined(__HIPCC__)
+// p: the DS_NL limbs of one statistic (zeroed at the start of a forward)
+__device__ __forceinline__ void dstat_add(dstat_t* p, double v) {
+  long long q[DS_NL];
+  if (!dstat_split(v, q)) {                  // inf, NaN or out of range: poison (dstat_read returns NaN)
+    atomicAdd(p + (DS_NL - 1), (unsigned long long)DS_POISON);
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < DS_NL; ++i)
+    if (q[i]) atomicAdd(p + i, (unsigned long long)q[i]);
 }
+
+__device__ __forceinline__ double dstat_read(const dstat_t* p) {
+  long long L[DS_NL];
+#pragma unroll
+  for (int i = 0; i < DS_NL; ++i) L[i] = (long long)p[i];
+  return dstat_combine(L);
+}
+#endif
 
 }  // namespace mn
