@@ -69,7 +69,10 @@ int misonet_net_commit(misonet_net* net);
  *               against the reference as mode 0 (2.3e-6 per forward) at 1.65 x its speed;
  *   4 "f16x3"   operands rounded to two fp16 pieces (22 bits; the weights carry a per-layer power-of-two scale), three
  *               terms, float32 accumulation: measured at or below mode 0's error on well-conditioned data (1.9e-6 per
- *               forward) at mode 2's cost, but 2.4 x mode 0 under |mean| >> std and limited to fp16's range;
+ *               forward).  The raw first-layer output (un-normalised: its scale follows the input) stays in mode 3's exact
+ *               layout and the dense block that reads it runs in mode 3's arithmetic; every other tensor is the output of
+ *               layers with instance-normalised inputs.  Input range: the un-normalised output of that first dense block
+ *               must stay inside fp16 (inputs up to ~1e4 x a unit-variance STFT; beyond: MISONET_ENAN, never silent);
  *   2 "bf16x3"  every product as w_hi*x_hi + w_hi*x_lo + w_lo*x_hi with 16-bit operands (2.4e-5 per forward, not
  *               fp32-faithful; loses |mean|/std of its accuracy when a layer's input has |mean| >> std), same dataflow
  *               with two parts -- the fastest mode;

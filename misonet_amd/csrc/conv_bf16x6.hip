@@ -249,7 +249,10 @@ __device__ __forceinline__ void x6_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int MODE, int FTR>
+// OUT16: the output goes to a buffer of the f16x3 mode (two fp16 pieces per value): the f16x3 networks run the layers that
+// read UN-NORMALISED data -- the first dense block, whose input is the raw first-layer output (model.py:44, 401-406) -- in
+// this exact arithmetic (net.hip, buf_oct); its last conv hands over to the fp16 dataflow.
+template <int MODE, int FTR, bool OUT16 = false>
 __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int nslots) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (the LDS-DMA builtin has no host form)
   constexpr int COP = 32;
@@ -570,9 +573,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
       }
       if constexpr (RM) {
         if (!(a.dbg & 4)) conv_epilogue_rm(a, acc[0], n, f0, t0 + 32 * wave, lane);
-      } else if (!(a.dbg & 4))
-        conv_epilogue_rows_nb<3>(a, acc, n, cg, f0, t0 + 32 * wave, lane, s_red + (ti & 1) * (4 * COP * 2) + wave * (COP * 2), FTR,
-                                 a.act ? s_ctr + (ti & 3) * COP : nullptr);
+      } else if (!(a.dbg & 4)) {
+        if constexpr (OUT16)
+          conv_epilogue_rows_nb<2, true>(a, acc, n, cg, f0, t0 + 32 * wave, lane, s_red + (ti & 1) * (4 * COP * 2) + wave * (COP * 2),
+                                         FTR, a.act ? s_ctr + (ti & 3) * COP : nullptr);
+        else
+          conv_epilogue_rows_nb<3>(a, acc, n, cg, f0, t0 + 32 * wave, lane, s_red + (ti & 1) * (4 * COP * 2) + wave * (COP * 2), FTR,
+                                   a.act ? s_ctr + (ti & 3) * COP : nullptr);
+      }
       ++ti;
       k += (unsigned)nslots;
       if (k >= nk) break;
@@ -674,9 +682,9 @@ static size_t x6_lds_bytes(int NR, int ftr) {
   return (size_t)(ns * (3 * NR * X6_TW + X6_WU)) * 16 + (size_t)(ns * 3 * ftr * 32 + 2 * 4 * 32 * 2 + 4 * 32) * sizeof(float);
 }
 
-template <int MODE, int FTR>
+template <int MODE, int FTR, bool OUT16 = false>
 static hipError_t x6_set_attr() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6<MODE, FTR>),
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6<MODE, FTR, OUT16>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -687,6 +695,8 @@ hipError_t conv_bf16x6_init() {
   if ((e = x6_set_attr<1, 4>()) != hipSuccess) return e;
   if ((e = x6_set_attr<2, 8>()) != hipSuccess) return e;
   if ((e = x6_set_attr<3, 8>()) != hipSuccess) return e;
+  if ((e = x6_set_attr<0, 8, true>()) != hipSuccess) return e;
+  if ((e = x6_set_attr<0, 4, true>()) != hipSuccess) return e;
   return x6_set_attr<2, 4>();
 }
 
@@ -712,7 +722,8 @@ hipError_t launch_conv_wprep6(const ConvArgs& a, const float* wf, int n_samples,
 hipError_t launch_conv_bf16x6(const ConvArgs& a_in, int n_samples, hipStream_t s) {
   ConvArgs a = a_in;
   if (a.in_oct != 3 || !a.wps || a.cop != 32 || (a.Cin & 7) || (a.in_c0 & 7) || (a.in_sstride & 7)) return hipErrorInvalidValue;
-  if (a.out_oct && (a.out_oct != 3 || (a.Cout & 7) || (a.out_c0 & 7) || (a.out_sstride & 7))) return hipErrorInvalidValue;
+  if (a.out_oct && ((a.out_oct != 3 && a.out_oct != 4) || (a.Cout & 7) || (a.out_c0 & 7) || (a.out_sstride & 7))) return hipErrorInvalidValue;
+  if (a.out_oct == 4 && (a.tr2 || a.sf != 1 || a.descale != 1.f)) return hipErrorInvalidValue;   // stride-1 layers only (see OUT16)
   // measurement hooks: read once per process (thread-safe function-local statics)
   static const int dbg = [] { const char* e = getenv("MISONET_WS_DEBUG"); return e ? atoi(e) : 0; }();
   a.dbg = dbg;
@@ -751,7 +762,9 @@ hipError_t launch_conv_bf16x6(const ConvArgs& a_in, int n_samples, hipStream_t s
     if (cap > 0 && nslots > cap) nslots = cap;
   }
   const dim3 pgrid((unsigned)(8 * nslots), 1, 1);
-  if (rows_in_m) hipLaunchKernelGGL((conv3x3_bf16x6<3, 8>), pgrid, dim3(512), x6_lds_bytes(10, 8), s, a, nslots);
+  if (a.out_oct == 4 && ftr == 8) hipLaunchKernelGGL((conv3x3_bf16x6<0, 8, true>), pgrid, dim3(512), x6_lds_bytes(10, 8), s, a, nslots);
+  else if (a.out_oct == 4) hipLaunchKernelGGL((conv3x3_bf16x6<0, 4, true>), pgrid, dim3(512), x6_lds_bytes(6, 4), s, a, nslots);
+  else if (rows_in_m) hipLaunchKernelGGL((conv3x3_bf16x6<3, 8>), pgrid, dim3(512), x6_lds_bytes(10, 8), s, a, nslots);
   else if (mode == 0 && ftr == 8) hipLaunchKernelGGL((conv3x3_bf16x6<0, 8>), pgrid, dim3(512), x6_lds_bytes(10, 8), s, a, nslots);
   else if (mode == 0) hipLaunchKernelGGL((conv3x3_bf16x6<0, 4>), pgrid, dim3(512), x6_lds_bytes(6, 4), s, a, nslots);
   else if (mode == 1) hipLaunchKernelGGL((conv3x3_bf16x6<1, 4>), pgrid, dim3(512), x6_lds_bytes(9, 4), s, a, nslots);

@@ -306,6 +306,10 @@ static inline int buf_oct(const misonet_net* n, int b) {
   // bf16x6 also keeps the F <= 3 bottleneck buffers D0 / D1 in its layout (the TCN reads / writes it at its two ends), so
   // that encoder 6 and decoders 0-1 run on the persistent kernel instead of the one-row-per-wave f32 kernel
   if (n->precision == 3 && (b == B_D0 || b == B_D1)) return 3;
+  // f16x3: the first dense-block buffer holds the RAW first-layer output (un-normalised, its scale follows the input), which
+  // two fp16 pieces cannot carry for every input scale nor to 24 bits: it stays in the exact three-bf16 layout and the
+  // layers that read it run on the bf16x6 kernel (its last conv writes the fp16 layout of the next buffer)
+  if (n->precision == 4 && b == B_E0) return 3;
   return o ? (n->precision == 3 ? 3 : (n->precision == 4 ? 4 : 1)) : 0;
 }
 // floats one sample occupies in buffer b (an oct3 buffer holds 1.5 floats per element; C is a multiple of 8 there)

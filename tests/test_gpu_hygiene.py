@@ -199,3 +199,30 @@ def test_hip_graph_capture_replays_identical_bits(sd1, sd3):
     torch.cuda.synchronize()
     assert torch.equal(out, eager_b)
     enh.check(1, 64)
+
+
+@pytest.mark.parametrize("scale", [1e-4, 1e-2, 1e3])
+def test_f16x3_input_scale_range(sd1, scale):
+    """f16x3 keeps the RAW first-layer output (whose scale follows the input) in the exact three-bf16 layout and runs the
+    dense block that reads it in the bf16x6 arithmetic, so low-level and loud inputs are as accurate as in the exact modes;
+    the ground truth is the float64 oracle (at small scales every float32 implementation, the reference included, loses
+    accuracy to the cancellation against the first conv's bias).  Beyond ~1e4 x unit scale the un-normalised output of
+    that block leaves fp16's range and the forward fails loudly (test_f16x3_overflow_fails_loudly)."""
+    _need_gpu()
+    import misonet_amd as mz
+    from misonet_amd import weights as W
+    from oracle import miso_oracle
+    from conftest import mag_parity
+    m = mz.MISO_1(2, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN").cuda(0)
+    m.load_state_dict(sd1)
+    m.eval()
+    r = np.random.default_rng(8)
+    x = (scale * (r.standard_normal((1, 6, 64, 129)) + 1j * r.standard_normal((1, 6, 64, 129)))).astype(np.complex64)
+    with miso_oracle.precision(torch.float64):
+        truth = miso_oracle.miso1_forward(torch.from_numpy(x).to(torch.complex128), sd1).numpy()
+    err = {}
+    for mode in ("f32", "bf16x6", "f16x3"):
+        err[mode] = mag_parity(m.set_precision(mode)(torch.from_numpy(x).cuda()).cpu().numpy(), truth)[0]
+    print(f"[scale {scale:g}] " + "  ".join(f"{k} {v:.2e}" for k, v in err.items()))
+    assert err["f16x3"] <= 2.0 * err["f32"] + 2e-6, err
+    assert err["bf16x6"] <= 2.0 * err["f32"] + 2e-6, err
