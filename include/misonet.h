@@ -99,6 +99,12 @@ int misonet_net_check(misonet_net* net, const void* ws_dev, misonet_stream strea
  * instead of 0.55.  keep != 0 gives every buffer its own memory so that every tap below stays readable after a forward;
  * the workspace size changes (ask misonet_net_workspace_bytes again). */
 int misonet_net_keep_activations(misonet_net* net, int keep);
+/* diagnostic (host only, no GPU): the memory plan of ONE sample's activation block for n_frames frames -- per buffer its
+ * byte offset inside the block, its size and the first / last step of a forward at which it is alive (0 input written,
+ * 1 + b encoder b, 8 TCN, 9 + i decoder i, 16 results read).  Returns the number of buffers written (<= max_buffers) or
+ * a negative error.  tests/test_lib_abi.py checks that buffers alive at the same step never overlap. */
+int misonet_net_buffer_plan(const misonet_net* net, int n_frames, int max_buffers, long long* offset_bytes,
+                            long long* size_bytes, int* first_step, int* last_step);
 /* test/diagnostic taps: copy an intermediate activation of the LAST forward (still in ws_dev) out as float32
  * [B, C, T, F] in the reference's layout and normalisation.  Names: enc0_conv, enc0..enc6, tcn_out, dec0..dec6.
  * Needs misonet_net_keep_activations(net, 1) BEFORE that forward (MISONET_ESTATE otherwise), except dec6 (the output). */

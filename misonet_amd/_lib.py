@@ -41,6 +41,8 @@ SIGNATURES = {
     "misonet_net_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "misonet_net_get_precision": (C.c_int, [C.c_void_p]),
     "misonet_net_keep_activations": (C.c_int, [C.c_void_p, C.c_int]),
+    "misonet_net_buffer_plan": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
+                                          C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "misonet_net_workspace_bytes": (C.c_longlong, [C.c_void_p, C.c_int, C.c_int]),
     "misonet_net_forward": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),

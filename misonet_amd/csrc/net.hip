@@ -783,6 +783,20 @@ int misonet_net_set_precision(misonet_net* n, int mode) {
 }
 int misonet_net_get_precision(const misonet_net* n) { return n ? n->precision : -1; }
 
+int misonet_net_buffer_plan(const misonet_net* n, int n_frames, int max_buffers, long long* offset_bytes,
+                            long long* size_bytes, int* first_step, int* last_step) {
+  if (!n || n_frames <= 0 || !offset_bytes || !size_bytes || !first_step || !last_step) return fail(MISONET_EINVAL, "null argument");
+  const Layout L = make_layout(n, 1, n_frames);
+  int k = 0;
+  for (int b = 0; b < B_TXA && k < max_buffers; ++b, ++k) {
+    offset_bytes[k] = L.data_off[b] * 4;
+    size_bytes[k] = buf_floats(n, L.Tp, b) * 4;
+    buf_lifetime(b, first_step[k], last_step[k]);
+    if (n->keep_taps) { first_step[k] = 0; last_step[k] = 16; }
+  }
+  return k;
+}
+
 int misonet_net_keep_activations(misonet_net* n, int keep) {
   if (!n) return fail(MISONET_EINVAL, "null argument");
   n->keep_taps = keep != 0;

@@ -157,3 +157,37 @@ def test_reference_checkpoint_format_roundtrip(tmp_path):
     back = m.state_dict()
     for k in sd:
         assert torch.equal(back[k], sd[k])
+
+
+@pytest.mark.parametrize("prec", [0, 2, 3, 4])
+def test_workspace_plan_never_overlaps_live_buffers(prec):
+    """The lifetime-shared activation arena: for every arithmetic mode and several utterance lengths, two
+    buffers that are alive at the same step of a forward never share a byte, the skip buffers D[i] live from their encoder
+    to their decoder (reference model.py:84-99), and keep_activations gives every buffer its own memory."""
+    L, rc, h = _make()
+    lib = L.lib()
+    assert rc == 0 and lib.misonet_net_set_precision(h, prec) == 0
+    for keep in (0, 1):
+        assert lib.misonet_net_keep_activations(h, keep) == 0
+        for T in (5, 501, 1001, 2500):
+            n = 32
+            off = (C.c_longlong * n)(); size = (C.c_longlong * n)(); t0 = (C.c_int * n)(); t1 = (C.c_int * n)()
+            k = lib.misonet_net_buffer_plan(h, T, n, off, size, t0, t1)
+            assert k == 19                                     # IN, E0-E4, D0-D6, X2-X6, OUT
+            rects = [(off[i], off[i] + size[i], t0[i], t1[i]) for i in range(k)]
+            assert all(a % 256 == 0 and b > a and 0 <= s <= e <= 16 for a, b, s, e in rects)
+            for i in range(k):
+                for j in range(i + 1, k):
+                    a0, a1, s0, e0 = rects[i]; b0, b1, s1, e1 = rects[j]
+                    alive_together = s0 <= e1 and s1 <= e0
+                    if alive_together:
+                        assert a1 <= b0 or b1 <= a0, (prec, keep, T, i, j, rects[i], rects[j])
+            if keep:
+                assert all(s == 0 and e == 16 for _, _, s, e in rects)
+            else:
+                # D[i] (plan index 6 + i): alive from encoder 6 - i (step 7 - i) to decoder i (step 9 + i)
+                for i in range(7):
+                    assert (rects[6 + i][2], rects[6 + i][3]) == (7 - i, 9 + i)
+                block = max(b for _, b, _, _ in rects)
+                assert block < sum(b - a for a, b, _, _ in rects)      # something is shared
+    lib.misonet_net_destroy(h)
