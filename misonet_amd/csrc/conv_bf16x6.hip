@@ -252,7 +252,9 @@ __device__ __forceinline__ void x6_wait_vm() {
 // OUT16: the output goes to a buffer of the f16x3 mode (two fp16 pieces per value): the f16x3 networks run the layers that
 // read UN-NORMALISED data -- the first dense block, whose input is the raw first-layer output (model.py:44, 401-406) -- in
 // this exact arithmetic (net.hip, buf_oct); its last conv hands over to the fp16 dataflow.
-template <int MODE, int FTR, bool OUT16 = false>
+// NQ = 3: an instantiation for layers of <= 24 output channels (the F = 127 dense blocks: 29 % of the conv time): the tile
+// epilogue skips the fourth register quad of every row (channels 24-31 of the 32-row MFMA tile are padding).
+template <int MODE, int FTR, bool OUT16 = false, int NQ = 4>
 __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int nslots) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (the LDS-DMA builtin has no host form)
   constexpr int COP = 32;
@@ -578,8 +580,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
           conv_epilogue_rows_nb<2, true>(a, acc, n, cg, f0, t0 + 32 * wave, lane, s_red + (ti & 1) * (4 * COP * 2) + wave * (COP * 2),
                                          FTR, a.act ? s_ctr + (ti & 3) * COP : nullptr);
         else
-          conv_epilogue_rows_nb<3>(a, acc, n, cg, f0, t0 + 32 * wave, lane, s_red + (ti & 1) * (4 * COP * 2) + wave * (COP * 2), FTR,
-                                   a.act ? s_ctr + (ti & 3) * COP : nullptr);
+          conv_epilogue_rows_nb<3, false, NQ>(a, acc, n, cg, f0, t0 + 32 * wave, lane,
+                                              s_red + (ti & 1) * (4 * COP * 2) + wave * (COP * 2), FTR,
+                                              a.act ? s_ctr + (ti & 3) * COP : nullptr);
       }
       ++ti;
       k += (unsigned)nslots;
@@ -682,9 +685,9 @@ static size_t x6_lds_bytes(int NR, int ftr) {
   return (size_t)(ns * (3 * NR * X6_TW + X6_WU)) * 16 + (size_t)(ns * 3 * ftr * 32 + 2 * 4 * 32 * 2 + 4 * 32) * sizeof(float);
 }
 
-template <int MODE, int FTR, bool OUT16 = false>
+template <int MODE, int FTR, bool OUT16 = false, int NQ = 4>
 static hipError_t x6_set_attr() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6<MODE, FTR, OUT16>),
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6<MODE, FTR, OUT16, NQ>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -696,6 +699,7 @@ hipError_t conv_bf16x6_init() {
   if ((e = x6_set_attr<2, 8>()) != hipSuccess) return e;
   if ((e = x6_set_attr<3, 8>()) != hipSuccess) return e;
   if ((e = x6_set_attr<0, 8, true>()) != hipSuccess) return e;
+  if ((e = x6_set_attr<0, 8, false, 3>()) != hipSuccess) return e;
   if ((e = x6_set_attr<0, 4, true>()) != hipSuccess) return e;
   return x6_set_attr<2, 4>();
 }
@@ -762,9 +766,13 @@ hipError_t launch_conv_bf16x6(const ConvArgs& a_in, int n_samples, hipStream_t s
     if (cap > 0 && nslots > cap) nslots = cap;
   }
   const dim3 pgrid((unsigned)(8 * nslots), 1, 1);
+  // <= 24 output channels in one group: the epilogue variant that skips the padded register quad (MISONET_X6_Q3=0: A/B runs)
+  static const int q3_env = [] { const char* e = getenv("MISONET_X6_Q3"); return e ? atoi(e) : 1; }();
+  const bool q3 = q3_env && a.ncg == 1 && a.Cout <= 24 && a.out_oct == 3;
   if (a.out_oct == 4 && ftr == 8) hipLaunchKernelGGL((conv3x3_bf16x6<0, 8, true>), pgrid, dim3(512), x6_lds_bytes(10, 8), s, a, nslots);
   else if (a.out_oct == 4) hipLaunchKernelGGL((conv3x3_bf16x6<0, 4, true>), pgrid, dim3(512), x6_lds_bytes(6, 4), s, a, nslots);
   else if (rows_in_m) hipLaunchKernelGGL((conv3x3_bf16x6<3, 8>), pgrid, dim3(512), x6_lds_bytes(10, 8), s, a, nslots);
+  else if (mode == 0 && ftr == 8 && q3) hipLaunchKernelGGL((conv3x3_bf16x6<0, 8, false, 3>), pgrid, dim3(512), x6_lds_bytes(10, 8), s, a, nslots);
   else if (mode == 0 && ftr == 8) hipLaunchKernelGGL((conv3x3_bf16x6<0, 8>), pgrid, dim3(512), x6_lds_bytes(10, 8), s, a, nslots);
   else if (mode == 0) hipLaunchKernelGGL((conv3x3_bf16x6<0, 4>), pgrid, dim3(512), x6_lds_bytes(6, 4), s, a, nslots);
   else if (mode == 1) hipLaunchKernelGGL((conv3x3_bf16x6<1, 4>), pgrid, dim3(512), x6_lds_bytes(9, 4), s, a, nslots);

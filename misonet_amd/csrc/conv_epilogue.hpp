@@ -184,13 +184,18 @@ __device__ __forceinline__ void split3_quad_t(float x0, float x1, float x2, floa
 // -> NP bf16 parts in the oct layout: part p of octet pair k is one 16-byte store per lane (lanes 0-31 store octet 2k,
 // lanes 32-63 octet 2k + 1, after a half-wave swap).  rs[p]: descriptor of part p; vo: byte offset of (row, frame) in
 // the plane of octet (group base + half); ok0 / ok1: this lane's octet of pair 0 / 1 exists and its frame is valid.
-template <int NP, bool F16 = false>
+// NQ: register quads (= octets of this half-wave pair) that can hold channels: 3 for a group of <= 24 output channels, whose
+// fourth octet is not split (it does not exist: its lanes' stores fall outside num_records).
+template <int NP, bool F16 = false, int NQ = 4>
 __device__ __forceinline__ void store_oct_row(const float (&v)[16], const __amdgpu_buffer_rsrc_t (&rs)[3], unsigned vo,
                                               unsigned P16, bool ok0, bool ok1) {
   unsigned P[3][4][2];
 #pragma unroll
   for (int o = 0; o < 4; ++o) {
-    if (NP == 3) {
+    if (o >= NQ) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) { P[p][o][0] = 0u; P[p][o][1] = 0u; }
+    } else if (NP == 3) {
       split3_quad_t(v[4 * o + 0], v[4 * o + 1], v[4 * o + 2], v[4 * o + 3], P[0][o], P[1][o], P[2][o]);
     } else {
       split_pair_x<F16>(v[4 * o + 0], v[4 * o + 1], P[0][o][0], P[1][o][0]);
@@ -589,7 +594,7 @@ __device__ __forceinline__ void conv_acc_init_rows(f32x16_t (&acc)[NROW], int tw
 
 // s_ctr (optional): 16 floats per half-wave in accumulator order, the centre c = ELU(bias) per channel: the row is stored
 // as x - c and the statistics are those of the stored values (conv_epilogue_impl's CENTRE note).
-template <bool MASKED, bool ACT, int NP, bool F16 = false, int NROW = 4>
+template <bool MASKED, bool ACT, int NP, bool F16 = false, int NROW = 4, int NQ = 4>
 __device__ __forceinline__ void conv_epilogue_rows_nb_impl(const ConvArgs& a, f32x16_t (&acc)[NROW], int cg, int f0, int tw,
                                                            int lane, const __amdgpu_buffer_rsrc_t (&rs)[3],
                                                            f32x2_e (&s1)[8], f32x2_e (&s2)[8], int rows,
@@ -624,11 +629,13 @@ __device__ __forceinline__ void conv_epilogue_rows_nb_impl(const ConvArgs& a, f3
     const float mf = ok ? 1.f : 0.f;
     const f32x2_e m2 = {mf, mf};
     float v[16];
+#pragma unroll
+    for (int i = 4 * NQ; i < 16; ++i) v[i] = 0.f;      // NQ < 4: channels that do not exist (<= 24-channel groups) cost nothing
     // two element pairs (A, B) per step, their instructions interleaved: on gfx950 a v_pk_*_f32 or v_exp_f32 result
     // needs one independent instruction before its consumer, and a dependent chain written pair by pair is padded with an
     // s_nop at every link (~30 wasted issue slots per 16-value row; the tile epilogue is VALU-issue bound)
 #pragma unroll
-    for (int i4 = 0; i4 < 4; ++i4) {
+    for (int i4 = 0; i4 < NQ; ++i4) {
       f32x2_e xa = {acc[r][4 * i4], acc[r][4 * i4 + 1]};
       f32x2_e xb = {acc[r][4 * i4 + 2], acc[r][4 * i4 + 3]};
       if (F16) { xa = xa * f32x2_e{a.descale, a.descale}; xb = xb * f32x2_e{a.descale, a.descale}; }
@@ -662,8 +669,8 @@ __device__ __forceinline__ void conv_epilogue_rows_nb_impl(const ConvArgs& a, f3
       const unsigned vo = (unsigned)(f * Tp + t) * 16u + (unsigned)half * P16 + (unsigned)(cbase >> 3) * P16;
       // un-masked tiles: no predicates at all -- octets past Cout lie outside num_records of the part descriptors and
       // are dropped by the hardware (the masked path still needs the per-lane frame / row test)
-      if (MASKED) store_oct_row<NP, F16>(v, rs, vo, P16, ok && oct_ok0, ok && oct_ok1);
-      else store_oct_row<NP, F16>(v, rs, vo, P16, true, true);
+      if (MASKED) store_oct_row<NP, F16, NQ>(v, rs, vo, P16, ok && oct_ok0, ok && oct_ok1);
+      else store_oct_row<NP, F16, NQ>(v, rs, vo, P16, true, true);
     } else {
       const unsigned vo = ok ? ((unsigned)(f * Tp + t) * 4u + (unsigned)(4 * half) * P4) : 0x80000000u;
 #pragma unroll
@@ -676,7 +683,7 @@ __device__ __forceinline__ void conv_epilogue_rows_nb_impl(const ConvArgs& a, f3
 }
 
 // rows: output rows of the tile (4, or 2 for the stride-2 layers of the bf16x3 kernel); NP: bf16 parts of an oct output
-template <int NP = 2, bool F16 = false, int NROW>
+template <int NP = 2, bool F16 = false, int NQ = 4, int NROW>
 __device__ __forceinline__ void conv_epilogue_rows_nb(const ConvArgs& a, f32x16_t (&acc)[NROW], int n, int cg, int f0, int tw,
                                                       int lane, float* s_red, int rows = NROW, const float* s_ctr = nullptr) {
   const int half = lane >> 5;
@@ -704,10 +711,10 @@ __device__ __forceinline__ void conv_epilogue_rows_nb(const ConvArgs& a, f32x16_
   }
 
   if (a.act) {
-    if (fast) conv_epilogue_rows_nb_impl<false, true, NP, F16, NROW>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows, s_ctr);
-    else conv_epilogue_rows_nb_impl<true, true, NP, F16, NROW>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows, s_ctr);
+    if (fast) conv_epilogue_rows_nb_impl<false, true, NP, F16, NROW, NQ>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows, s_ctr);
+    else conv_epilogue_rows_nb_impl<true, true, NP, F16, NROW, NQ>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows, s_ctr);
   } else {
-    conv_epilogue_rows_nb_impl<true, false, NP, F16, NROW>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows);
+    conv_epilogue_rows_nb_impl<true, false, NP, F16, NROW, NQ>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows);
   }
 
   if (a.act && !(a.dbg & 16)) {
