@@ -118,6 +118,8 @@ struct Layout {
   long long data_off[NBUF];      // floats: activation buffers (b < B_TXA): offset INSIDE a sample's block of the arena (sample n
                                  // at + n * sample_stride); TCN buffers: offset of the whole [N][128][Tp] block
   long long sample_stride;       // floats per sample of the activation arena
+  long long in_ext_off = -1;     // >= 0: the network input lives OUTSIDE this workspace, at ws + in_ext_off bytes, with
+  long long in_ext_bstride = 0;  // in_ext_bstride floats between samples (the pipeline's MISO3 input, see pipe_layout)
   long long stats_off[NBUF];     // 8-byte words (dstat_t): [N][C][2][DS_NL] per buffer
   long long tcn_xs, tcn_ps, tcn_gln;   // words (2 per double2 partial): [15][N*128*slots], [14][N*128*slots], [28][N*32]
   long long stats_doubles;       // words in all
@@ -320,6 +322,7 @@ static inline long long buf_floats(const misonet_net* n, int Tp, int b) {
 // floats between consecutive samples of buffer b: the activation arena is SAMPLE-major (all buffers of a sample in one
 // block, so that buffers whose lifetimes do not overlap can share memory: make_layout), the TCN buffers are buffer-major
 static inline long long bstride(const misonet_net* n, const Layout& L, int b) {
+  if (b == B_IN && L.in_ext_off >= 0) return L.in_ext_bstride;
   return b >= B_TXA ? buf_floats(n, L.Tp, b) : L.sample_stride;
 }
 
@@ -336,7 +339,7 @@ static void buf_lifetime(int b, int& t0, int& t1) {
   else { t0 = 15; t1 = 16; }                                     // B_OUT
 }
 
-static Layout make_layout(const misonet_net* n, int N, int T) {
+static Layout make_layout(const misonet_net* n, int N, int T, bool ext_in = false) {
   Layout L;
   L.N = N; L.T = T; L.Tp = frames_pitch(T);
   long long so = 0;
@@ -356,7 +359,9 @@ static Layout make_layout(const misonet_net* n, int N, int T) {
     struct Rect { int b, t0, t1; long long off, size; };
     std::vector<Rect> placed;
     std::vector<int> order;
-    for (int b = 0; b < B_TXA; ++b) order.push_back(b);
+    for (int b = 0; b < B_TXA; ++b)
+      if (!(ext_in && b == B_IN)) order.push_back(b);          // an external input takes no room in the arena
+    L.data_off[B_IN] = 0;
     std::sort(order.begin(), order.end(), [&](int x, int y) {
       const long long sx = buf_floats(n, L.Tp, x), sy = buf_floats(n, L.Tp, y);
       return sx != sy ? sx > sy : x < y;
@@ -409,6 +414,7 @@ static Layout make_layout(const misonet_net* n, int N, int T) {
 }
 
 static inline float* buf_ptr(const Layout& L, void* ws, int b) {
+  if (b == B_IN && L.in_ext_off >= 0) return reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + L.in_ext_off);
   return reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + L.data_base) + L.data_off[b];
 }
 static inline dstat_t* stats_base(void* ws) { return reinterpret_cast<dstat_t*>(reinterpret_cast<char*>(ws) + 256); }
@@ -977,8 +983,11 @@ struct PipeLayout {
 
 static PipeLayout pipe_layout(const misonet_pipeline* p, int B, int T) {
   PipeLayout P;
+  // MISO3 runs in MISO1's workspace (MISO1 is finished when MISO3 starts; what the steps in between read of it -- its input
+  // and output planes -- is consumed before the MISO3 forward writes anything): only the MISO3 INPUT, which those steps
+  // build while MISO1's planes are still being read, has its own memory
   P.L1 = make_layout(p->n1, B * p->M, T);
-  P.L3 = make_layout(p->n3, B * p->S, T);
+  P.L3 = make_layout(p->n3, B * p->S, T, true);
   const int F = p->n1->cfg.n_freq, Tp = P.L1.Tp;
   long long o = 256;                                   // [0]: nan flag
   // PIT distances [B*M + B][S][S] followed by their per-bin partials [B*M + B][F][S][S] (mvdr.hip pit_dist_k)
@@ -987,8 +996,12 @@ static PipeLayout pipe_layout(const misonet_pipeline* p, int B, int T) {
   P.off_mvdr = o;  o += align_up(mvdr_ws_bytes(B, p->S, F, p->M), 256);
   P.clean_bstride = (long long)2 * p->S * F * Tp;
   P.off_clean = o; o += align_up(P.clean_bstride * B * 4, 256);
-  P.off_ws1 = o;   o += align_up(P.L1.total_bytes, 256);
-  P.off_ws3 = o;   o += align_up(P.L3.total_bytes, 256);
+  P.L3.in_ext_bstride = (long long)p->n3->cfg.in_ch * F * Tp;
+  const long long in3_bytes = align_up(P.L3.in_ext_bstride * B * p->S * 4, 256);
+  P.off_ws1 = o;   o += align_up(std::max(P.L1.total_bytes, P.L3.total_bytes), 256);
+  P.off_ws3 = P.off_ws1;
+  P.L3.in_ext_off = o - P.off_ws3;                     // relative to the (shared) workspace base
+  o += in3_bytes;
   P.total = o;
   return P;
 }
@@ -1094,7 +1107,11 @@ static int pipeline_run_impl(misonet_pipeline* p, const void* mix, const void* c
       ProfScope ps(s, PK_MVDR);
       HIPCHK(launch_mvdr(a, co, base + P.off_mvdr, s));
     }
-    // 6. MISO3 per speaker (tester.py:1231-1244)
+    // (the aligned MISO1 estimates leave the shared workspace before MISO3 overwrites it)
+    if (miso1_out)
+      HIPCHK(launch_unpack_ex(out1, out1_bs, Tp, S, T, F, 0, S, 1, M, sel_final, reinterpret_cast<float2*>(miso1_out),
+                              B * S * M, reinterpret_cast<int*>(base), s));
+    // 6. MISO3 per speaker (tester.py:1231-1244), in MISO1's workspace
     r = forward_planar(n3, P.L3, ws3, s);
     if (r) return r;
     HIPCHK(launch_unpack(buf_ptr(P.L3, ws3, B_OUT), bstride(n3, P.L3, B_OUT), Tp, 1, T, F, reinterpret_cast<float2*>(out),
@@ -1102,10 +1119,10 @@ static int pipeline_run_impl(misonet_pipeline* p, const void* mix, const void* c
     if (bf_out)
       HIPCHK(launch_unpack_ex(in3, in3_bs, Tp, 1, T, F, M, 2 * M + 2, 0, 1, nullptr,
                               reinterpret_cast<float2*>(bf_out), B * S, reinterpret_cast<int*>(base), s));
-  }
-  if (miso1_out)
+  } else if (miso1_out) {
     HIPCHK(launch_unpack_ex(out1, out1_bs, Tp, S, T, F, 0, S, 1, M, sel_final, reinterpret_cast<float2*>(miso1_out),
                             B * S * M, reinterpret_cast<int*>(base), s));
+  }
   return MISONET_OK;
 }
 
