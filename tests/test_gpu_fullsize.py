@@ -121,3 +121,28 @@ def test_folded_norm_ill_conditioned_statistics(sd1, dc, bias_sigma):
     # yardstick: the exact-f32 MFMA mode of this library under the same conditioning (the float32 oracle is reported too)
     assert np.isfinite(err["f32"]) and np.isfinite(err["bf16x6"]) and np.isfinite(err["bf16x3"]), err
     assert err["bf16x6"] <= 4.0 * err["f32"] + 2e-6, err
+
+
+def test_large_batch_offsets_beyond_4_gib(sd1, sd3):
+    """40 utterances at T = 1001 (a 64 GB workspace: sample blocks far beyond 32-bit byte offsets) -- two distinct utterances
+    repeated: every copy returns the bits of the first one (exact statistics, per-sample blocks), wherever it sits."""
+    _need_gpu()
+    import misonet_amd as mz
+    from misonet_amd import weights as W
+    if torch.cuda.get_device_properties(0).total_memory < 120e9:
+        pytest.skip("needs > 120 GB of device memory")
+    m1 = mz.MISO_1(2, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN").cuda(0)
+    m1.load_state_dict(sd1)
+    m3 = mz.MISO_3(1, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN").cuda(0)
+    m3.load_state_dict(sd3)
+    enh = mz.Enhancer(m1.eval(), m3.eval(), num_spks=2, ref_ch=0)
+    a, b = _utt_inputs(1, 1001), _utt_inputs(2, 1001)
+    mix = torch.from_numpy(np.stack([a[0], b[0]])).cuda().repeat(20, 1, 1, 1)
+    clean = torch.from_numpy(np.stack([a[1], b[1]])).cuda().repeat(20, 1, 1, 1)
+    out = enh.enhance(mix, clean)
+    ref = enh.enhance(mix[:2].contiguous(), clean[:2].contiguous())
+    for i in (2, 17, 38, 39):
+        assert torch.equal(out[i], ref[i % 2]), i
+    del out, mix, clean
+    enh._ws.clear()
+    torch.cuda.empty_cache()
