@@ -39,12 +39,14 @@ int conv_rows(int sf, int tr2) { return tr2 ? 3 : sf * (FT - 1) + 3; }
 // KFMASK selects the frequency taps (all three for convs; {1} / {0,2} for the odd / even rows of a stride-2
 // transposed conv).  The kernel always computes all four column tiles: frames >= T are staged as zeros, so a ragged
 // last tile costs MFMAs, not correctness (T = 1001 and T = 501 both end in a tile that needs four anyway).
-template <int NCO, int NR, int SF, bool TR2, int KFMASK>
+// NCP: channel pairs of the chunk that hold channels (4 = all of CK; 2 for a last chunk with <= 4 channels -- the 12-channel
+// network input (model.py:44) leaves half of its second chunk empty: a quarter of that layer's MFMAs).
+template <int NCO, int NR, int SF, bool TR2, int KFMASK, int NCP = CK / 2>
 __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[NCO][4], const float* s_in, const float* s_w, int frel,
                                            int half, int l31) {
   constexpr int COP = NCO * 32;
   constexpr int NKF = ((KFMASK >> 0) & 1) + ((KFMASK >> 1) & 1) + ((KFMASK >> 2) & 1);
-  constexpr int NSTEP = 3 * NKF * (CK / 2);
+  constexpr int NSTEP = 3 * NKF * NCP;
   const float* wbase = s_w + half * COP + l31;
   // one input-row base per selected kf
   const float* ibase[3];
@@ -56,7 +58,7 @@ __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[NCO][4], const float* s
   float av[2][NCO], bv[2][4];
 #define MN_LOAD(ST, BUF)                                                                        \
   {                                                                                             \
-    constexpr int tap_ = (ST) / (CK / 2), cp_ = (ST) % (CK / 2);                                \
+    constexpr int tap_ = (ST) / NCP, cp_ = (ST) % NCP;                                          \
     constexpr int kt_ = tap_ / NKF, ks_ = tap_ % NKF;                                           \
     constexpr int kf_ = (NKF == 3) ? ks_ : ((KFMASK == 2) ? 1 : (ks_ == 0 ? 0 : 2));            \
     _Pragma("unroll") for (int j = 0; j < NCO; ++j)                                             \
@@ -71,7 +73,7 @@ __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[NCO][4], const float* s
     if (st + 1 < NSTEP) {
       // (the macro needs a constant: unrolled loop index)
       const int nx = st + 1;
-      const int tap_ = nx / (CK / 2), cp_ = nx % (CK / 2);
+      const int tap_ = nx / NCP, cp_ = nx % NCP;
       const int kt_ = tap_ / NKF, ks_ = tap_ % NKF;
       const int kf_ = (NKF == 3) ? ks_ : ((KFMASK == 2) ? 1 : (ks_ == 0 ? 0 : 2));
 #pragma unroll
@@ -258,6 +260,8 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0) ? 3 : 2)
       if (TR2) {
         if ((f - f0) & 1) chunk_mfma<NCO, NR, SF, TR2, 2>(acc, s_in, s_w, f - f0, half, l31);
         else chunk_mfma<NCO, NR, SF, TR2, 5>(acc, s_in, s_w, f - f0, half, l31);
+      } else if (MODE == 0 && kc == nchunk - 1 && Cin - kc * CK <= CK / 2) {
+        chunk_mfma<NCO, NR, SF, TR2, 7, CK / 4>(acc, s_in, s_w, f - f0, half, l31);      // half-empty last chunk
       } else {
         chunk_mfma<NCO, NR, SF, TR2, 7>(acc, s_in, s_w, f - f0, half, l31);
       }
