@@ -238,6 +238,8 @@ def main():
     ap.add_argument("--precision", choices=sorted(MODES), default=HEADLINE_PRECISION,
                     help="arithmetic of the 3x3 convs (default: the fp32-faithful headline mode)")
     ap.add_argument("--no-alt", action="store_true", help="skip the runs of the other precision modes (N = 1 only)")
+    ap.add_argument("--alt", default="f32,bf16x6,f16x3,bf16x3",
+                    help="comma-separated precision modes timed beside the headline (alt_precision on the line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the event-instrumented pass (no roofline object)")
     ap.add_argument("--verify-gather", action="store_true",
@@ -358,8 +360,8 @@ def main():
             roof["hbm_frac_pipeline"] = round(ALGO_BYTES_PER_UTT * (value / world) / (PEAK_HBM_TBS * 1e12), 4)
         alts = []
         if world == 1 and not args.no_alt:
-            for other in ("f32", "bf16x6", "f16x3", "bf16x3"):
-                if other == args.precision:
+            for other in [m for m in args.alt.split(",") if m]:
+                if other == args.precision or other not in MODES:
                     continue
                 try:
                     m1.set_precision(other)

@@ -102,8 +102,12 @@ __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[NCO][4], const float* s
 // for every staged row; threads < 16*NR own the two halo frames t0-1 / t0+128 of one (row, channel).
 // OCTP = 3 / 4: the instantiations that write the bf16x6 (hi | mid | lo bf16 parts) / f16x3 (hi | lo fp16 parts) oct layout:
 // the planar-input layers in front of a dense block when the network runs in one of those modes.
-template <int NCO, int MODE, int OCTP = 0>
-__global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0) ? 3 : 2)) void conv3x3_mfma(const ConvArgs a) {
+// HALFK: the instantiation for a layer whose LAST K-chunk holds <= CK/2 channels (the 12-channel network input, model.py:44):
+// that chunk runs half the channel pairs.  It is a separate instantiation because a second fully unrolled chunk_mfma body
+// inside the common kernel costs every MODE 0 instantiation its register allocation (round 3: 74-241 spilled VGPRs, f32
+// mode -36 %); tests/test_build_resources.py holds the hot instantiations to ScratchSize == 0.
+template <int NCO, int MODE, int OCTP = 0, bool HALFK = false>
+__global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0 && !HALFK) ? 3 : 2)) void conv3x3_mfma(const ConvArgs a) {
   constexpr int COP = NCO * 32;
   constexpr int NR = MODE == 0 ? 6 : (MODE == 1 ? 9 : 3);
   constexpr int SF = MODE == 1 ? 2 : 1;
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0) ? 3 : 2)
       if (TR2) {
         if ((f - f0) & 1) chunk_mfma<NCO, NR, SF, TR2, 2>(acc, s_in, s_w, f - f0, half, l31);
         else chunk_mfma<NCO, NR, SF, TR2, 5>(acc, s_in, s_w, f - f0, half, l31);
-      } else if (MODE == 0 && kc == nchunk - 1 && Cin - kc * CK <= CK / 2) {
+      } else if (HALFK && kc == nchunk - 1) {
         chunk_mfma<NCO, NR, SF, TR2, 7, CK / 4>(acc, s_in, s_w, f - f0, half, l31);      // half-empty last chunk
       } else {
         chunk_mfma<NCO, NR, SF, TR2, 7>(acc, s_in, s_w, f - f0, half, l31);
@@ -298,9 +302,9 @@ static size_t conv_lds_bytes(int NR, int cop, int Cin) {
   return (size_t)(CK * NR * TW + 9 * CK * cop) * sizeof(float) + (size_t)nchunk * CK * sizeof(float2);
 }
 
-template <int NCO, int MODE, int OCTP = 0>
+template <int NCO, int MODE, int OCTP = 0, bool HALFK = false>
 static hipError_t set_lds_attr() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma<NCO, MODE, OCTP>),
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma<NCO, MODE, OCTP, HALFK>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
 }
 
@@ -319,6 +323,9 @@ hipError_t conv_init() {
   if ((e = set_lds_attr<1, 0, 4>()) != hipSuccess) return e;
   if ((e = set_lds_attr<1, 2, 4>()) != hipSuccess) return e;
   if ((e = set_lds_attr<2, 0, 4>()) != hipSuccess) return e;
+  if ((e = set_lds_attr<1, 0, 0, true>()) != hipSuccess) return e;
+  if ((e = set_lds_attr<1, 0, 3, true>()) != hipSuccess) return e;
+  if ((e = set_lds_attr<1, 0, 4, true>()) != hipSuccess) return e;
   return set_lds_attr<2, 2, 4>();
 }
 
@@ -349,25 +356,29 @@ hipError_t launch_conv(const ConvArgs& a_in, int n_samples, hipStream_t s) {
 #define MN_LAUNCH(NCO, MODE) hipLaunchKernelGGL((conv3x3_mfma<NCO, MODE>), grid, dim3(256), lds, s, a)
 #define MN_LAUNCH3(NCO, MODE) hipLaunchKernelGGL((conv3x3_mfma<NCO, MODE, 3>), grid, dim3(256), lds, s, a)
 #define MN_LAUNCH4(NCO, MODE) hipLaunchKernelGGL((conv3x3_mfma<NCO, MODE, 4>), grid, dim3(256), lds, s, a)
+  // last K-chunk at most half full (the network's first layer): the HALFK instantiations, 32-channel groups only
+  const bool halfk = mode == 0 && a.cop == 32 && ((a.Cin - 1) % CK) < CK / 2;
+#define MN_LAUNCH_H(OCTP) hipLaunchKernelGGL((conv3x3_mfma<1, 0, OCTP, true>), grid, dim3(256), lds, s, a)
   if (a.out_oct) {
     // planar float32 in, oct layout out (bf16x6: three bf16 pieces; f16x3: two fp16 pieces): only the layer shapes that
     // occur in front of a dense block
     if ((a.out_oct != 3 && a.out_oct != 4) || mode == 1 || (a.Cout & 7) || (a.out_c0 & 7) || (a.out_sstride & 7)) return hipErrorInvalidValue;
     if (a.out_oct == 3) {
-      if (a.cop == 32) { if (mode == 0) MN_LAUNCH3(1, 0); else MN_LAUNCH3(1, 2); }
+      if (a.cop == 32) { if (halfk) MN_LAUNCH_H(3); else if (mode == 0) MN_LAUNCH3(1, 0); else MN_LAUNCH3(1, 2); }
       else { if (mode == 0) MN_LAUNCH3(2, 0); else MN_LAUNCH3(2, 2); }
     } else {
-      if (a.cop == 32) { if (mode == 0) MN_LAUNCH4(1, 0); else MN_LAUNCH4(1, 2); }
+      if (a.cop == 32) { if (halfk) MN_LAUNCH_H(4); else if (mode == 0) MN_LAUNCH4(1, 0); else MN_LAUNCH4(1, 2); }
       else { if (mode == 0) MN_LAUNCH4(2, 0); else MN_LAUNCH4(2, 2); }
     }
   } else if (a.cop == 32) {
-    if (mode == 0) MN_LAUNCH(1, 0); else if (mode == 1) MN_LAUNCH(1, 1); else MN_LAUNCH(1, 2);
+    if (halfk) MN_LAUNCH_H(0); else if (mode == 0) MN_LAUNCH(1, 0); else if (mode == 1) MN_LAUNCH(1, 1); else MN_LAUNCH(1, 2);
   } else {
     if (mode == 0) MN_LAUNCH(2, 0); else if (mode == 1) MN_LAUNCH(2, 1); else MN_LAUNCH(2, 2);
   }
 #undef MN_LAUNCH
 #undef MN_LAUNCH3
 #undef MN_LAUNCH4
+#undef MN_LAUNCH_H
   return hipGetLastError();
 }
 

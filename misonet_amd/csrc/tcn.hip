@@ -28,6 +28,7 @@ __device__ inline double block_sum_256(double v, double* s_tmp /*[4]*/) {
 // fixed-order sum of the np partials of one statistic pair
 __device__ inline double2 tpart_sum(const double2* p, int np) {
   double2 s = p[0];
+#pragma unroll 8      // (fully unrolled, the 32 uniform partials of a gLN sum are 128 SGPRs of scalar loads at once)
   for (int i = 1; i < np; ++i) { const double2 q = p[i]; s.x += q.x; s.y += q.y; }
   return s;
 }
@@ -215,8 +216,8 @@ __global__ __launch_bounds__(256) void tcn_pw_k(const float* d, const double2* g
     u32x4_t A[3];
 #define X6_ISSUE(SL, K0)                                                                                          \
   _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                                                \
-    xin[SL][c] = tok ? xl[(long long)((K0) + c) * Tp] : 0.f;                                                     \
-    win[SL][c] = wl[(long long)((K0) + c) * C];                                                                  \
+    xin[SL][c] = tok ? xl[((K0) + c) * Tp] : 0.f;          /* 32-bit offsets: C * Tp elements per sample */      \
+    win[SL][c] = wl[((K0) + c) * C];                                                                             \
   }
 #define X6_COMMIT(BUF, SL, K0)                                                                                   \
   {                                                                                                              \
@@ -240,30 +241,36 @@ __global__ __launch_bounds__(256) void tcn_pw_k(const float* d, const double2* g
     X6_ISSUE(1, 16)
     X6_COMMIT(0, 0, 0)
     __syncthreads();
-#pragma unroll
-    for (int kc = 0; kc < C / 16; ++kc) {
-      const int buf = kc & 1;
-      if (kc + 2 < C / 16) X6_ISSUE(kc & 1, (kc + 2) * 16)      // slot kc & 1 was consumed by the commit of chunk kc
-      const bf16x8_t Ah = __builtin_bit_cast(bf16x8_t, A[0]), Am = __builtin_bit_cast(bf16x8_t, A[1]),
-                     Al = __builtin_bit_cast(bf16x8_t, A[2]);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const bf16x8_t Bh = __builtin_bit_cast(bf16x8_t, s_x[buf][0][half][s * 32 + l31]);
-        const bf16x8_t Bm = __builtin_bit_cast(bf16x8_t, s_x[buf][1][half][s * 32 + l31]);
-        const bf16x8_t Bl = __builtin_bit_cast(bf16x8_t, s_x[buf][2][half][s * 32 + l31]);
-        // small terms first: lh, hl, mm, mh, hm, hh
-        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acc[s], 0, 0, 0);
-        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acc[s], 0, 0, 0);
-        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm, acc[s], 0, 0, 0);
-        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, acc[s], 0, 0, 0);
-        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, acc[s], 0, 0, 0);
-        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc[s], 0, 0, 0);
-      }
-      if (kc + 1 < C / 16) {
-        X6_COMMIT(buf ^ 1, (kc + 1) & 1, (kc + 1) * 16)
-        __syncthreads();
-      }
+    // the slot / buffer index of a chunk is a LITERAL in each half of the pair below: indexed by `kc & 1` the two-slot
+    // arrays stayed an alloca (68 bytes of scratch per lane: SROA runs before the loop is unrolled)
+#define X6_STEP(KC, SL)                                                                                          \
+    {                                                                                                            \
+      if ((KC) + 2 < C / 16) X6_ISSUE(SL, ((KC) + 2) * 16)      /* slot SL was consumed by the commit of chunk KC */ \
+      const bf16x8_t Ah = __builtin_bit_cast(bf16x8_t, A[0]), Am = __builtin_bit_cast(bf16x8_t, A[1]),           \
+                     Al = __builtin_bit_cast(bf16x8_t, A[2]);                                                    \
+      _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                            \
+        const bf16x8_t Bh = __builtin_bit_cast(bf16x8_t, s_x[SL][0][half][s * 32 + l31]);                        \
+        const bf16x8_t Bm = __builtin_bit_cast(bf16x8_t, s_x[SL][1][half][s * 32 + l31]);                        \
+        const bf16x8_t Bl = __builtin_bit_cast(bf16x8_t, s_x[SL][2][half][s * 32 + l31]);                        \
+        /* small terms first: lh, hl, mm, mh, hm, hh */                                                          \
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acc[s], 0, 0, 0);                               \
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acc[s], 0, 0, 0);                               \
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm, acc[s], 0, 0, 0);                               \
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, acc[s], 0, 0, 0);                               \
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, acc[s], 0, 0, 0);                               \
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc[s], 0, 0, 0);                               \
+      }                                                                                                          \
+      if ((KC) + 1 < C / 16) {                                                                                   \
+        X6_COMMIT((SL) ^ 1, (SL) ^ 1, ((KC) + 1) * 16)                                                           \
+        __syncthreads();                                                                                         \
+      }                                                                                                          \
     }
+#pragma unroll
+    for (int kp = 0; kp < C / 32; ++kp) {
+      X6_STEP(2 * kp, 0)
+      X6_STEP(2 * kp + 1, 1)
+    }
+#undef X6_STEP
 #undef X6_ISSUE
 #undef X6_COMMIT
   } else {

@@ -1,0 +1,90 @@
+"""Register budget of the hot kernels, checked at BUILD time (no GPU).
+
+Round 3 lost 36 % of the f32 mode's speed to a commit that made `conv3x3_mfma<1|2,0,0>` spill (0 -> 74 / 241 VGPRs, measured
+only on another mode).  The Makefile now compiles every object with -Rpass-analysis=kernel-resource-usage and leaves the
+remarks in misonet_amd/csrc/build/*.res; this test reads them (tools/kernel_resources.py) and fails when a kernel that
+carries the bench's time starts to use scratch memory.  tests/test_gpu_bench.py holds the matching per-mode floors on the
+measured roofline fraction."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+# every instantiation that runs in the bench's timed region in the `bf16x6` (headline) and `f32` modes, plus the TCN / MVDR /
+# layout kernels of both: no spills, no scratch
+HOT = [
+    "mn::conv3x3_mfma<1, 0, 0, false>", "mn::conv3x3_mfma<2, 0, 0, false>",        # f32: stride-1 convs, 32 / 64 channels
+    "mn::conv3x3_mfma<1, 1, 0, false>", "mn::conv3x3_mfma<2, 1, 0, false>",        # f32: stride-2 convs
+    "mn::conv3x3_mfma<1, 2, 0, false>",                                            # f32: stride-2 transposed convs
+    "mn::conv3x3_mfma<1, 0, 0, true>", "mn::conv3x3_mfma<1, 0, 3, true>",          # first layer (12 input channels)
+    "mn::conv3x3_mfma<1, 0, 3, false>",                                            # MISO3 first layer in bf16x6
+    "mn::conv3x3_bf16x6<0, 8, false, 4>", "mn::conv3x3_bf16x6<0, 8, false, 3>",    # 59 % + 28 % of the bf16x6 step
+    "mn::conv3x3_bf16x6<0, 4, false, 4>", "mn::conv3x3_bf16x6<1, 4, false, 4>",
+    "mn::conv3x3_bf16x6<2, 8, false, 4>", "mn::conv3x3_bf16x6<2, 4, false, 4>",
+    "mn::conv3x3_bf16x6<3, 8, false, 4>", "mn::conv_wprep6_k",
+    "mn::tcn_pw_k<false, true>", "mn::tcn_pw_k<true, true>", "mn::tcn_pw_k<false, false>", "mn::tcn_pw_k<true, false>",
+    "mn::tcn_dw_k", "mn::tcn_prepare_k",
+    "mn::mvdr_scm_eig<6>", "mn::mvdr_solve<6>", "mn::mvdr_apply<6>",
+    "mn::pack_k", "mn::unpack_k", "mn::assemble3_k", "mn::pit_dist_k<2>", "mn::pit_pick_k<2>", "mn::stft_pack_k",
+]
+
+# known spillers that are NOT on the bench's path, with the scratch they are allowed (bytes per lane): instantiations of
+# the opt-in modes / of shapes this network does not have.  A number going UP here is a regression too.
+TOLERATED = {
+    "mn::conv3x3_mfma<2, 0, 3, false>": 64, "mn::conv3x3_mfma<2, 0, 4, false>": 32,      # 64-channel planar-in / oct-out: unused
+    "mn::conv3x3_mfma<2, 2, 0, false>": 400, "mn::conv3x3_mfma<2, 2, 3, false>": 480,    # stride-2 transposed, > 32 channels: unused
+    "mn::conv3x3_mfma<2, 2, 4, false>": 320,
+    "mn::conv3x3_bf16x6<0, 8, true, 4>": 224,                                            # f16x3 hand-over layer (alt mode)
+    "mn::conv3x3_bf16x3<2, 1>": 32,                                                      # bf16x3p (alt mode)
+    "mn::mvdr_scm_eig<8>": 600,                                                          # M = 8 microphones (tests only)
+}
+
+
+@pytest.fixture(scope="module")
+def table():
+    subprocess.run(["make", "-C", os.path.join(ROOT, "misonet_amd", "csrc"), "-j4"], check=True, stdout=subprocess.DEVNULL)
+    import kernel_resources
+    t = kernel_resources.parse()
+    assert len(t) >= 80, f"only {len(t)} kernels in build/*.res: was the library built by this Makefile?"
+    return t
+
+
+# the one hot instantiation that is allowed scratch: the 8-row stride-2-transposed tile holds 1 spilled VGPR (8 bytes) since
+# round 2 (3 % of a step); every attempt to remove it moved the allocator to 38+ spills (compiling the timeline stamps out:
+# 256 VGPRs / 38 spilled).  It may not grow.
+HOT_SCRATCH_ALLOWED = {"mn::conv3x3_bf16x6<2, 8, false, 4>": 8}
+
+
+def test_hot_kernels_do_not_spill(table):
+    missing = [k for k in HOT if k not in table]
+    assert not missing, f"hot kernels not found in the build remarks (renamed instantiation?): {missing}"
+    bad = {k: (table[k]["vgpr_spill"], table[k]["scratch"]) for k in HOT
+           if table[k]["scratch"] > HOT_SCRATCH_ALLOWED.get(k, 0) or table[k]["vgpr_spill"] > HOT_SCRATCH_ALLOWED.get(k, 0) // 8}
+    assert not bad, f"(VGPR spills, scratch bytes) of hot kernels: {bad}"
+    # SGPR spills go to VGPR lanes (v_writelane, no memory): the persistent kernels' producer bookkeeping has 13-41 of them.
+    # They are bounded here so that a jump is seen.
+    sg = {k: table[k]["sgpr_spill"] for k in HOT if table[k]["sgpr_spill"] > 48}
+    assert not sg, f"SGPR spills: {sg}"
+
+
+def test_no_other_kernel_spills_unnoticed(table):
+    bad = {}
+    for k, r in table.items():
+        if k in HOT:
+            continue
+        if r["scratch"] > TOLERATED.get(k, 0):
+            bad[k] = (r["scratch"], TOLERATED.get(k, 0))
+    assert not bad, f"scratch bytes per lane (found, allowed): {bad}"
+
+
+def test_headline_kernel_occupancy(table):
+    # the persistent bf16x6 kernels are written for ONE 512-thread workgroup per CU = 2 waves per SIMD: <= 256 VGPRs
+    for k in ("mn::conv3x3_bf16x6<0, 8, false, 4>", "mn::conv3x3_bf16x6<0, 8, false, 3>"):
+        assert table[k]["vgprs"] <= 256 and table[k]["occupancy"] >= 2, table[k]
+    # the f32 32-channel kernel is tuned for three workgroups per CU (<= 168 VGPRs)
+    assert table["mn::conv3x3_mfma<1, 0, 0, false>"]["vgprs"] <= 168
+    assert table["mn::conv3x3_mfma<1, 0, 0, false>"]["occupancy"] >= 3
