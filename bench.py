@@ -199,6 +199,69 @@ def roofline_objects(precision, B, T, steps, dt_conv_ms, n_launch):
     return binding, (r_hbm if binding is r_mfma else r_mfma)
 
 
+def wav_leg(enh, W, rank, B, n, steps, warmup, dev, headline_value):
+    """wav in -> int16 wav out (reference tester.py:865-867 H2D, 949-974 iSTFT -> int16): the same batch as the headline,
+    entering as float32 waveforms [B, n, 6] (+ the clean references [B, n, 2]) and leaving as int16 [B, 2, n]."""
+    wav_h = torch.empty((B, n, N_MIC), dtype=torch.float32).pin_memory()
+    clean_h = torch.empty((B, n, N_SPK), dtype=torch.float32).pin_memory()
+    for i in range(B):
+        obs, s0, s1 = W.synthetic_utterance(rank * B + i, n)
+        wav_h[i] = torch.from_numpy(obs)
+        clean_h[i, :, 0] = torch.from_numpy(s0[:, 0].copy())
+        clean_h[i, :, 1] = torch.from_numpy(s1[:, 0].copy())
+    wav_d, clean_d = wav_h.to(dev), clean_h.to(dev)
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, r
+
+    # (a) device-resident: inputs in HBM, int16 result left in HBM
+    def dev_loop(k):
+        pcm = None
+        for _ in range(k):
+            pcm = enh.enhance_wav_int16(wav_d, clean_d, check_nan=False)
+        return pcm
+    dev_loop(warmup)
+    dt_dev, pcm_d = timed(lambda: dev_loop(steps))
+
+    # (b) host-resident, copies overlapped with compute on two extra streams (Enhancer.stream_wav)
+    def gen(k):
+        for _ in range(k):
+            yield (wav_h, clean_h)
+
+    def host_loop(k):
+        last = None
+        for pcm in enh.stream_wav(gen(k), check_nan=False):
+            last = pcm
+        return last
+    host_loop(max(warmup, 2))
+    dt_host, pcm_h = timed(lambda: host_loop(steps))
+
+    # (c) host-resident, serial (what the per-split .to(device) / .cpu() of the reference harness does)
+    def serial_loop(k):
+        last = None
+        for _ in range(k):
+            last = enh.enhance_wav_int16(wav_h.to(dev), clean_h.to(dev), check_nan=False).cpu()
+        return last
+    serial_loop(1)
+    dt_ser, _ = timed(lambda: serial_loop(steps))
+    same = bool(np.array_equal(pcm_h, pcm_d.cpu().numpy()))
+    v_dev, v_host, v_ser = B * steps / dt_dev, B * steps / dt_host, B * steps / dt_ser
+    return {"unit": "utt/s", "steps": steps,
+            "device_resident": round(v_dev, 3), "host_resident_overlapped": round(v_host, 3),
+            "host_resident_serial": round(v_ser, 3),
+            "vs_headline": {"device_resident": round(v_dev / headline_value, 4),
+                            "host_resident_overlapped": round(v_host / headline_value, 4),
+                            "host_resident_serial": round(v_ser / headline_value, 4)},
+            "pcie_bytes_per_utterance": {"h2d": n * (N_MIC + N_SPK) * 4, "d2h": N_SPK * n * 2},
+            "host_equals_device_result": same,
+            "what": "float32 wav [B, 64000, 6] (+ clean [B, 64000, 2]) -> HIP STFT -> MISO1x6/align/MVDRx2/MISO3x2 -> one "
+                    "batched torch.istft -> x 32767 -> int16 [B, 2, 64000]; the headline starts and ends at spectrograms"}, pcm_d
+
+
 def workload_name(world, B):
     """BASELINE.json's name of what this launch runs: configs[3] = batch 16 on one GPU, configs[4] = batch 128 sharded over
     8 GPUs (8 x 16); other rank counts / batch sizes run configs[4]'s sharding at their own global batch."""
@@ -209,6 +272,15 @@ def workload_name(world, B):
         return f"BASELINE configs[4]: {pipe}, batch 128 sharded over 8 GPUs (8 x 16), no data-path collective"
     return (f"BASELINE configs[4] sharding at {world} ranks: {pipe}, global batch {world * B} = {world} x {B} "
             f"(configs[4] itself is 8 x 16), no data-path collective")
+
+
+def rank_utterances(rank, world, B):
+    """Global utterance indices of this rank's shard: the contiguous block split of the global batch world * B
+    (misonet_amd.pipeline.shard_range; the reference's utterances are independent, dataloader/data.py:558-595).
+    At 8 x 16 rank r owns utterances [16 r, 16 r + 16) of BASELINE configs[4]'s batch of 128."""
+    from misonet_amd.pipeline import shard_range
+    lo, hi = shard_range(world * B, rank, world)
+    return list(range(lo, hi))
 
 
 def free_port():
@@ -241,6 +313,10 @@ def main():
     ap.add_argument("--alt", default="f32,bf16x6,f16x3,bf16x3",
                     help="comma-separated precision modes timed beside the headline (alt_precision on the line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--wav", action="store_true",
+                    help="time the reference's real unit of work, wav in -> int16 wav out (HIP STFT front-end, pipeline, batched "
+                         "iSTFT, x 32767 -> int16), device-resident and host-resident with overlapped copies; runs by default "
+                         "at N = 1 unless --no-alt, this flag forces it")
     ap.add_argument("--no-profile", action="store_true", help="skip the event-instrumented pass (no roofline object)")
     ap.add_argument("--verify-gather", action="store_true",
                     help="after the timed loop: all_gather every rank's enhanced spectrograms over the process group (RCCL "
@@ -289,8 +365,9 @@ def main():
     B, T = args.batch, args.frames
     n = (T - 1) * 64
     mixes, cleans = [], []
-    for i in range(B):
-        obs, s0, s1 = W.synthetic_utterance(rank * B + i, n)
+    my_utts = rank_utterances(rank, world, B)
+    for u in my_utts:
+        obs, s0, s1 = W.synthetic_utterance(u, n)
         mixes.append(stft.stft(torch.from_numpy(obs.T.copy()).to(dev)))                       # [M,T,F]
         cleans.append(torch.stack([stft.stft(torch.from_numpy(s[:, 0].copy()).to(dev)) for s in (s0, s1)]))
     mix = torch.stack(mixes).contiguous()
@@ -305,7 +382,12 @@ def main():
     dt_rank = dt
     per_rank = [B * args.steps / dt]
     rccl_ranks = 1
+    rank_ranges = [[my_utts[0], my_utts[-1] + 1]]
     if dist is not None:
+        rr = torch.tensor([my_utts[0], my_utts[-1] + 1], dtype=torch.int64, device=dev)
+        allr = [torch.zeros_like(rr) for _ in range(world)]
+        dist.all_gather(allr, rr)
+        rank_ranges = [[int(x[0]), int(x[1])] for x in allr]
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         allt = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allt, t)
@@ -409,11 +491,20 @@ def main():
                 b1["hip_graph_error"] = str(e)[:200]
             enh.enhance(mix, clean, check_nan=False, out=out)            # restore the batch workspace / result
             torch.cuda.synchronize()
+        wavp, wav_pcm = None, None
+        if world == 1 and (args.wav or not args.no_alt) and T == 1001:
+            try:
+                wavp, wav_pcm = wav_leg(enh, W, rank, B, n, args.steps, args.warmup, dev, value)
+            except Exception as e:                                       # the extra leg never costs the headline its line
+                wavp = {"error": repr(e)[:300]}
+            enh.enhance(mix, clean, check_nan=False, out=out)
+            torch.cuda.synchronize()
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             enh.enhance(mix, clean, check_nan=False, out=out)            # the headline mode's result for the checker
             torch.cuda.synchronize()
-            cpu = cpu_baseline(sd1, sd3, T, out[:4].cpu().numpy())
+            cpu = cpu_baseline(sd1, sd3, T, out[:4].cpu().numpy(),
+                               wav_pcm[:4].cpu().numpy() if wav_pcm is not None else None)
         line = {
             "metric": "utterances/sec MISO1->MVDR->MISO3, 6-mic 16kHz 4s",
             "value": round(value, 3), "unit": "utt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -425,8 +516,10 @@ def main():
                        "parallelism": f"utterance-shard x{world}"},
             "realtime_factor": round(value * (n / 16000.0), 2),
             "rccl_ranks": rccl_ranks, "per_rank_utt_per_s": [round(v, 3) for v in per_rank],
+            "per_rank_utterances": rank_ranges, "backend": (backend if world > 1 else None),
             "parity": (cpu or {}).pop("parity_of_headline", None) if cpu else None,
-            "roofline": roof, "roofline_other": roof2, "alt_precision": alts, "single_utterance": b1, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_other": roof2, "alt_precision": alts, "single_utterance": b1, "wav_path": wavp,
+            "cpu_baseline": cpu,
         }
         if gather:
             line.update(gather)
@@ -456,7 +549,7 @@ def _physical_cores():
     return os.cpu_count() or 1
 
 
-def cpu_baseline(sd1, sd3, T, gpu_out=None):
+def cpu_baseline(sd1, sd3, T, gpu_out=None, gpu_pcm=None):
     """The oracle (kind "port": our stock-torch-CPU/NumPy restatement of the reference path, B = 1 per call as in
     tester.py:846-975) on this host's cores.  Bounded sample: one forward warm-up, one
     utterance at each of a ladder of thread counts (8 ... physical cores), then 3 different utterances end to end at
@@ -519,6 +612,15 @@ def cpu_baseline(sd1, sd3, T, gpu_out=None):
                 errs[str(u)] = float(np.linalg.norm(g - np.abs(ref)) / np.linalg.norm(np.abs(ref)))
         parity = {"rel_l2_magnitudes_vs_oracle_by_utterance": {k: float(f"{v:.3e}") for k, v in errs.items()},
                   "worst": float(f"{max(errs.values()):.3e}") if errs else None, "tolerance": 1e-3}
+        if gpu_pcm is not None:
+            # the wav leg's int16 output against the oracle's own iSTFT -> x 32767 -> int16 of ITS spectrograms (tester.py:
+            # 949-952): the two paths differ by the STFT front-end (HIP vs SciPy) and everything after it
+            lsb = {}
+            for u, ref in ref_out.items():
+                if u < gpu_pcm.shape[0]:
+                    want = np.stack([pipeline_oracle.istft_int16(ref[s]) for s in range(ref.shape[0])])
+                    lsb[str(u)] = int(np.abs(gpu_pcm[u].astype(np.int32) - want.astype(np.int32)).max())
+            parity["wav_int16_max_abs_diff_lsb_by_utterance"] = lsb
     return {"parity_of_headline": parity, "value": round(1.0 / med, 4), "unit": "utt/s", "cores": best, "kind": "port",
             "host_logical_cpus": logical, "host_physical_cores": physical, "usable_cpus": usable,
             "utt_per_s_by_threads": {str(c): round(1.0 / t, 4) for c, t in probes.items()},

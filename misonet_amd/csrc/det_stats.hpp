@@ -22,7 +22,14 @@ namespace mn {
 
 typedef unsigned long long dstat_t;
 constexpr int DS_NL = 5;                     // limbs per statistic
-constexpr long long DS_POISON = 1ll << 62;   // added to the top limb by a non-finite / out-of-range partial
+// Poison: a non-finite / out-of-range partial RAISES the top limb to DS_POISON with an atomic MAX.  That is idempotent --
+// any number of bad partials leaves it at >= 2^62 - 2^61 (legitimate additions move the limb by < 2^61 in all: |q| < 2^38,
+// 2^23 additions), so dstat_combine's test `top limb >= 2^61` holds whatever the order and the count.  (Round 3 ADDED
+// 2^62 per bad partial: two made the limb negative, four wrapped it to zero -- and a NaN activation poisons many tiles.)
+constexpr long long DS_POISON = 1ll << 62;
+
+// the poison step on plain memory (the kernels use atomicMax; tests/helpers/det_stats_host.cpp uses this)
+MN_HD void dstat_poison_limb(long long& top) { top = top > DS_POISON ? top : DS_POISON; }
 
 // v -> q[0 .. DS_NL-1] with v = sum q[i] 2^(40 i - 80) + (a remainder below 2^-80, truncated toward zero); |q[i]| < 2^40.
 // Returns false (q untouched) when v is inf, NaN or >= 2^118 in magnitude.
@@ -65,8 +72,8 @@ MN_HD double dstat_combine(const long long (&Lin)[DS_NL]) {
 // p: the DS_NL limbs of one statistic (zeroed at the start of a forward)
 __device__ __forceinline__ void dstat_add(dstat_t* p, double v) {
   long long q[DS_NL];
-  if (!dstat_split(v, q)) {                  // inf, NaN or out of range: poison (dstat_read returns NaN)
-    atomicAdd(p + (DS_NL - 1), (unsigned long long)DS_POISON);
+  if (!dstat_split(v, q)) {                  // inf, NaN or out of range: poison (dstat_read returns NaN), idempotent
+    atomicMax(reinterpret_cast<long long*>(p + (DS_NL - 1)), DS_POISON);
     return;
   }
 #pragma unroll

@@ -63,6 +63,32 @@ def run_sharded(process: Callable[[int, int], torch.Tensor], n_items: int, rank:
     return local
 
 
+class CapturedPass:
+    """One :meth:`Enhancer.enhance` pass captured in a HIP graph, together with everything the graph's kernels point at.
+
+    The graph bakes raw device addresses (workspace, inputs, result), so this object OWNS references to all of them: the
+    workspace stays alive for as long as the graph does, whatever other batch sizes / lengths / precision modes the
+    Enhancer is used with in between (its own cache may drop and re-allocate workspaces freely).  ``replay()`` re-runs the
+    pass; new inputs are copied INTO ``mix`` / ``clean`` first (``load``).  Unpacks as ``(graph, out)``."""
+
+    def __init__(self, graph, out, ws, mix, clean, key):
+        self.graph, self.out, self.mix, self.clean = graph, out, mix, clean
+        self._ws, self.key = ws, key
+
+    def load(self, mix, clean=None):
+        self.mix.copy_(mix)
+        if self.clean is not None and clean is not None:
+            self.clean.copy_(clean)
+
+    def replay(self):
+        self.graph.replay()
+        return self.out
+
+    def __iter__(self):                       # ``g, out = enh.capture_graph(...)``
+        yield self
+        yield self.out
+
+
 class Enhancer:
     """Fused on-device MISO1 -> (alignment) -> MVDR -> MISO3 for batches of 4 s chunks."""
 
@@ -115,14 +141,18 @@ class Enhancer:
             raise ValueError(f"{name} must be {list(shape)}, got {list(x.shape)}")
         return x.to(torch.complex64).contiguous()
 
-    def workspace(self, B, T):
+    def _ws_key(self, B, T):
         # the layout depends on the arithmetic modes and on whether buffers may share memory
-        key = (B, T, self.model_sep.precision, self.model.precision, self.model_sep._keep, self.model._keep)
+        return (B, T, self.model_sep.precision, self.model.precision, self.model_sep._keep, self.model._keep)
+
+    def workspace(self, B, T):
+        key = self._ws_key(B, T)
         ws = self._ws.get(key)
         if ws is None:
             self._ws.clear()
             n = _lib.lib().misonet_pipeline_workspace_bytes(self._pipe, B, T)
             ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+            ws[:16].zero_()                    # the NaN flag word: check() on a workspace no pass has run in reads "clean"
             self._ws[key] = ws
         return ws
 
@@ -162,27 +192,44 @@ class Enhancer:
             return out, dict(bf=bf, miso1=m1)
         return out
 
-    def capture_graph(self, mix: torch.Tensor, clean: Optional[torch.Tensor] = None):
-        """Capture one :meth:`enhance` pass over the given (static) input tensors into a HIP graph and return
-        ``(graph, out)``: ``graph.replay()`` re-runs the ≈ 450 kernel launches of the pass with one host call and
-        leaves the result in ``out``; new inputs are copied INTO ``mix`` / ``clean`` before a replay.  Every entry
-        point of the C ABI is asynchronous on the caller's stream and allocates nothing, so the whole pass is
-        capturable.  What it buys is host time: at batch 16 the GPU is the bottleneck either way, a single utterance
-        (B = 1, the reference harness' own batch size) is launch-bound without it.  NaN checking is the caller's
-        (``misonet_pipeline_check`` synchronises, so it is not part of the graph): call :meth:`check` when needed."""
+    def capture_graph(self, mix: torch.Tensor, clean: Optional[torch.Tensor] = None) -> CapturedPass:
+        """Capture one :meth:`enhance` pass over the given (static) input tensors into a HIP graph and return a
+        :class:`CapturedPass` (unpacks as ``(graph, out)``): ``graph.replay()`` re-runs the ≈ 450 kernel launches of the
+        pass with one host call and leaves the result in ``out``; new inputs are copied INTO ``mix`` / ``clean`` before a
+        replay.  Every entry point of the C ABI is asynchronous on the caller's stream and allocates nothing, so the whole
+        pass is capturable.  The graph holds raw addresses: ``mix`` / ``clean`` must ALREADY be contiguous complex64
+        device tensors (a converted copy would be what the graph reads, not the caller's tensor), and the returned object
+        keeps the workspace, the inputs and the result alive -- the Enhancer's own workspace cache may be re-used for other
+        shapes / modes meanwhile.  NaN checking is the caller's (``misonet_pipeline_check`` synchronises, so it is not part
+        of the graph): call :meth:`check` when needed."""
         self._ready()
+        for name, x in (("mix", mix), ("clean", clean)):
+            if x is None:
+                continue
+            if (not isinstance(x, torch.Tensor) or x.dtype != torch.complex64 or not x.is_contiguous()
+                    or x.device != self.device):
+                raise ValueError(f"capture_graph: {name} must be a contiguous complex64 tensor on {self.device} (the graph "
+                                 "records its address)")
         B, M, T, F = mix.shape
         out = torch.empty((B, self.num_spks, T, F), dtype=torch.complex64, device=self.device)
         self.enhance(mix, clean, check_nan=False, out=out)               # warm-up: workspace allocation, lazy init
         torch.cuda.synchronize(self.device)
+        key = self._ws_key(B, T)
+        ws = self._ws[key]
         g = torch.cuda.CUDAGraph()
         with torch.cuda.device(self.device), torch.cuda.graph(g):
             self.enhance(mix, clean, check_nan=False, out=out)
-        return g, out
+        if self._ws.get(key) is not ws:                                  # (cannot happen: same key as the warm-up)
+            raise RuntimeError("workspace changed during capture")
+        # from now on this workspace belongs to the graph: the cache hands out a fresh one for the same key, so an eager
+        # pass between two replays cannot clobber activations a replay is about to read
+        del self._ws[key]
+        return CapturedPass(g, out, ws, mix, clean, key)
 
-    def check(self, B: int, T: int):
-        """Synchronise and raise FloatingPointError if the last pass on the (B, T) workspace produced a NaN."""
-        ws = self.workspace(B, T)
+    def check(self, B: int, T: int, captured: Optional[CapturedPass] = None):
+        """Synchronise and raise FloatingPointError if the last pass on the (B, T) workspace produced a NaN
+        (``captured``: the workspace of that captured pass instead of the eager one)."""
+        ws = captured._ws if captured is not None else self.workspace(B, T)
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().misonet_pipeline_check(self._pipe, ws.data_ptr(), _lib.stream_ptr(self.device)))
 
@@ -225,6 +272,94 @@ class Enhancer:
         if want_bf or want_miso1:
             return out, dict(bf=bf, miso1=m1)
         return out
+
+    def enhance_wav_int16(self, wav: torch.Tensor, clean_wav: Optional[torch.Tensor] = None, check_nan=True) -> torch.Tensor:
+        """The reference's unit of work on the device: wav in -> int16 wav out (tester.py:865-867 H2D ... 949-952 iSTFT,
+        x 32767, int16).  wav float32 [B, n_samples, M] (device) -> int16 [B, S, n_samples] (device): HIP STFT front-end,
+        the fused pipeline, ONE batched ``torch.istft`` over the B * S enhanced spectrograms and the truncating cast --
+        nothing leaves the device and nothing synchronises (with ``check_nan=False``)."""
+        return S.istft_int16(self.enhance_wav(wav, clean_wav, check_nan=check_nan))
+
+    def stream_wav(self, batches, depth: int = 2, check_nan: bool = True):
+        """HOST-resident batches in, int16 waves out, copies overlapped with compute.
+
+        ``batches`` yields ``wav`` or ``(wav, clean_wav)``: CPU float32 tensors [B, n_samples, M] / [B, n_samples, S] (pinned
+        or not; un-pinned ones are staged through a pinned buffer of this generator).  For every batch, in order, yields
+        int16 ndarray [B, S, n_samples].  Three streams: H2D copies of batch i + 1 (copy-in stream) and the D2H copy of
+        batch i - 1's int16 result (copy-out stream) run beside the pipeline of batch i (current stream); ``depth`` device
+        input / pinned output slots.  The host only blocks on the result of the OLDEST batch in flight, so the GPU always
+        has the next batch queued.  A NaN in batch i raises FloatingPointError when that batch is handed out (the
+        pipeline's flag word travels with the result instead of a synchronising check)."""
+        import collections
+        self._ready()
+        dev = self.device
+        depth = max(1, int(depth))
+        with torch.cuda.device(dev):
+            cur = torch.cuda.current_stream(dev)
+            s_in, s_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+            slots = [dict() for _ in range(depth)]
+            pending = collections.deque()
+
+            def finish(rec):
+                rec["ev_out"].synchronize()
+                if check_nan and int(rec["flag_h"][0]) != 0:
+                    raise FloatingPointError("libmisonet_hip: NaN in pipeline output")
+                return rec["pcm_h"].numpy().copy()
+
+            def staged(sl, name, host):
+                """pinned source for the H2D copy of `host` (itself if already pinned)"""
+                host = host.to(torch.float32).contiguous() if host.dtype != torch.float32 or not host.is_contiguous() else host
+                if host.is_pinned():
+                    return host
+                pin = sl.get("pin_" + name)
+                if pin is None or pin.shape != host.shape:
+                    pin = sl["pin_" + name] = torch.empty(host.shape, dtype=torch.float32, pin_memory=True)
+                elif "ev_in" in sl:
+                    sl["ev_in"].synchronize()                 # the previous H2D out of this staging buffer is done
+                pin.copy_(host)
+                return pin
+
+            for i, item in enumerate(batches):
+                wav_h, clean_h = item if isinstance(item, (tuple, list)) else (item, None)
+                while len(pending) >= depth:                  # slot i % depth still belongs to batch i - depth
+                    yield finish(pending.popleft())
+                sl = slots[i % depth]
+                src_w = staged(sl, "wav", wav_h)
+                src_c = staged(sl, "clean", clean_h) if clean_h is not None else None
+                if sl.get("wav_d") is None or sl["wav_d"].shape != src_w.shape:
+                    sl["wav_d"] = torch.empty(src_w.shape, dtype=torch.float32, device=dev)
+                if src_c is not None and (sl.get("clean_d") is None or sl["clean_d"].shape != src_c.shape):
+                    sl["clean_d"] = torch.empty(src_c.shape, dtype=torch.float32, device=dev)
+                with torch.cuda.stream(s_in):
+                    if "ev_free" in sl:
+                        s_in.wait_event(sl["ev_free"])        # the pass that read this slot's device buffers is done
+                    sl["wav_d"].copy_(src_w, non_blocking=True)
+                    if src_c is not None:
+                        sl["clean_d"].copy_(src_c, non_blocking=True)
+                    sl["ev_in"] = torch.cuda.Event()
+                    sl["ev_in"].record(s_in)
+                cur.wait_event(sl["ev_in"])
+                B, Ls, _ = sl["wav_d"].shape
+                pcm = self.enhance_wav_int16(sl["wav_d"], sl["clean_d"] if src_c is not None else None, check_nan=False)
+                T = _lib.lib().misonet_stft_frames(Ls)
+                flag = self.workspace(B, T)[:4].view(torch.int32).clone()      # the pass's NaN flag word (ws[0])
+                sl["ev_free"] = torch.cuda.Event()
+                sl["ev_free"].record(cur)
+                rec = {"pcm_h": sl.get("pcm_h"), "flag_h": sl.get("flag_h")}
+                if rec["pcm_h"] is None or rec["pcm_h"].shape != pcm.shape:
+                    rec["pcm_h"] = sl["pcm_h"] = torch.empty(pcm.shape, dtype=torch.int16, pin_memory=True)
+                    rec["flag_h"] = sl["flag_h"] = torch.zeros(1, dtype=torch.int32, pin_memory=True)
+                with torch.cuda.stream(s_out):
+                    s_out.wait_event(sl["ev_free"])
+                    rec["pcm_h"].copy_(pcm, non_blocking=True)
+                    rec["flag_h"].copy_(flag, non_blocking=True)
+                    pcm.record_stream(s_out)
+                    flag.record_stream(s_out)
+                    rec["ev_out"] = torch.cuda.Event()
+                    rec["ev_out"].record(s_out)
+                pending.append(rec)
+            while pending:
+                yield finish(pending.popleft())
 
     def separate(self, mix: torch.Tensor, clean: Optional[torch.Tensor] = None, check_nan=True) -> torch.Tensor:
         """Separation stage only: MISO1_Inference over the circular shifts + alignments (tester.py:1014-1068, 889-915).
@@ -294,30 +429,62 @@ class Enhancer:
         import os
         os.makedirs(saveDir, exist_ok=True)
         results = {}
-        for (obs_d, s0_d, s1_d, gap, wav_name) in data_loader:
-            n_split = len(obs_d)
-            per_split = []
-            for k in range(n_split):
-                obs = torch.as_tensor(obs_d[str(k)]).to(self.device)
-                s0 = torch.as_tensor(s0_d[str(k)])[:, self.ref_ch].to(self.device)          # tester.py:889-890
-                s1 = torch.as_tensor(s1_d[str(k)])[:, self.ref_ch].to(self.device)
-                clean = torch.stack((s0, s1), dim=1)
-                per_split.append(self.enhance(obs, clean))                                  # [B,S,T,F]
-            B = per_split[0].shape[0]
-            for b in range(B):
-                g = int(gap[b]) if hasattr(gap, "__len__") else int(gap)
-                wav = self.to_wav_int16([sp[b] for sp in per_split], g)                     # [S, n]
-                name = wav_name[b] if not isinstance(wav_name, str) else wav_name
+        dev = self.device
+
+        def h2d(x):
+            """one asynchronous copy per tensor (pinned staging), instead of a synchronous ``.to(device)`` per split"""
+            x = torch.as_tensor(x)
+            if x.device == dev:
+                return x
+            if x.device.type == "cpu" and not x.is_pinned():
+                x = x.contiguous().pin_memory()
+            return x.to(dev, non_blocking=True)
+
+        def finalize(rec):
+            """the previous loader item: wait for ITS D2H only, stitch, write"""
+            rec["ev"].synchronize()
+            pcm = rec["pcm_h"].numpy()                                                        # [n_split, B, S, n]
+            for b in range(pcm.shape[1]):
+                gp = rec["gap"]
+                g = int(gp[b]) if hasattr(gp, "__len__") else int(gp)
+                wav = np.stack([S.stitch_int16([pcm[k, b, s] for k in range(pcm.shape[0])], g)
+                                for s in range(self.num_spks)])                               # [S, n_total]
+                name = rec["name"][b] if not isinstance(rec["name"], str) else rec["name"]
                 results[name] = wav
                 if write:
                     for s in range(self.num_spks):
                         S.write_wav_pcm24(os.path.join(saveDir, f"{name}_{s}.wav"), wav[s], fs)
+
+        with torch.cuda.device(dev):
+            s_out = torch.cuda.Stream(dev)
+            prev = None
+            for (obs_d, s0_d, s1_d, gap, wav_name) in data_loader:
+                n_split = len(obs_d)
+                outs = []
+                for k in range(n_split):
+                    obs = h2d(obs_d[str(k)])
+                    s0 = h2d(torch.as_tensor(s0_d[str(k)])[:, self.ref_ch])                   # tester.py:889-890
+                    s1 = h2d(torch.as_tensor(s1_d[str(k)])[:, self.ref_ch])
+                    outs.append(self.enhance(obs, torch.stack((s0, s1), dim=1)))              # [B,S,T,F]
+                pcm = S.istft_int16(torch.stack(outs))           # ONE batched iSTFT over n_split * B * S spectrograms
+                ev_done = torch.cuda.Event()
+                ev_done.record(torch.cuda.current_stream(dev))
+                rec = {"pcm_h": torch.empty(pcm.shape, dtype=torch.int16, pin_memory=True), "gap": gap, "name": wav_name}
+                with torch.cuda.stream(s_out):                   # ONE D2H per loader item, beside the next item's compute
+                    s_out.wait_event(ev_done)
+                    rec["pcm_h"].copy_(pcm, non_blocking=True)
+                    pcm.record_stream(s_out)
+                    rec["ev"] = torch.cuda.Event()
+                    rec["ev"].record(s_out)
+                if prev is not None:
+                    finalize(prev)
+                prev = rec
+            if prev is not None:
+                finalize(prev)
         return results
 
     def to_wav_int16(self, enhanced_chunks: List[torch.Tensor], gap: int) -> np.ndarray:
-        """tester.py:949-969 for one recording: list over 4 s splits of complex [S,T,F] -> int16 [S, n_samples]."""
-        per_spk = []
-        for s in range(self.num_spks):
-            pcs = [S.istft_int16(ch[s]).cpu().numpy() for ch in enhanced_chunks]
-            per_spk.append(S.stitch_int16(pcs, gap))
-        return np.stack(per_spk)
+        """tester.py:949-969 for one recording: list over 4 s splits of complex [S,T,F] -> int16 [S, n_samples].
+        One batched iSTFT over all (split, speaker) spectrograms and one device-to-host copy."""
+        pcm = S.istft_int16(torch.stack([torch.as_tensor(ch) for ch in enhanced_chunks])).cpu().numpy()   # [n_split, S, n]
+        return np.stack([S.stitch_int16([pcm[k, s] for k in range(pcm.shape[0])], gap) for s in range(self.num_spks)])

@@ -7,7 +7,7 @@ int ds_nl(void) { return mn::DS_NL; }
 // adds v to the limbs acc[DS_NL]; returns 0 when v poisons the statistic
 int ds_accumulate(long long* acc, double v) {
   long long q[mn::DS_NL];
-  if (!mn::dstat_split(v, q)) { acc[mn::DS_NL - 1] += mn::DS_POISON; return 0; }
+  if (!mn::dstat_split(v, q)) { mn::dstat_poison_limb(acc[mn::DS_NL - 1]); return 0; }
   for (int i = 0; i < mn::DS_NL; ++i) acc[i] += q[i];
   return 1;
 }

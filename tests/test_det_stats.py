@@ -85,3 +85,28 @@ def test_non_finite_partials_poison(ds):
         assert ds.ds_accumulate(acc, bad) == 0
         ds.ds_accumulate(acc, -2.0)
         assert math.isnan(ds.ds_value(acc))
+
+
+@pytest.mark.parametrize("n_bad", [1, 2, 3, 4, 5, 8, 64, 1024, 4096])
+def test_poison_is_idempotent(ds, n_bad):
+    """a NaN activation poisons MANY tiles of a (sample, channel) row.  With an additive poison two or three bad
+    partials read as a finite -2^143 and four wrapped to exactly zero; the poison is now a MAX, so any count, in any
+    interleaving with finite partials of either sign (incl. the largest the range allows), reads as NaN."""
+    r = np.random.default_rng(n_bad)
+    good = (r.standard_normal(4096) * np.float32(1e30)).astype(np.float32)        # top-limb sized partials, both signs
+    ops = [("g", float(v)) for v in good] + [("b", b) for b in
+                                             (r.choice([float("nan"), float("inf"), float("-inf"), -(2.0 ** 119)], n_bad))]
+    for trial in range(3):
+        acc = (C.c_longlong * 5)()
+        for i in r.permutation(len(ops)):
+            kind, v = ops[i]
+            assert ds.ds_accumulate(acc, v) == (1 if kind == "g" else 0)
+        assert math.isnan(ds.ds_value(acc)), (n_bad, trial, [int(a) for a in acc])
+    # worst case by construction: 2^23 - 1 additions of the most negative legitimate top limb AFTER the poison
+    acc = (C.c_longlong * 5)()
+    ds.ds_accumulate(acc, float("nan"))
+    acc[4] += -(2 ** 38 - 1) * (2 ** 23 - 1)
+    for _ in range(n_bad):
+        ds.ds_accumulate(acc, float("inf"))
+        acc[4] += -(2 ** 36)
+    assert math.isnan(ds.ds_value(acc))

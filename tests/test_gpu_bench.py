@@ -62,6 +62,7 @@ def test_bench_two_ranks_on_one_device():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
     assert d["config"]["batch_per_gpu"] == 4
     assert d["rccl_ranks"] == 2 and len(d["per_rank_utt_per_s"]) == 2
+    assert d["per_rank_utterances"] == [[0, 4], [4, 8]] and d["backend"] == "gloo"
     assert "configs[4]" in d["config"]["workload"] and d["config"]["global_batch"] == 8
     # --verify-gather: the all_gather of the results (the path's only collective), one utterance of the LAST rank's shard
     # checked by the oracle on rank 0
@@ -70,3 +71,25 @@ def test_bench_two_ranks_on_one_device():
     assert gp["from_rank"] == 1 and gp["utterance"] == 4 and gp["ok"] and gp["rel_l2_magnitudes_vs_oracle"] < 1e-3
     # whole-job aggregate: 2 ranks x 4 utterances x 2 steps over the max-over-ranks time
     assert abs(d["value"] - 2 * 4 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-2
+
+
+def test_bench_two_ranks_rccl():
+    """The real thing when the box has two GPUs: one rank per device over RCCL (backend "nccl"), the gather verified by
+    the oracle, rank 1's inputs = utterances 16-31 of the global batch.  Skipped on the 1-GPU boxes of the pool (the
+    one-device gloo test above covers the script's distributed code there)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MISONET_BENCH_ONE_DEVICE", "MISONET_BENCH_BACKEND"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-alt",
+           "--verify-gather"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["backend"] == "nccl"
+    assert d["per_rank_utterances"] == [[0, 16], [16, 32]]
+    assert d["gather_parity"]["ok"] and d["gather_parity"]["from_rank"] == 1 and d["gather_parity"]["utterance"] == 16
+    assert d["gathered_shape"] == [32, 2, 1001, 129]

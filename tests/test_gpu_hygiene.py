@@ -189,7 +189,8 @@ def test_hip_graph_capture_replays_identical_bits(sd1, sd3):
     clean = torch.from_numpy(a[1][None]).cuda()
     eager_a = enh.enhance(mix, clean).clone()
     eager_b = enh.enhance(torch.from_numpy(b[0][None]).cuda(), torch.from_numpy(b[1][None]).cuda()).clone()
-    g, out = enh.capture_graph(mix, clean)
+    cap = enh.capture_graph(mix, clean)
+    g, out = cap
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, eager_a)
@@ -198,7 +199,8 @@ def test_hip_graph_capture_replays_identical_bits(sd1, sd3):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, eager_b)
-    enh.check(1, 64)
+    enh.check(1, 64, captured=cap)          # the graph owns its workspace (tests/test_gpu_wavpath.py: lifetime)
+    enh.check(1, 64)                        # a fresh eager workspace reads clean
 
 
 @pytest.mark.parametrize("scale", [1e-4, 1e-2, 1e3])
