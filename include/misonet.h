@@ -130,9 +130,12 @@ int misonet_mvdr_debug(const void* ws_dev, int B, int F, int M, void* steer_c128
  * the per-bin partial sums [B, F, S, S], which are added in bin order (no atomics: the distances and the selected
  * permutation are bit-reproducible from run to run).  All S! permutations are enumerated in
  * itertools.permutations order with the first minimum winning, as the reference's einsum('bij,pij->bp') + argmin
- * (tester.py:1053-1064); 1 <= S <= 4. */
+ * (tester.py:1053-1064); 1 <= S <= 4.
+ * dist_bytes = the size of dist_dev in bytes: less than misonet_pit_scratch_bytes(B, S, F) returns MISONET_ENOMEM (ABI 400;
+ * until ABI 300 the size was implicit, and it had grown from B*S*S doubles in ABI 200 without the signature changing). */
+long long misonet_pit_scratch_bytes(int B, int S, int F);
 int misonet_pit_select(const void* anchor_dev, const void* cand_dev, int B, int S, int T, int F,
-                       int* sel_dev, double* dist_dev, misonet_stream stream);
+                       int* sel_dev, double* dist_dev, long long dist_bytes, misonet_stream stream);
 
 /* ---- fused on-device pipeline: the body of Tester_Enhance.inference (tester.py:865-939) -------------------- */
 /* MISO1_Inference (6 circular shifts batched as 6B forwards, tester.py:1014-1068) -> clean-reference

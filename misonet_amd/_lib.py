@@ -53,8 +53,9 @@ SIGNATURES = {
     "misonet_mvdr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                C.c_void_p, C.c_longlong, C.c_void_p]),
     "misonet_mvdr_debug": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "misonet_pit_scratch_bytes": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
     "misonet_pit_select": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
-                                     C.c_void_p]),
+                                     C.c_longlong, C.c_void_p]),
     "misonet_pipeline_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
                                           C.POINTER(C.c_void_p)]),
     "misonet_pipeline_destroy": (C.c_int, [C.c_void_p]),

@@ -70,8 +70,10 @@ def pit_select(anchor, cand, return_dist=False):
         raise ValueError("anchor and cand must both be [B, S, T, F]")
     B, S, T, F = a.shape
     sel = torch.empty((B, S), dtype=torch.int32, device=a.device)
-    dist = torch.empty((B * (F + 1), S, S), dtype=torch.float64, device=a.device)    # result [B,S,S] + per-bin partials
+    L = _lib.lib()
+    nd = L.misonet_pit_scratch_bytes(B, S, F) // 8                                    # result [B,S,S] + per-bin partials
+    dist = torch.empty((nd // (S * S), S, S), dtype=torch.float64, device=a.device)
     with torch.cuda.device(a.device):
-        _lib.check(_lib.lib().misonet_pit_select(a.data_ptr(), c.data_ptr(), B, S, T, F, sel.data_ptr(), dist.data_ptr(),
-                                                 _lib.stream_ptr(a.device)))
+        _lib.check(L.misonet_pit_select(a.data_ptr(), c.data_ptr(), B, S, T, F, sel.data_ptr(), dist.data_ptr(),
+                                        dist.numel() * 8, _lib.stream_ptr(a.device)))
     return (sel, dist[:B]) if return_dist else sel

@@ -501,10 +501,22 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
   return MISONET_OK;
 }
 
+// The workspace header (256 bytes): word 0 = NaN flag; word 2 = LAYOUT STAMP of the forward that last ran in it -- which
+// buffer plan (shared arena or one memory per buffer), arithmetic mode and geometry the offsets inside belong to.
+// misonet_net_tap compares it before it reads a buffer (a tap after keep_activations(net, 1) on a workspace whose
+// forward ran with the SHARED plan passed the old host-side check and read past the smaller workspace).
+static unsigned layout_stamp(const misonet_net* n, const Layout& L) {
+  unsigned h = 2166136261u;
+  auto mix = [&](unsigned long long v) { for (int i = 0; i < 8; ++i) { h ^= (unsigned)(v & 0xff); h *= 16777619u; v >>= 8; } };
+  mix(n->keep_taps ? 1 : 0); mix((unsigned)n->precision); mix((unsigned)L.N); mix((unsigned)L.T); mix((unsigned long long)L.total_bytes);
+  return h | 1u;                                  // never 0 (= "no forward has run here")
+}
+
 // IN buffer already filled (planar).  Leaves the result (raw) in B_OUT.
 static int forward_planar(misonet_net* n, const Layout& L, void* ws, hipStream_t s) {
   // the nan flag + the conv statistics (integer limbs are ACCUMULATED); the TCN partial arrays behind them are plainly written
   HIPCHK(hipMemsetAsync(ws, 0, (size_t)(256 + L.tcn_xs * 8), s));
+  HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(reinterpret_cast<char*>(ws) + 8), (int)layout_stamp(n, L), 1, s));
   // Optional sample sub-batching of the conv stacks (MISONET_SUBBATCH = samples per pass at F = 127; deeper levels take
   // proportionally more): keeps a level's producer->consumer traffic inside the 256 MiB Infinity Cache.
   static const int sub_env = [] { const char* e = getenv("MISONET_SUBBATCH"); return e ? atoi(e) : 0; }();
@@ -588,7 +600,7 @@ const char* misonet_strerror(int code) {
   }
 }
 const char* misonet_last_error(void) { return g_err; }
-int misonet_version(void) { return 300; }
+int misonet_version(void) { return 400; }
 
 int misonet_net_create(const misonet_cfg* cfg, misonet_net** out) {
   if (!cfg || !out) return fail(MISONET_EINVAL, "null argument");
@@ -866,6 +878,17 @@ int misonet_net_tap(misonet_net* n, const char* name, const void* ws, int B, int
       if (!n->keep_taps && t.buf != B_OUT)
         return fail(MISONET_ESTATE, "tap '%s': activation buffers share memory; call misonet_net_keep_activations(net, 1) "
                                     "before the forward", name);
+      {
+        // the plan the workspace was WRITTEN with must be the one this call would read it with (a diagnostic entry point:
+        // the 4-byte read-back synchronises the stream)
+        unsigned stamp = 0;
+        hipStream_t s_ = reinterpret_cast<hipStream_t>(stream);
+        HIPCHK(hipMemcpyAsync(&stamp, reinterpret_cast<const char*>(ws) + 8, sizeof(stamp), hipMemcpyDeviceToHost, s_));
+        HIPCHK(hipStreamSynchronize(s_));
+        if (stamp != layout_stamp(n, L))
+          return fail(MISONET_ESTATE, "tap '%s': the forward in this workspace ran with another buffer plan / mode / shape "
+                                      "(keep_activations, precision, B or T changed since); run the forward again", name);
+      }
       void* w = const_cast<void*>(ws);
       HIPCHK(launch_export(buf_ptr(L, w, t.buf), bstride(n, L, t.buf), t.c0, t.C, n->bufs[t.buf].F, T, L.Tp,
                            t.normalised ? stats_ptr(L, w, t.buf) : nullptr, n->bufs[t.buf].C, 0, dst, B,
@@ -904,11 +927,18 @@ int misonet_mvdr_debug(const void* ws, int B, int F, int M, void* steer, void* w
   return MISONET_OK;
 }
 
+long long misonet_pit_scratch_bytes(int B, int S, int F) {
+  if (B <= 0 || S <= 0 || F <= 0) return -1;
+  return (long long)B * S * S * (F + 1) * (long long)sizeof(double);
+}
+
 int misonet_pit_select(const void* anchor, const void* cand, int B, int S, int T, int F, int* sel, double* dist,
-                       misonet_stream stream) {
+                       long long dist_bytes, misonet_stream stream) {
   if (!anchor || !cand || !sel || !dist) return fail(MISONET_EINVAL, "null argument (dist is required: B*S*S*(F+1) doubles)");
   if (S < 1 || S > 4) return fail(MISONET_EINVAL, "PIT alignment enumerates S! permutations: 1 <= num_spks <= 4 (got %d)", S);
   if (B <= 0 || T <= 0 || F <= 0) return fail(MISONET_EINVAL, "B, T, F must be positive");
+  if (dist_bytes < misonet_pit_scratch_bytes(B, S, F))
+    return fail(MISONET_ENOMEM, "dist scratch %lld < %lld bytes (B*S*S*(F+1) doubles)", dist_bytes, misonet_pit_scratch_bytes(B, S, F));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const float* a = reinterpret_cast<const float*>(anchor);
   const float* c = reinterpret_cast<const float*>(cand);

@@ -228,3 +228,78 @@ def test_f16x3_input_scale_range(sd1, scale):
     print(f"[scale {scale:g}] " + "  ".join(f"{k} {v:.2e}" for k, v in err.items()))
     assert err["f16x3"] <= 2.0 * err["f32"] + 2e-6, err
     assert err["bf16x6"] <= 2.0 * err["f32"] + 2e-6, err
+
+
+def test_tap_refuses_a_workspace_written_with_another_plan(sd1):
+    """forward with the shared arena, then misonet_net_keep_activations(net, 1), then a tap on the SAME workspace.
+    The host-side keep flag is now true, but the buffers in that workspace were laid out by the shared plan (0.26 instead of
+    0.55 GB per sample): the tap must fail with MISONET_ESTATE instead of reading past the workspace.  The forward stamps
+    its layout into the workspace header; the tap compares."""
+    _need_gpu()
+    import ctypes as C
+    import misonet_amd as mz
+    from misonet_amd import _lib, weights as W
+    m = mz.MISO_1(2, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN").cuda(0)
+    m.load_state_dict(sd1)
+    mx, _ = _utt_inputs(4, 40)
+    y = m.eval()(torch.from_numpy(mx[None]).cuda())
+    ws = m._ws[(1, 40)]                                   # the workspace of that forward (shared-arena plan)
+    L = _lib.lib()
+    dst = torch.empty((1, 24, 40, 127), dtype=torch.float32, device="cuda")
+    # the output tap is always readable ...
+    c, f = C.c_int(), C.c_int()
+    _lib.check(L.misonet_net_tap_shape(m._net, b"enc0", C.byref(c), C.byref(f)))
+    assert (c.value, f.value) == (24, 127)
+    # ... an inner one is refused while buffers share memory
+    rc = L.misonet_net_tap(m._net, b"enc0", ws.data_ptr(), 1, 40, dst.data_ptr(), _lib.stream_ptr(ws.device))
+    assert rc == _lib.ESTATE
+    # switch the plan WITHOUT a new forward: still refused (this sequence used to read out of bounds)
+    _lib.check(L.misonet_net_keep_activations(m._net, 1))
+    rc = L.misonet_net_tap(m._net, b"enc0", ws.data_ptr(), 1, 40, dst.data_ptr(), _lib.stream_ptr(ws.device))
+    assert rc == _lib.ESTATE and b"another buffer plan" in L.misonet_last_error()
+    _lib.check(L.misonet_net_keep_activations(m._net, 0))
+    # the supported sequence: keep first, forward, tap -- and a different T on that workspace is refused again
+    m.keep_activations(True)
+    y2 = m(torch.from_numpy(mx[None]).cuda())
+    assert torch.equal(y, y2)
+    t = m.tap("enc0", 1, 40)
+    assert tuple(t.shape) == (1, 24, 40, 127) and torch.isfinite(t).all()
+    ws2 = m._ws[(1, 40)]
+    rc = L.misonet_net_tap(m._net, b"enc0", ws2.data_ptr(), 1, 39, dst.data_ptr(), _lib.stream_ptr(ws2.device))
+    assert rc == _lib.ESTATE
+
+
+def test_pit_select_checks_its_scratch_size():
+    """the scratch of misonet_pit_select grew from B*S*S to B*S*S*(F+1) doubles between ABI 200 and 300 with
+    no size in the signature; ABI 400 takes dist_bytes and answers MISONET_ENOMEM."""
+    _need_gpu()
+    from misonet_amd import _lib
+    L = _lib.lib()
+    assert L.misonet_version() >= 400
+    B, S, T, F = 2, 2, 16, 129
+    need = L.misonet_pit_scratch_bytes(B, S, F)
+    assert need == B * S * S * (F + 1) * 8
+    a = torch.randn((B, S, T, F), dtype=torch.complex64, device="cuda")
+    sel = torch.empty((B, S), dtype=torch.int32, device="cuda")
+    dist = torch.empty(need // 8, dtype=torch.float64, device="cuda")
+    st = _lib.stream_ptr(a.device)
+    assert L.misonet_pit_select(a.data_ptr(), a.data_ptr(), B, S, T, F, sel.data_ptr(), dist.data_ptr(), B * S * S * 8, st) == _lib.ENOMEM
+    assert L.misonet_pit_select(a.data_ptr(), a.data_ptr(), B, S, T, F, sel.data_ptr(), dist.data_ptr(), need - 1, st) == _lib.ENOMEM
+    _lib.check(L.misonet_pit_select(a.data_ptr(), a.data_ptr(), B, S, T, F, sel.data_ptr(), dist.data_ptr(), need, st))
+    assert sel.cpu().tolist() == [[0, 1], [0, 1]]
+
+
+def test_default_precision_is_bf16x6_and_golden_green(sd1, monkeypatch):
+    """the arithmetic of a freshly constructed network changed from f32 to bf16x6 in ABI 300.  This pins the
+    UNTOUCHED default (no set_precision call, no MISONET_PRECISION) to the reference golden G1 and states which mode it is."""
+    _need_gpu()
+    monkeypatch.delenv("MISONET_PRECISION", raising=False)
+    import misonet_amd as mz
+    from misonet_amd import _lib, weights as W
+    from conftest import golden
+    m = mz.MISO_1(2, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN").cuda(0)
+    m.load_state_dict(sd1)
+    assert m.precision == "bf16x6" and _lib.lib().misonet_net_get_precision(m._net) == 3
+    g = golden("g1_miso1_T32.npz")
+    y = m.eval()(torch.from_numpy(g["x"]).cuda()).cpu().numpy()
+    _assert_parity(y, g["y"], "default-constructed MISO_1 vs G1")
