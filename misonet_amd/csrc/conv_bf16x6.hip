@@ -126,6 +126,96 @@ __device__ __forceinline__ void chunk_mfma6(f32x16 (&acc)[NROW], const bf16x8* s
   }
 }
 
+// "Two rows in M" (G16): the LAST output-channel group of a stride-1 layer with Cout % 32 == 16 -- the 144 -> 48 conv that
+// closes the F = 127 dense block of the last decoder (reference model.py:437-482 with de_channels[6] = 24: 10 % of a
+// step).  As a 32-channel group its tile pads 16 of the 32 MFMA rows.  Here the rows are (output row d = 0, 1) x (channel
+// co = 0..15): accumulator j holds the output rows 2j and 2j + 1 (registers 0-7: row 2j, 8-15: row 2j + 1 -- the first two
+// register quads of the 32-channel order ARE the 16 channels of a 16-channel group, so tables, statistics and the oct
+// stores keep their layout), and a staged input row R is multiplied by the BANDED weight fragment
+// A_dR[(d, co)] = W[kf = dR - d][co], dR = R - 2j in 0..3 (zero outside 0 <= kf <= 2): 4 staged rows x 9 MFMAs per row pair
+// instead of 2 x 3 x 9 = 144 instead of 216 MFMAs per chunk and wave.
+//   sw: the STANDARD weight image of the group (channels 16-31 of it are zero padding): a lane outside the band reads the
+//       unit of padded channel co + 16, i.e. zeros -- no masking instructions.
+template <int NR, int NROW>
+__device__ __forceinline__ void chunk_mfma6_rm2(f32x16 (&acc)[NROW], const bf16x8* sx, const bf16x8* sw, int wave, int half,
+                                                int l31) {
+  static_assert(NR == NROW + 2, "stride-1 tiles only");
+  constexpr int XN = NR * X6_TW;
+  constexpr int NP2 = NROW / 2;
+  // an opaque copy of the lane index: everything derived from it below (11 per-lane LDS addresses) is otherwise hoisted out
+  // of the persistent tile loop and held in registers across the standard-group tiles too (34 spilled VGPRs)
+  asm volatile("" : "+v"(l31));
+  const int d = l31 >> 4, co = l31 & 15;
+  const int xa = 32 * wave + l31 + half;                   // + p * XN + R * X6_TW     (kt = half)
+  const int p2 = half ? 2 : 0;
+  const int xb0 = (half ? XN : 0) + 32 * wave + l31 + 2;
+  const int xb1 = (half ? 0 : 2 * XN) + 32 * wave + l31 + 2;
+  // per-lane units of the banded fragments: kf = dR - d inside the band, else the zero-padded channel co + 16 of kf = 0
+  int wa[4], w2[4];
+#pragma unroll
+  for (int dR = 0; dR < 4; ++dR) {
+    const int kf = dR - d;
+    const bool in_band = (unsigned)kf < 3u;
+    wa[dR] = in_band ? (kf * 3 * 2) * 32 + half * 32 + co : half * 32 + co + 16;         // + (p * 2) * 32
+    w2[dR] = X6_WPAIR + (in_band ? (kf * 3) * 32 + co : co + 16);                         // + p * 32
+  }
+  bf16x8 A[4][3], A2[4][3], B[2][3], B2[2][2];
+#pragma unroll
+  for (int dR = 0; dR < 4; ++dR)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) A[dR][p] = sw[wa[dR] + (p * 2) * 32];
+  constexpr int NSTEP = 2 * NR;
+#pragma unroll
+  for (int st = -1; st < NSTEP; ++st) {
+    if (st + 1 < NR) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) B[(st + 1) & 1][p] = sx[p * XN + (st + 1) * X6_TW + xa];
+    } else if (st + 1 < NSTEP) {
+      const int R_ = st + 1 - NR;
+      B2[(st + 1) & 1][0] = sx[xb0 + R_ * X6_TW];
+      B2[(st + 1) & 1][1] = sx[xb1 + R_ * X6_TW];
+    }
+    if (st == NR - 2) {
+      // the weight fragments of phase B: [w_h | w_h], [w_m | w_m], [w_h | w_l], one step ahead of their first use
+#pragma unroll
+      for (int dR = 0; dR < 4; ++dR) {
+        A2[dR][0] = sw[w2[dR] + 0 * 32];
+        A2[dR][1] = sw[w2[dR] + 1 * 32];
+        A2[dR][2] = sw[w2[dR] + p2 * 32];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);     // keep the next step's ds_reads AHEAD of this step's MFMAs
+    if (st >= 0 && st < NR) {
+      const int R = st, cur = st & 1;
+#pragma unroll
+      for (int term = 0; term < 6; ++term) {               // lh, hl, mm, mh, hm, hh
+        const int ap = term == 0 ? 2 : ((term == 2 || term == 3) ? 1 : 0);
+        const int bp = term == 1 ? 2 : ((term == 2 || term == 4) ? 1 : 0);
+#pragma unroll
+        for (int j = 0; j < NP2; ++j)
+#pragma unroll
+          for (int dR = 0; dR < 4; ++dR)
+            if (2 * j + dR == R)
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[dR][ap], B[cur][bp], acc[j], 0, 0, 0);
+      }
+    } else if (st >= NR) {
+      const int R = st - NR, cur = st & 1;
+#pragma unroll
+      for (int term = 0; term < 3; ++term) {               // hl + lh, mh + mm, hh + hm
+        const int aq = 2 - term;
+        const int bq = term == 0 ? 1 : 0;
+#pragma unroll
+        for (int j = 0; j < NP2; ++j)
+#pragma unroll
+          for (int dR = 0; dR < 4; ++dR)
+            if (2 * j + dR == R)
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2[dR][aq], B2[cur][bq], acc[j], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // MODE 3, "rows in M": a stride-1 layer with Cout <= 4 -- the network's last transposed conv, 48 -> 2 * num_spks channels at
 // F = 129 (reference model.py:418-423, 64).  With channels on the 32 MFMA rows it uses 4 of them.  Here the rows are
 // (output row d = 0..7) x (channel co = 0..3): ONE accumulator tile holds a wave's whole 8-row x 4-channel x 32-frame
@@ -254,7 +344,9 @@ __device__ __forceinline__ void x6_wait_vm() {
 // this exact arithmetic (net.hip, buf_oct); its last conv hands over to the fp16 dataflow.
 // NQ = 3: an instantiation for layers of <= 24 output channels (the F = 127 dense blocks: 29 % of the conv time): the tile
 // epilogue skips the fourth register quad of every row (channels 24-31 of the 32-row MFMA tile are padding).
-template <int MODE, int FTR, bool OUT16 = false, int NQ = 4>
+// G16: the instantiation for layers whose last output-channel group has 16 channels (Cout % 32 == 16): the tiles of that group
+// run the two-rows-in-M mapping (chunk_mfma6_rm2), the other groups the standard one.
+template <int MODE, int FTR, bool OUT16 = false, int NQ = 4, bool G16 = false>
 __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int nslots) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (the LDS-DMA builtin has no host form)
   constexpr int COP = 32;
@@ -263,6 +355,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
   constexpr bool RM = MODE == 3;                               // rows in M (chunk_mfma6_rm): Cout <= 4, act = 0, planar output
   static_assert(FTR == 4 || (FTR == 8 && MODE != 1), "8-row tiles: not for the stride-2 layers (17 staged rows)");
   static_assert(!RM || FTR == 8, "rows-in-M tiles are 8 output rows x 4 channels");
+  static_assert(!G16 || (MODE == 0 && FTR == 8 && !OUT16 && NQ == 4), "two-rows-in-M groups: stride-1 8-row tiles, oct3 output");
   constexpr int NR = (MODE == 0 || RM) ? FTR + 2 : (MODE == 1 ? 9 : FTR / 2 + 1);   // staged input rows of an FTR-row tile
   constexpr int NS = 2;                                        // stages
   constexpr int XN = NR * X6_TW;                               // units per input part image
@@ -557,16 +650,24 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
     for (;;) {
       f32x16 acc[RM ? 1 : FTR];
       const bool wave_live = (t0 + 32 * wave < T) && !(a.dbg & 1);   // this consumer's frames exist (ragged last tile)
+      const bool g16 = G16 && (cg == a.ncg - 1);                    // uniform: this tile is the 16-channel group
+      // (two-rows-in-M tiles use the first FTR / 2 accumulators)
       {
         const float* tb = s_tab + (ti % NS) * (3 * FTR * COP);  // accumulators start at bias + folded shift
-        conv_acc_init_rows(acc, t0 + 32 * wave, T, lane, tb, tb + FTR * COP, tb + 2 * FTR * COP);
+        if constexpr (G16) {
+          if (g16) conv_acc_init_rows_rm2<FTR>(acc, t0 + 32 * wave, T, lane, tb, tb + FTR * COP, tb + 2 * FTR * COP);
+          else conv_acc_init_rows(acc, t0 + 32 * wave, T, lane, tb, tb + FTR * COP, tb + 2 * FTR * COP);
+        } else conv_acc_init_rows(acc, t0 + 32 * wave, T, lane, tb, tb + FTR * COP, tb + 2 * FTR * COP);
       }
       for (int kc = 0; kc < nchunk; ++kc, ++g) {
         if (wave_live) {
           const bf16x8* st = s_stage + (g % NS) * SN;
           __builtin_amdgcn_s_setprio(1);
           if constexpr (RM) chunk_mfma6_rm<NR>(acc[0], st, st + 3 * XN, wave, half, l31);
-          else chunk_mfma6<NR, SF, TR2, FTR>(acc, st, st + 3 * XN, wave, half, l31);
+          else if constexpr (G16) {
+            if (g16) chunk_mfma6_rm2<NR, FTR>(acc, st, st + 3 * XN, wave, half, l31);
+            else chunk_mfma6<NR, SF, TR2, FTR>(acc, st, st + 3 * XN, wave, half, l31);
+          } else chunk_mfma6<NR, SF, TR2, FTR>(acc, st, st + 3 * XN, wave, half, l31);
           __builtin_amdgcn_s_setprio(0);
         }
         STAMP(ti);
@@ -576,13 +677,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
       if constexpr (RM) {
         if (!(a.dbg & 4)) conv_epilogue_rm(a, acc[0], n, f0, t0 + 32 * wave, lane);
       } else if (!(a.dbg & 4)) {
+        float* sr = s_red + (ti & 1) * (4 * COP * 2) + wave * (COP * 2);
+        const float* sc = a.act ? s_ctr + (ti & 3) * COP : nullptr;
         if constexpr (OUT16)
-          conv_epilogue_rows_nb<2, true>(a, acc, n, cg, f0, t0 + 32 * wave, lane, s_red + (ti & 1) * (4 * COP * 2) + wave * (COP * 2),
-                                         FTR, a.act ? s_ctr + (ti & 3) * COP : nullptr);
-        else
-          conv_epilogue_rows_nb<3, false, NQ>(a, acc, n, cg, f0, t0 + 32 * wave, lane,
-                                              s_red + (ti & 1) * (4 * COP * 2) + wave * (COP * 2), FTR,
-                                              a.act ? s_ctr + (ti & 3) * COP : nullptr);
+          conv_epilogue_rows_nb<2, true>(a, acc, n, cg, f0, t0 + 32 * wave, lane, sr, FTR, sc);
+        else if constexpr (G16) {
+          if (g16) conv_epilogue_rows_nb<3, false, 2, true>(a, acc, n, cg, f0, t0 + 32 * wave, lane, sr, FTR, sc);
+          else conv_epilogue_rows_nb<3, false, NQ>(a, acc, n, cg, f0, t0 + 32 * wave, lane, sr, FTR, sc);
+        } else
+          conv_epilogue_rows_nb<3, false, NQ>(a, acc, n, cg, f0, t0 + 32 * wave, lane, sr, FTR, sc);
       }
       ++ti;
       k += (unsigned)nslots;
@@ -685,9 +788,9 @@ static size_t x6_lds_bytes(int NR, int ftr) {
   return (size_t)(ns * (3 * NR * X6_TW + X6_WU)) * 16 + (size_t)(ns * 3 * ftr * 32 + 2 * 4 * 32 * 2 + 4 * 32) * sizeof(float);
 }
 
-template <int MODE, int FTR, bool OUT16 = false, int NQ = 4>
+template <int MODE, int FTR, bool OUT16 = false, int NQ = 4, bool G16 = false>
 static hipError_t x6_set_attr() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6<MODE, FTR, OUT16, NQ>),
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6<MODE, FTR, OUT16, NQ, G16>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -700,6 +803,7 @@ hipError_t conv_bf16x6_init() {
   if ((e = x6_set_attr<3, 8>()) != hipSuccess) return e;
   if ((e = x6_set_attr<0, 8, true>()) != hipSuccess) return e;
   if ((e = x6_set_attr<0, 8, false, 3>()) != hipSuccess) return e;
+  if ((e = x6_set_attr<0, 8, false, 4, true>()) != hipSuccess) return e;
   if ((e = x6_set_attr<0, 4, true>()) != hipSuccess) return e;
   return x6_set_attr<2, 4>();
 }
@@ -769,7 +873,12 @@ hipError_t launch_conv_bf16x6(const ConvArgs& a_in, int n_samples, hipStream_t s
   // <= 24 output channels in one group: the epilogue variant that skips the padded register quad (MISONET_X6_Q3=0: A/B runs)
   static const int q3_env = [] { const char* e = getenv("MISONET_X6_Q3"); return e ? atoi(e) : 1; }();
   const bool q3 = q3_env && a.ncg == 1 && a.Cout <= 24 && a.out_oct == 3;
-  if (a.out_oct == 4 && ftr == 8) hipLaunchKernelGGL((conv3x3_bf16x6<0, 8, true>), pgrid, dim3(512), x6_lds_bytes(10, 8), s, a, nslots);
+  // Cout % 32 == 16 (the 48-channel conv of the last decoder's dense block): its 16-channel group as two rows in M
+  // (MISONET_X6_G16=0: the padded 32-channel tiles, for A/B runs)
+  static const int g16_env = [] { const char* e = getenv("MISONET_X6_G16"); return e ? atoi(e) : 1; }();
+  const bool g16 = g16_env && mode == 0 && ftr == 8 && a.out_oct == 3 && a.ncg >= 2 && (a.Cout & 31) == 16;
+  if (g16) hipLaunchKernelGGL((conv3x3_bf16x6<0, 8, false, 4, true>), pgrid, dim3(512), x6_lds_bytes(10, 8), s, a, nslots);
+  else if (a.out_oct == 4 && ftr == 8) hipLaunchKernelGGL((conv3x3_bf16x6<0, 8, true>), pgrid, dim3(512), x6_lds_bytes(10, 8), s, a, nslots);
   else if (a.out_oct == 4) hipLaunchKernelGGL((conv3x3_bf16x6<0, 4, true>), pgrid, dim3(512), x6_lds_bytes(6, 4), s, a, nslots);
   else if (rows_in_m) hipLaunchKernelGGL((conv3x3_bf16x6<3, 8>), pgrid, dim3(512), x6_lds_bytes(10, 8), s, a, nslots);
   else if (mode == 0 && ftr == 8 && q3) hipLaunchKernelGGL((conv3x3_bf16x6<0, 8, false, 3>), pgrid, dim3(512), x6_lds_bytes(10, 8), s, a, nslots);

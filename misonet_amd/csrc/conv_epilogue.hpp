@@ -203,7 +203,7 @@ __device__ __forceinline__ void store_oct_row(const float (&v)[16], const __amdg
     }
   }
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < (NQ <= 2 ? 1 : 2); ++k) {          // NQ <= 2 (a 16-channel group): octets 2, 3 do not exist
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
 #pragma unroll
@@ -592,9 +592,47 @@ __device__ __forceinline__ void conv_acc_init_rows(f32x16_t (&acc)[NROW], int tw
   }
 }
 
+// The same for a "two rows in M" tile (conv_bf16x6.hip, chunk_mfma6_rm2): accumulator j holds output rows 2j (registers
+// 0-7) and 2j + 1 (registers 8-15) of a 16-channel group, register i & 7 = table slot i & 7 of that row (the first two
+// register quads of the 32-channel order are exactly the 16 channels of such a group).
+template <int NROW>
+__device__ __forceinline__ void conv_acc_init_rows_rm2(f32x16_t (&acc)[NROW], int tw, int T, int lane, const float* s_bs,
+                                                       const float* s_bl, const float* s_br) {
+  const int half = lane >> 5, l31 = lane & 31;
+  const int t = tw + l31;
+  const bool t_edge = (tw == 0 || tw + 32 >= T);                            // uniform
+#pragma unroll
+  for (int r = 0; r < NROW; ++r) {
+    const float4* pb = reinterpret_cast<const float4*>(s_bs + (r * 2 + half) * 16);
+#pragma unroll
+    for (int q4 = 0; q4 < 2; ++q4) {
+      const float4 q = pb[q4];
+      const int b = 8 * (r & 1) + 4 * q4;
+      acc[r >> 1][b + 0] = q.x; acc[r >> 1][b + 1] = q.y; acc[r >> 1][b + 2] = q.z; acc[r >> 1][b + 3] = q.w;
+    }
+  }
+  if (t_edge) {
+    const float e0 = (t == 0) ? 1.f : 0.f, e1 = (t == T - 1) ? 1.f : 0.f;
+#pragma unroll
+    for (int r = 0; r < NROW; ++r) {
+      const float4* pl = reinterpret_cast<const float4*>(s_bl + (r * 2 + half) * 16);
+      const float4* pr = reinterpret_cast<const float4*>(s_br + (r * 2 + half) * 16);
+#pragma unroll
+      for (int q4 = 0; q4 < 2; ++q4) {
+        const float4 ql = pl[q4], qr = pr[q4];
+        const int b = 8 * (r & 1) + 4 * q4;
+        acc[r >> 1][b + 0] -= e0 * ql.x + e1 * qr.x; acc[r >> 1][b + 1] -= e0 * ql.y + e1 * qr.y;
+        acc[r >> 1][b + 2] -= e0 * ql.z + e1 * qr.z; acc[r >> 1][b + 3] -= e0 * ql.w + e1 * qr.w;
+      }
+    }
+  }
+}
+
 // s_ctr (optional): 16 floats per half-wave in accumulator order, the centre c = ELU(bias) per channel: the row is stored
 // as x - c and the statistics are those of the stored values (conv_epilogue_impl's CENTRE note).
-template <bool MASKED, bool ACT, int NP, bool F16 = false, int NROW = 4, int NQ = 4>
+// RM2: the accumulators are those of a two-rows-in-M tile (row r = registers 8 (r & 1) .. + 7 of accumulator r >> 1: the first
+// NROW / 2 of the array are in use; NQ must be 2).
+template <bool MASKED, bool ACT, int NP, bool F16 = false, int NROW = 4, int NQ = 4, bool RM2 = false>
 __device__ __forceinline__ void conv_epilogue_rows_nb_impl(const ConvArgs& a, f32x16_t (&acc)[NROW], int cg, int f0, int tw,
                                                            int lane, const __amdgpu_buffer_rsrc_t (&rs)[3],
                                                            f32x2_e (&s1)[8], f32x2_e (&s2)[8], int rows,
@@ -636,8 +674,10 @@ __device__ __forceinline__ void conv_epilogue_rows_nb_impl(const ConvArgs& a, f3
     // s_nop at every link (~30 wasted issue slots per 16-value row; the tile epilogue is VALU-issue bound)
 #pragma unroll
     for (int i4 = 0; i4 < NQ; ++i4) {
-      f32x2_e xa = {acc[r][4 * i4], acc[r][4 * i4 + 1]};
-      f32x2_e xb = {acc[r][4 * i4 + 2], acc[r][4 * i4 + 3]};
+      constexpr int AR_SHIFT = RM2 ? 1 : 0;
+      const int ar = r >> AR_SHIFT, ab = RM2 ? 8 * (r & 1) : 0;            // compile-time after unrolling
+      f32x2_e xa = {acc[ar][ab + 4 * i4], acc[ar][ab + 4 * i4 + 1]};
+      f32x2_e xb = {acc[ar][ab + 4 * i4 + 2], acc[ar][ab + 4 * i4 + 3]};
       if (F16) { xa = xa * f32x2_e{a.descale, a.descale}; xb = xb * f32x2_e{a.descale, a.descale}; }
       if (ACT) {                                   // compile-time: a run-time test here becomes a branch per pair and
                                                    // serialises the exp latency of the eight pairs
@@ -683,9 +723,10 @@ __device__ __forceinline__ void conv_epilogue_rows_nb_impl(const ConvArgs& a, f3
 }
 
 // rows: output rows of the tile (4, or 2 for the stride-2 layers of the bf16x3 kernel); NP: bf16 parts of an oct output
-template <int NP = 2, bool F16 = false, int NQ = 4, int NROW>
+template <int NP = 2, bool F16 = false, int NQ = 4, bool RM2 = false, int NROW>
 __device__ __forceinline__ void conv_epilogue_rows_nb(const ConvArgs& a, f32x16_t (&acc)[NROW], int n, int cg, int f0, int tw,
                                                       int lane, float* s_red, int rows = NROW, const float* s_ctr = nullptr) {
+  static_assert(!RM2 || NQ == 2, "two-rows-in-M tiles hold 16-channel groups");
   const int half = lane >> 5;
   const int T = a.T, Tp = a.Tp;
   const bool fast = (tw + 32 <= T) && (f0 + NROW <= a.Fout) && rows == NROW;   // uniform: all 32 frames and all rows exist
@@ -711,10 +752,10 @@ __device__ __forceinline__ void conv_epilogue_rows_nb(const ConvArgs& a, f32x16_
   }
 
   if (a.act) {
-    if (fast) conv_epilogue_rows_nb_impl<false, true, NP, F16, NROW, NQ>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows, s_ctr);
-    else conv_epilogue_rows_nb_impl<true, true, NP, F16, NROW, NQ>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows, s_ctr);
+    if (fast) conv_epilogue_rows_nb_impl<false, true, NP, F16, NROW, NQ, RM2>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows, s_ctr);
+    else conv_epilogue_rows_nb_impl<true, true, NP, F16, NROW, NQ, RM2>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows, s_ctr);
   } else {
-    conv_epilogue_rows_nb_impl<true, false, NP, F16, NROW, NQ>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows);
+    conv_epilogue_rows_nb_impl<true, false, NP, F16, NROW, NQ, RM2>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows);
   }
 
   if (a.act && !(a.dbg & 16)) {
