@@ -132,6 +132,112 @@ def run_steps(enh, mix, clean, out, steps, warmup, dist, L, _lib, profile):
     return dt, list(ms), list(cnt)
 
 
+PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"))
+
+
+def _git_head():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                              timeout=10).stdout.strip() or None
+    except Exception:
+        return None
+
+
+def _pmc_read_db(db_path):
+    """{counter: {kernel: [dispatches, sum]}} and {kernel: [dispatches, total_ns]} of one rocprofv3 --pmc --kernel-trace run
+    (rocpd sqlite output; tools/rocpd_pmc.py / rocpd_stats.py print the same tables)."""
+    import re
+    import sqlite3
+    db = sqlite3.connect(db_path)
+    cur = db.cursor()
+    views = [r[0] for r in cur.execute("select name from sqlite_master where type='view'")]
+    src = "counters_collection" if "counters_collection" in views else "pmc_events"
+    cols = [r[1] for r in cur.execute(f"pragma table_info({src})")]
+    ncol = "kernel_name" if "kernel_name" in cols else "name"
+    ccol = "counter_name" if "counter_name" in cols else "pmc_name"
+    vcol = "value" if "value" in cols else "counter_value"
+    dcol = "dispatch_id" if "dispatch_id" in cols else "id"
+    ctr = {}
+    for name, c, _d, val in cur.execute(f"select {ncol}, {ccol}, {dcol}, sum({vcol}) from {src} group by {ncol}, {ccol}, {dcol}"):
+        a = ctr.setdefault(c, {}).setdefault(re.sub(r"\(.*$", "", name), [0, 0.0])
+        a[0] += 1
+        a[1] += val
+    kcols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    kn = "name" if "name" in kcols else "kernel_name"
+    dur = {}
+    for name, st, en in cur.execute(f"select {kn}, start, end from kernels"):
+        a = dur.setdefault(re.sub(r"\(.*$", "", name), [0, 0])
+        a[0] += 1
+        a[1] += en - st
+    return ctr, dur
+
+
+def pmc_live(precision, B, T, timeout_s=300):
+    """Hardware counters of THIS box at THIS tree: re-executes this script (1 warm-up + 1 timed step, nothing else) under
+    ``rocprofv3 --pmc ... --kernel-trace`` once per counter group -- FETCH_SIZE, WRITE_SIZE (they do not fit one pass),
+    SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE -- and derives, over the conv3x3_* launches, as the guide's HBM / rocprofv3
+    sections prescribe:
+        bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / launches   (FETCH_SIZE counts 1/2 of a wide stream on gfx950)
+        mfma_busy_frac   = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs)
+        clock_ghz        = GRBM_GUI_ACTIVE / 8 / summed kernel duration of the SAME pass
+        useful_over_issued = 6 * algorithmic FLOPs / (SQ_VALU_MFMA_BUSY_CYCLES / 32 * 32768)   (bf16x6: 32-cycle 32x32x16 MFMAs)
+    Returns None when rocprofv3 is missing or a pass fails (the caller falls back to the committed file and says so)."""
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-profile",
+           "--no-alt", "--no-pmc", "--precision", precision, "--batch", str(B), "--frames", str(T)]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    ctr_all, dur_of = {}, {}
+    t_all = time.perf_counter()
+    for grp in PMC_PASSES:
+        d = tempfile.mkdtemp(prefix="misonet_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run([exe, "--pmc", *grp, "--kernel-trace", "-d", d, "-o", "pmc", "--"] + cmd, cwd="/tmp", env=env,
+                               capture_output=True, text=True, timeout=timeout_s)
+            dbs = glob.glob(os.path.join(d, "*.db")) + glob.glob(os.path.join(d, "*", "*.db"))
+            if r.returncode != 0 or not dbs:
+                return None
+            ctr, dur = _pmc_read_db(dbs[0])
+            for c in grp:
+                if c not in ctr:
+                    return None
+                ctr_all[c] = ctr[c]
+                dur_of[c] = dur
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+
+    def conv_sum(c):
+        ks = {k: v for k, v in ctr_all[c].items() if "conv3x3_" in k}
+        return sum(v[1] for v in ks.values()), sum(v[0] for v in ks.values())
+    fetch_kb, n_f = conv_sum("FETCH_SIZE")
+    write_kb, n_w = conv_sum("WRITE_SIZE")
+    busy, n_b = conv_sum("SQ_VALU_MFMA_BUSY_CYCLES")
+    gui, _ = conv_sum("GRBM_GUI_ACTIVE")
+    if not (n_f and n_f == n_w == n_b and gui > 0):
+        return None
+    conv_ns = sum(v[1] for k, v in dur_of["GRBM_GUI_ACTIVE"].items() if "conv3x3_" in k)
+    terms = MODES[precision][1]
+    passes = 2                                                         # warm-up + the timed step
+    flops = passes * B * (N_MIC * conv_flops_per_forward(2 * N_MIC, 2 * N_SPK, T) + N_SPK * conv_flops_per_forward(2 * (N_MIC + 2), 2, T))
+    out = {"conv_launches": int(n_f), "fetch_kb": fetch_kb, "write_kb": write_kb,
+           "bytes_per_launch": int((2.0 * fetch_kb + write_kb) * 1024.0 / n_f),
+           "mfma_busy_frac": round(busy / (1024.0 * gui / 8.0), 4),
+           "clock_ghz_observed": round(gui / 8.0 / conv_ns, 3) if conv_ns else None,
+           "pipeline_passes_profiled": passes, "collect_seconds": round(time.perf_counter() - t_all, 1),
+           "git_head": _git_head()}
+    if terms:                                                          # 32 pipe cycles and 32768 FLOP per 32x32x16 16-bit MFMA
+        out["useful_over_issued_mfma"] = round(terms * flops / (busy / 32.0 * 32768.0), 4)
+    return out
+
+
 def _traffic_entry(precision):
     """measured HBM bytes per conv launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/)"""
     for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
@@ -144,8 +250,9 @@ def _traffic_entry(precision):
     return None, None
 
 
-def roofline_objects(precision, B, T, steps, dt_conv_ms, n_launch):
-    """roofline of the dominant kernel (the 3x3 conv launches) for one precision mode."""
+def roofline_objects(precision, B, T, steps, dt_conv_ms, n_launch, live=None):
+    """roofline of the dominant kernel (the 3x3 conv launches) for one precision mode.  live: pmc_live()'s dict (counters of
+    this box, this tree) or None -> the committed measurement under profiles/, labelled as such."""
     kernel, terms = MODES[precision][:2]
     fl1 = conv_flops_per_forward(2 * N_MIC, 2 * N_SPK, T)
     fl3 = conv_flops_per_forward(2 * (N_MIC + 2), 2, T)
@@ -160,6 +267,8 @@ def roofline_objects(precision, B, T, steps, dt_conv_ms, n_launch):
     ach_tf = flops_step * steps / conv_s / 1e12
     ach_tb = bytes_step * steps / conv_s / 1e12
     tj, tsrc = _traffic_entry(precision)
+    if live:
+        tj, tsrc = live, None
     traffic = tj["bytes_per_launch"] if tj else None
     common = {"kernel": kernel,
               "launches_per_step": int(n_launch // steps), "avg_launch_ms": round(dt_conv_ms / max(n_launch, 1), 4),
@@ -169,11 +278,15 @@ def roofline_objects(precision, B, T, steps, dt_conv_ms, n_launch):
               "layout_gbyte_per_launch": round(lay_step * steps / max(n_launch, 1) / 1e9, 3),
               "traffic": traffic,
               "traffic_over_layout_bytes": round(traffic / (lay_step * steps / max(n_launch, 1)), 3) if traffic else None,
-              "traffic_source": (tsrc + " (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, x2 fetch correction)") if tsrc else None,
-              # the three PMC-derived fields (traffic, mfma_busy_frac_pmc, clock_ghz_observed_pmc) are COMMITTED
-              # measurements of the same command on another box / day, read from that file -- not counters of this run
-              # (counters need their own rocprofv3 --pmc passes); everything else on the line is measured live
-              "pmc_fields_measured_live": False,
+              "traffic_source": ("live: rocprofv3 --pmc passes of this script on this box (FETCH_SIZE x2 + WRITE_SIZE; "
+                                 f"{live.get('conv_launches')} conv launches, {live.get('collect_seconds')} s)") if live
+              else ((tsrc + " (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, x2 fetch correction)") if tsrc else None),
+              # the three PMC-derived fields (traffic, mfma_busy_frac_pmc, clock_ghz_observed_pmc): live = counters of THIS
+              # box at THIS tree (bench.py re-executes itself under rocprofv3 --pmc, one pass per counter group); otherwise
+              # the committed measurement of the same command (another box / day), stamped with the commit it was taken at
+              "pmc_fields_measured_live": bool(live),
+              "pmc_git_head": (live.get("git_head") if live else (tj.get("git_head") if tj else None)),
+              "useful_over_issued_mfma_pmc": tj.get("useful_over_issued_mfma") if tj else None,
               "mfma_busy_frac_pmc": tj.get("mfma_busy_frac") if tj else None,
               # engine clock seen in the PMC pass (the peaks below are the guide's 2.4 GHz figures; under the bf16 MFMA
               # load the part is power-limited)
@@ -318,6 +431,9 @@ def main():
                          "iSTFT, x 32767 -> int16), device-resident and host-resident with overlapped copies; runs by default "
                          "at N = 1 unless --no-alt, this flag forces it")
     ap.add_argument("--no-profile", action="store_true", help="skip the event-instrumented pass (no roofline object)")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not re-execute under rocprofv3 --pmc for the live counters of the roofline object (traffic, matrix-"
+                         "pipe busy fraction, observed clock): ~2 min; the fields then come from profiles/*_traffic.json")
     ap.add_argument("--verify-gather", action="store_true",
                     help="after the timed loop: all_gather every rank's enhanced spectrograms over the process group (RCCL "
                          "on GPUs; 33 MB per rank at batch 16, SURVEY.md 8(e)) and let rank 0 check one utterance that came "
@@ -434,7 +550,10 @@ def main():
         roof, roof2 = None, None
         if prof and prof[3][0] > 0:
             kp, dtp, ms, cnt = prof
-            roof, roof2 = roofline_objects(args.precision, B, T, kp, ms[0], cnt[0])
+            live = None
+            if world == 1 and not args.no_pmc and not args.no_alt:      # (--no-alt = the quick A/B form of this script)
+                live = pmc_live(args.precision, B, T)
+            roof, roof2 = roofline_objects(args.precision, B, T, kp, ms[0], cnt[0], live)
             roof["time_share"] = {"conv_ms_per_step": round(ms[0] / kp, 2), "tcn_ms_per_step": round(ms[1] / kp, 2),
                                   "mvdr_ms_per_step": round(ms[2] / kp, 2), "other_ms_per_step": round(ms[3] / kp, 2)}
             roof["instrumented_steps"] = kp

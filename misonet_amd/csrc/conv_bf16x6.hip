@@ -400,6 +400,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
   const unsigned ntile = (nk - slot + (unsigned)nslots - 1u) / (unsigned)nslots;   // tiles of this workgroup
   const unsigned G = ntile * (unsigned)nchunk;                               // its chunks
 
+  // G16: the channel group of a tile rotates with the workgroup's iteration (K / nslots), so that every workgroup gets
+  // tiles of BOTH groups -- with the plain order a workgroup's tiles all have one (row tile, group) when nslots is a multiple of
+  // nty * ncg (the 48-channel layer: 16 x 2 = 32 slots per XCD), and the two-rows-in-M tiles of the 16-channel group are a
+  // third cheaper: half the workgroups would finish early and wait.  A bijection as long as a block of nslots consecutive
+  // tiles holds whole (group, row tile) sets; results do not depend on which workgroup computes a tile.
+  const unsigned cg_mix = (G16 && ((unsigned)nslots % (unsigned)(a.nty * a.ncg) == 0u)) ? 1u : 0u;
   int t0, f0, n, cg;
 #define TILE_COORDS(K)                                                                                          \
   {                                                                                                             \
@@ -409,7 +415,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
     n = (int)(unit_ / ux);                                                                                      \
     f0 = (int)(tile_ % (unsigned)a.nty) * FTR;                                                                  \
     tile_ /= (unsigned)a.nty;                                                                                   \
-    cg = (int)(tile_ % (unsigned)a.ncg);                                                                        \
+    cg = (int)((tile_ + ((K) / (unsigned)nslots) * cg_mix) % (unsigned)a.ncg);                                   \
     t0 = (int)(tile_ / (unsigned)a.ncg + (unit_ - (unsigned)n * ux)) * TT;                                      \
   }
 
@@ -561,7 +567,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
       const unsigned grp_ = kj_ / per;                                                                          \
       const unsigned tile_ = kj_ - grp_ * per;                                                                  \
       const int pn_ = (int)((grp_ * 8u + xcd) / ux);                                                            \
-      const int pcg_ = (int)((tile_ / (unsigned)a.nty) % (unsigned)a.ncg);                                      \
+      const int pcg_ = (int)((tile_ / (unsigned)a.nty + (kj_ / (unsigned)nslots) * cg_mix) % (unsigned)a.ncg);  \
       const float* sr_ = s_red + ((J) & 1) * (4 * COP * 2);                                                     \
       const int co_l = lane >> 1, which = lane & 1;                                                             \
       const int co = pcg_ * COP + co_l;                                                                         \

@@ -39,7 +39,8 @@ def test_bench_mode_floors():
     """Per-mode floor on the measured roofline fraction of the conv kernels (the bench's own instrumented pass): round 3
     shipped an f32 mode that had silently lost 36 % (88 -> 56 utt/s, frac 0.68 -> 0.43) to register spills.  Boxes differ
     by a few per cent in sustained clocks; the floors sit ~8 % under the measured values (f32 0.68, bf16x6 0.43-0.45)."""
-    r = subprocess.run([sys.executable, "bench.py", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--alt", "f32"],
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--alt", "f32",
+                        "--no-pmc"],
                        cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
@@ -48,6 +49,28 @@ def test_bench_mode_floors():
     f32 = [a for a in d["alt_precision"] if a["dtype"] == "f32"]
     assert f32 and f32[0]["roofline"]["frac"] >= 0.62, f32
     assert f32[0]["value"] >= 80.0, f32[0]["value"]
+
+
+def test_bench_live_pmc_fields():
+    """The roofline object's counter fields come from THIS box and THIS tree: bench.py re-executes itself under
+    ``rocprofv3 --pmc`` (FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE in separate passes)."""
+    import shutil
+    if not (shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3")):
+        pytest.skip("rocprofv3 not installed")
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--alt", ""],
+                       cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    rf = d["roofline"]
+    assert rf["pmc_fields_measured_live"] is True, rf.get("traffic_source")
+    assert rf["traffic_source"].startswith("live")
+    assert 1.2e9 < rf["traffic"] < 3.5e9                                   # 1.39 GB algorithmic (fp32), 2.07 GB in the oct3 layout
+    assert 0.5 < rf["mfma_busy_frac_pmc"] < 0.98
+    assert 1.0 < rf["clock_ghz_observed_pmc"] <= 2.45
+    assert 0.7 < rf["useful_over_issued_mfma_pmc"] <= 1.0
+    # and the wav-in -> int16-out leg is on the same line
+    wp = d["wav_path"]
+    assert wp["host_equals_device_result"] and wp["vs_headline"]["host_resident_overlapped"] > 0.9
 
 
 def test_bench_two_ranks_on_one_device():
