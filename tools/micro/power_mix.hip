@@ -43,9 +43,12 @@ __global__ __launch_bounds__(512, 1) void k(float* out, unsigned long long* cyc,
     unsigned rd = lane + wave * 64;
 #pragma unroll 1
     for (long long it = 0; it < periods; ++it) {
-      for (int q = 0; q < lds; ++q) {                          // operand fragments from LDS (conflict-free, lane-linear)
-        b[q & 3] = __builtin_bit_cast(bf16x8, s_x[rd & 4095]);
-        rd += 256;
+      for (int q = 0; q < lds; q += 4) {                       // operand fragments from LDS (conflict-free, lane-linear),
+        b[0] = __builtin_bit_cast(bf16x8, s_x[rd & 4095]);     // four per trip: constant register indices
+        b[1] = __builtin_bit_cast(bf16x8, s_x[(rd + 256) & 4095]);
+        b[2] = __builtin_bit_cast(bf16x8, s_x[(rd + 512) & 4095]);
+        b[3] = __builtin_bit_cast(bf16x8, s_x[(rd + 768) & 4095]);
+        rd += 1024;
       }
 #pragma unroll
       for (int u = 0; u < 64; ++u)
