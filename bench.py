@@ -143,6 +143,19 @@ def _git_head():
         return None
 
 
+def _source_sha16():
+    """sha256 (first 16 hex digits) over the kernel sources and this script: identifies the tree a counter measurement
+    belongs to on boxes that have no .git (the GPU boxes get a snapshot of the working tree)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "misonet_amd", "csrc", "*.hip")) +
+                    glob.glob(os.path.join(ROOT, "misonet_amd", "csrc", "*.hpp"))) + [os.path.abspath(__file__)]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _pmc_read_db(db_path):
     """{counter: {kernel: [dispatches, sum]}} and {kernel: [dispatches, total_ns]} of one rocprofv3 --pmc --kernel-trace run
     (rocpd sqlite output; tools/rocpd_pmc.py / rocpd_stats.py print the same tables)."""
@@ -232,7 +245,7 @@ def pmc_live(precision, B, T, timeout_s=300):
            "mfma_busy_frac": round(busy / (1024.0 * gui / 8.0), 4),
            "clock_ghz_observed": round(gui / 8.0 / conv_ns, 3) if conv_ns else None,
            "pipeline_passes_profiled": passes, "collect_seconds": round(time.perf_counter() - t_all, 1),
-           "git_head": _git_head()}
+           "git_head": _git_head(), "source_sha16": _source_sha16()}
     if terms:                                                          # 32 pipe cycles and 32768 FLOP per 32x32x16 16-bit MFMA
         out["useful_over_issued_mfma"] = round(terms * flops / (busy / 32.0 * 32768.0), 4)
     return out
@@ -286,6 +299,8 @@ def roofline_objects(precision, B, T, steps, dt_conv_ms, n_launch, live=None):
               # the committed measurement of the same command (another box / day), stamped with the commit it was taken at
               "pmc_fields_measured_live": bool(live),
               "pmc_git_head": (live.get("git_head") if live else (tj.get("git_head") if tj else None)),
+              # the tree the counters belong to (kernel sources + this script); equals source_sha16 of the line when live
+              "pmc_source_sha16": (live.get("source_sha16") if live else (tj.get("source_sha16") if tj else None)),
               "useful_over_issued_mfma_pmc": tj.get("useful_over_issued_mfma") if tj else None,
               "mfma_busy_frac_pmc": tj.get("mfma_busy_frac") if tj else None,
               # engine clock seen in the PMC pass (the peaks below are the guide's 2.4 GHz figures; under the bf16 MFMA
@@ -633,7 +648,7 @@ def main():
             "config": {"workload": workload_name(world, B),
                        "batch_per_gpu": B, "global_batch": world * B, "frames": T, "freq_bins": 129,
                        "parallelism": f"utterance-shard x{world}"},
-            "realtime_factor": round(value * (n / 16000.0), 2),
+            "realtime_factor": round(value * (n / 16000.0), 2), "source_sha16": _source_sha16(),
             "rccl_ranks": rccl_ranks, "per_rank_utt_per_s": [round(v, 3) for v in per_rank],
             "per_rank_utterances": rank_ranges, "backend": (backend if world > 1 else None),
             "parity": (cpu or {}).pop("parity_of_headline", None) if cpu else None,

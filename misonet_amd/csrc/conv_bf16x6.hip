@@ -346,7 +346,9 @@ __device__ __forceinline__ void x6_wait_vm() {
 // epilogue skips the fourth register quad of every row (channels 24-31 of the 32-row MFMA tile are padding).
 // G16: the instantiation for layers whose last output-channel group has 16 channels (Cout % 32 == 16): the tiles of that group
 // run the two-rows-in-M mapping (chunk_mfma6_rm2), the other groups the standard one.
-template <int MODE, int FTR, bool OUT16 = false, int NQ = 4, bool G16 = false>
+// U2: two statistic units per 8-row tile (conv_epilogue_rows_nb): the instantiation for the F <= 31 stride-1 layers, which run
+// on 4-row tiles (<0, 4>) instead when the launch has fewer 8-row tiles than CUs -- bit-identical either way.
+template <int MODE, int FTR, bool OUT16 = false, int NQ = 4, bool G16 = false, bool U2 = false>
 __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int nslots) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (the LDS-DMA builtin has no host form)
   constexpr int COP = 32;
@@ -356,6 +358,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
   static_assert(FTR == 4 || (FTR == 8 && MODE != 1), "8-row tiles: not for the stride-2 layers (17 staged rows)");
   static_assert(!RM || FTR == 8, "rows-in-M tiles are 8 output rows x 4 channels");
   static_assert(!G16 || (MODE == 0 && FTR == 8 && !OUT16 && NQ == 4), "two-rows-in-M groups: stride-1 8-row tiles, oct3 output");
+  static_assert(!U2 || (MODE == 0 && FTR == 8 && !OUT16 && NQ == 4 && !G16), "two statistic units: stride-1 8-row tiles, oct3 output");
+  constexpr int NU = U2 ? 2 : 1;                               // statistic units (partial sets) per tile
   constexpr int NR = (MODE == 0 || RM) ? FTR + 2 : (MODE == 1 ? 9 : FTR / 2 + 1);   // staged input rows of an FTR-row tile
   constexpr int NS = 2;                                        // stages
   constexpr int XN = NR * X6_TW;                               // units per input part image
@@ -365,8 +369,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
   extern __shared__ __align__(16) unsigned char smem_b[];
   bf16x8* s_stage = reinterpret_cast<bf16x8*>(smem_b);         // [NS][SN]
   float* s_tab = reinterpret_cast<float*>(s_stage + NS * SN);  // [NS sets][bs | bl | br][FTR][2][16] (written NS - 1 chunks ahead)
-  float* s_red = s_tab + NS * 3 * FTR * COP;                   // [2 sets][4 waves][COP][2]
-  float* s_ctr = s_red + 2 * 4 * COP * 2;                      // [4 sets][2 half-waves][16]: ELU(bias) per channel, the centre the
+  float* s_red = s_tab + NS * 3 * FTR * COP;                   // [2 sets][NU units][4 waves][COP][2]
+  float* s_ctr = s_red + 2 * NU * 4 * COP * 2;                      // [4 sets][2 half-waves][16]: ELU(bias) per channel, the centre the
                                                                // activations are stored about
 
   const int tid = threadIdx.x;
@@ -568,13 +572,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
       const unsigned tile_ = kj_ - grp_ * per;                                                                  \
       const int pn_ = (int)((grp_ * 8u + xcd) / ux);                                                            \
       const int pcg_ = (int)((tile_ / (unsigned)a.nty + (kj_ / (unsigned)nslots) * cg_mix) % (unsigned)a.ncg);  \
-      const float* sr_ = s_red + ((J) & 1) * (4 * COP * 2);                                                     \
       const int co_l = lane >> 1, which = lane & 1;                                                             \
       const int co = pcg_ * COP + co_l;                                                                         \
       if (co < a.Cout) {                                                                                        \
-        float tot = 0.f;                                                                                        \
-        for (int w = 0; w < 4; ++w) tot += sr_[(w * COP + co_l) * 2 + which];                                   \
-        dstat_add(a.out_stats + (((long long)pn_ * a.out_sstride + a.out_c0 + co) * 2 + which) * DS_NL, (double)tot); \
+        _Pragma("unroll") for (int u_ = 0; u_ < NU; ++u_) {     /* each statistic unit is added exactly, on its own */ \
+          const float* sr_ = s_red + (((J) & 1) * NU + u_) * (4 * COP * 2);                                     \
+          float tot = 0.f;                                                                                      \
+          for (int w = 0; w < 4; ++w) tot += sr_[(w * COP + co_l) * 2 + which];                                 \
+          dstat_add(a.out_stats + (((long long)pn_ * a.out_sstride + a.out_c0 + co) * 2 + which) * DS_NL, (double)tot); \
+        }                                                                                                       \
       }                                                                                                         \
     }                                                                                                           \
   }
@@ -683,14 +689,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
       if constexpr (RM) {
         if (!(a.dbg & 4)) conv_epilogue_rm(a, acc[0], n, f0, t0 + 32 * wave, lane);
       } else if (!(a.dbg & 4)) {
-        float* sr = s_red + (ti & 1) * (4 * COP * 2) + wave * (COP * 2);
+        float* sr = s_red + (ti & 1) * (NU * 4 * COP * 2) + wave * (COP * 2);
         const float* sc = a.act ? s_ctr + (ti & 3) * COP : nullptr;
         if constexpr (OUT16)
           conv_epilogue_rows_nb<2, true>(a, acc, n, cg, f0, t0 + 32 * wave, lane, sr, FTR, sc);
         else if constexpr (G16) {
           if (g16) conv_epilogue_rows_nb<3, false, 2, true>(a, acc, n, cg, f0, t0 + 32 * wave, lane, sr, FTR, sc);
           else conv_epilogue_rows_nb<3, false, NQ>(a, acc, n, cg, f0, t0 + 32 * wave, lane, sr, FTR, sc);
-        } else
+        } else if constexpr (U2)
+          conv_epilogue_rows_nb<3, false, NQ, false, true>(a, acc, n, cg, f0, t0 + 32 * wave, lane, sr, FTR, sc, 4 * COP * 2);
+        else
           conv_epilogue_rows_nb<3, false, NQ>(a, acc, n, cg, f0, t0 + 32 * wave, lane, sr, FTR, sc);
       }
       ++ti;
@@ -789,14 +797,14 @@ __global__ __launch_bounds__(288) void conv_wprep6_k(const float* wf, const dsta
   btab[(long long)n * btab_nstride + ((long long)blockIdx.y * ncg * 32 + cg * 32 + co) * 9 + tap] = (float)bsum;
 }
 
-static size_t x6_lds_bytes(int NR, int ftr) {
-  const int ns = 2;                                  // two stages + epilogue tables + statistics partials
-  return (size_t)(ns * (3 * NR * X6_TW + X6_WU)) * 16 + (size_t)(ns * 3 * ftr * 32 + 2 * 4 * 32 * 2 + 4 * 32) * sizeof(float);
+static size_t x6_lds_bytes(int NR, int ftr, int nu = 1) {
+  const int ns = 2;                                  // two stages + epilogue tables + statistics partials (nu units per tile)
+  return (size_t)(ns * (3 * NR * X6_TW + X6_WU)) * 16 + (size_t)(ns * 3 * ftr * 32 + 2 * nu * 4 * 32 * 2 + 4 * 32) * sizeof(float);
 }
 
-template <int MODE, int FTR, bool OUT16 = false, int NQ = 4, bool G16 = false>
+template <int MODE, int FTR, bool OUT16 = false, int NQ = 4, bool G16 = false, bool U2 = false>
 static hipError_t x6_set_attr() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6<MODE, FTR, OUT16, NQ, G16>),
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6<MODE, FTR, OUT16, NQ, G16, U2>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -810,6 +818,7 @@ hipError_t conv_bf16x6_init() {
   if ((e = x6_set_attr<0, 8, true>()) != hipSuccess) return e;
   if ((e = x6_set_attr<0, 8, false, 3>()) != hipSuccess) return e;
   if ((e = x6_set_attr<0, 8, false, 4, true>()) != hipSuccess) return e;
+  if ((e = x6_set_attr<0, 8, false, 4, false, true>()) != hipSuccess) return e;
   if ((e = x6_set_attr<0, 4, true>()) != hipSuccess) return e;
   return x6_set_attr<2, 4>();
 }
@@ -860,7 +869,18 @@ hipError_t launch_conv_bf16x6(const ConvArgs& a_in, int n_samples, hipStream_t s
   // rows-in-M tiles (MODE 3) for the raw 4-channel output layer (MISONET_X6_RM=0: the 32-channel tiles, for A/B runs)
   static const int rm_env = [] { const char* e = getenv("MISONET_X6_RM"); return e ? atoi(e) : 1; }();
   const bool rows_in_m = rm_env && mode == 0 && a.padf == 2 && !a.act && !a.out_oct && a.Cout <= 4 && a.ncg == 1 && a.Fout > 4;
-  const int ftr = rows_in_m ? 8 : ((mode != 1 && a.Fout > 4 && (ft8 & (mode == 0 ? 1 : 2))) ? 8 : 4);
+  int ftr = rows_in_m ? 8 : ((mode != 1 && a.Fout > 4 && (ft8 & (mode == 0 ? 1 : 2))) ? 8 : 4);
+  // "flexible" layers: stride-1, oct3 in and out, 4 < F <= 31.  Their 8-row kernel forms the statistics per half tile (U2), so
+  // 4-row tiles give the same bits: the launch takes 4-row tiles when 8-row tiles would leave CUs without work (one utterance:
+  // 48 frame-tile columns x ceil(F / 8) row tiles).  MISONET_X6_FLEX=0: always 8-row tiles with one statistic unit (A/B runs).
+  static const int flex_env = [] { const char* e = getenv("MISONET_X6_FLEX"); return e ? atoi(e) : 1; }();
+  const bool flex = flex_env && mode == 0 && ftr == 8 && !rows_in_m && a.out_oct == 3 && a.Fout <= 31 && (a.Cout & 31) == 0;
+  if (flex) {
+    const int g_cus_ = device_cus();
+    const long long ntx_ = (a.T + TT - 1) / TT;
+    const long long tiles8 = (long long)n_samples * ntx_ * ((a.Fout + 7) / 8) * a.ncg;
+    if (g_cus_ > 0 && tiles8 < g_cus_) ftr = 4;
+  }
   (void)conv_grid(a, n_samples, TT, ftr, 1);
   if (n_samples % 8) a.xcd = 2;                                    // columns, not samples, are dealt to the XCDs
   const int g_cus = device_cus();
@@ -884,6 +904,7 @@ hipError_t launch_conv_bf16x6(const ConvArgs& a_in, int n_samples, hipStream_t s
   static const int g16_env = [] { const char* e = getenv("MISONET_X6_G16"); return e ? atoi(e) : 1; }();
   const bool g16 = g16_env && mode == 0 && ftr == 8 && a.out_oct == 3 && a.ncg >= 2 && (a.Cout & 31) == 16;
   if (g16) hipLaunchKernelGGL((conv3x3_bf16x6<0, 8, false, 4, true>), pgrid, dim3(512), x6_lds_bytes(10, 8), s, a, nslots);
+  else if (flex && ftr == 8) hipLaunchKernelGGL((conv3x3_bf16x6<0, 8, false, 4, false, true>), pgrid, dim3(512), x6_lds_bytes(10, 8, 2), s, a, nslots);
   else if (a.out_oct == 4 && ftr == 8) hipLaunchKernelGGL((conv3x3_bf16x6<0, 8, true>), pgrid, dim3(512), x6_lds_bytes(10, 8), s, a, nslots);
   else if (a.out_oct == 4) hipLaunchKernelGGL((conv3x3_bf16x6<0, 4, true>), pgrid, dim3(512), x6_lds_bytes(6, 4), s, a, nslots);
   else if (rows_in_m) hipLaunchKernelGGL((conv3x3_bf16x6<3, 8>), pgrid, dim3(512), x6_lds_bytes(10, 8), s, a, nslots);

@@ -632,7 +632,9 @@ __device__ __forceinline__ void conv_acc_init_rows_rm2(f32x16_t (&acc)[NROW], in
 // as x - c and the statistics are those of the stored values (conv_epilogue_impl's CENTRE note).
 // RM2: the accumulators are those of a two-rows-in-M tile (row r = registers 8 (r & 1) .. + 7 of accumulator r >> 1: the first
 // NROW / 2 of the array are in use; NQ must be 2).
-template <bool MASKED, bool ACT, int NP, bool F16 = false, int NROW = 4, int NQ = 4, bool RM2 = false>
+// RBEG, REND: the rows of the tile this call handles (all of them by default; the two-unit statistics call it per half).
+template <bool MASKED, bool ACT, int NP, bool F16 = false, int NROW = 4, int NQ = 4, bool RM2 = false, int RBEG = 0,
+          int REND = NROW>
 __device__ __forceinline__ void conv_epilogue_rows_nb_impl(const ConvArgs& a, f32x16_t (&acc)[NROW], int cg, int f0, int tw,
                                                            int lane, const __amdgpu_buffer_rsrc_t (&rs)[3],
                                                            f32x2_e (&s1)[8], f32x2_e (&s2)[8], int rows,
@@ -661,7 +663,7 @@ __device__ __forceinline__ void conv_epilogue_rows_nb_impl(const ConvArgs& a, f3
     }
   }
 #pragma unroll
-  for (int r = 0; r < NROW; ++r) {
+  for (int r = RBEG; r < REND; ++r) {
     const int f = f0 + r;
     const bool ok = !MASKED || ((f < a.Fout) && (t < T) && (r < rows));
     const float mf = ok ? 1.f : 0.f;
@@ -723,10 +725,18 @@ __device__ __forceinline__ void conv_epilogue_rows_nb_impl(const ConvArgs& a, f3
 }
 
 // rows: output rows of the tile (4, or 2 for the stride-2 layers of the bf16x3 kernel); NP: bf16 parts of an oct output
-template <int NP = 2, bool F16 = false, int NQ = 4, bool RM2 = false, int NROW>
+// U2 ("two statistic units", NROW = 8): the float partial sums of the statistics are formed per HALF tile (rows 0-3, rows 4-7:
+// two reduce-scatters, two partial sets at s_red and s_red + u2_stride) and each half is added to the exact accumulator on
+// its own.  An 8-row tile then contributes EXACTLY what two 4-row tiles at the same rows contribute, so a layer may run on
+// 4-row tiles when it has fewer 8-row tiles than the chip has CUs (a single utterance) without changing one bit of the result
+// (the batch-invariance tests compare B = 1 with B = 9 bit for bit).  Used for the F <= 31 stride-1 layers only: the
+// second pair of reductions costs ~1.5 % of a tile.
+template <int NP = 2, bool F16 = false, int NQ = 4, bool RM2 = false, bool U2 = false, int NROW>
 __device__ __forceinline__ void conv_epilogue_rows_nb(const ConvArgs& a, f32x16_t (&acc)[NROW], int n, int cg, int f0, int tw,
-                                                      int lane, float* s_red, int rows = NROW, const float* s_ctr = nullptr) {
+                                                      int lane, float* s_red, int rows = NROW, const float* s_ctr = nullptr,
+                                                      int u2_stride = 0) {
   static_assert(!RM2 || NQ == 2, "two-rows-in-M tiles hold 16-channel groups");
+  static_assert(!U2 || (NROW == 8 && !RM2), "two statistic units: 8-row tiles");
   const int half = lane >> 5;
   const int T = a.T, Tp = a.Tp;
   const bool fast = (tw + 32 <= T) && (f0 + NROW <= a.Fout) && rows == NROW;   // uniform: all 32 frames and all rows exist
@@ -750,15 +760,7 @@ __device__ __forceinline__ void conv_epilogue_rows_nb(const ConvArgs& a, f32x16_
     rs[1] = rs[0];
     rs[2] = rs[0];
   }
-
-  if (a.act) {
-    if (fast) conv_epilogue_rows_nb_impl<false, true, NP, F16, NROW, NQ, RM2>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows, s_ctr);
-    else conv_epilogue_rows_nb_impl<true, true, NP, F16, NROW, NQ, RM2>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows, s_ctr);
-  } else {
-    conv_epilogue_rows_nb_impl<true, false, NP, F16, NROW, NQ, RM2>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows);
-  }
-
-  if (a.act && !(a.dbg & 16)) {
+  auto reduce_to = [&](float* dst) {
     float f1[16], f2[16];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { f1[2 * i] = s1[i].x; f1[2 * i + 1] = s1[i].y; f2[2 * i] = s2[i].x; f2[2 * i + 1] = s2[i].y; }
@@ -767,9 +769,29 @@ __device__ __forceinline__ void conv_epilogue_rows_nb(const ConvArgs& a, f32x16_
     if ((lane & 16) == 0) {
       const int q = lane & 15;
       const int co_l = (q & 3) + 8 * (q >> 2) + 4 * half;
-      s_red[co_l * 2 + 0] = x1;
-      s_red[co_l * 2 + 1] = x2;
+      dst[co_l * 2 + 0] = x1;
+      dst[co_l * 2 + 1] = x2;
     }
+  };
+  constexpr int RMID = U2 ? NROW / 2 : NROW;
+
+  if (a.act) {
+    if (fast) conv_epilogue_rows_nb_impl<false, true, NP, F16, NROW, NQ, RM2, 0, RMID>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows, s_ctr);
+    else conv_epilogue_rows_nb_impl<true, true, NP, F16, NROW, NQ, RM2, 0, RMID>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows, s_ctr);
+  } else {
+    conv_epilogue_rows_nb_impl<true, false, NP, F16, NROW, NQ, RM2, 0, RMID>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows);
+  }
+  if (a.act && !(a.dbg & 16)) reduce_to(s_red);
+  if constexpr (U2) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s1[i] = f32x2_e{0.f, 0.f}; s2[i] = f32x2_e{0.f, 0.f}; }
+    if (a.act) {
+      if (fast) conv_epilogue_rows_nb_impl<false, true, NP, F16, NROW, NQ, RM2, RMID, NROW>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows, s_ctr);
+      else conv_epilogue_rows_nb_impl<true, true, NP, F16, NROW, NQ, RM2, RMID, NROW>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows, s_ctr);
+    } else {
+      conv_epilogue_rows_nb_impl<true, false, NP, F16, NROW, NQ, RM2, RMID, NROW>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows);
+    }
+    if (a.act && !(a.dbg & 16)) reduce_to(s_red + u2_stride);
   }
 }
 

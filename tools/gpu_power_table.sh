@@ -23,7 +23,7 @@ sample() {   # median sclk / power while PID $1 lives (skipping its first 1.5 s)
 {
 echo "# synthetic loads: one 512-thread workgroup per CU, 4 MFMA waves (v_mfma_f32_32x32x16_bf16, random operands) + 4 streaming waves"
 echo "# columns: load | in-kernel duty, clock, issued TF/s, HBM TB/s | rocm-smi sclk, socket power"
-for V in "6 0 0 0" "6 0 0 0 1" "6 2 0 0" "6 5 0 0" "6 8 0 0" "6 12 0 0" "6 0 24 0" "6 0 24 11" "6 0 24 22" "6 5 24 11" "6 8 24 11" "6 8 24 22"; do
+for V in "6 0 0 0" "6 0 0 0 1" "6 2 0 0" "6 5 0 0" "6 8 0 0" "6 12 0 0" "6 0 24 0" "6 0 24 16" "6 5 24 16" "6 8 24 16" "6 8 24 32" "6 12 24 32"; do
   $BIN $V > /tmp/pm.out 2>&1 &
   PID=$!
   S=$(sample $PID)

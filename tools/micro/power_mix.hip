@@ -65,15 +65,19 @@ __global__ __launch_bounds__(512, 1) void k(float* out, unsigned long long* cyc,
     // 256 producer threads: each period they fetch units_per_period 16-byte units per workgroup, striding through a
     // buffer far larger than the 256 MB Infinity Cache
     const int ptid = tid - 256;
-    unsigned long long pos = ((unsigned long long)blockIdx.x * 1315423911ull) % hbm_units;
+    const unsigned long long mask = hbm_units - 1;             // power of two
+    unsigned long long pos = ((unsigned long long)blockIdx.x * 1315423911ull) & mask;
     u32x4 sink = {0, 0, 0, 0};
 #pragma unroll 1
     for (long long it = 0; it < periods; ++it) {
-      for (int u = ptid; u < units_per_period; u += 256) {
-        const u32x4 v = hbm[(pos + u) % hbm_units];
-        sink[0] ^= v[0]; sink[1] ^= v[1]; sink[2] ^= v[2]; sink[3] ^= v[3];
+      // units_per_period 16-byte units per workgroup: 256 lanes x nper loads, all issued before the first use
+      const u32x4* base = hbm + ((pos + ptid) & mask & ~255ull) + ptid;
+#pragma unroll 1
+      for (int u = 0; u < units_per_period; u += 256 * 4) {
+        const u32x4 v0 = base[(u + 0) & mask], v1 = base[(u + 256) & mask], v2 = base[(u + 512) & mask], v3 = base[(u + 768) & mask];
+        sink[0] ^= v0[0] ^ v1[1] ^ v2[2] ^ v3[3];
       }
-      pos = (pos + (unsigned long long)units_per_period * 256ull) % hbm_units;   // next period: another region (every CU its own walk)
+      pos = (pos + 65536ull * 257ull) & mask;                  // next period: another region (every CU its own walk)
       __builtin_amdgcn_s_barrier();
     }
     if (sink[0] == 0x12345678u && sink[1] == 0x9abcdef0u) out[tid] = 1.f;          // keep the loads
@@ -86,9 +90,9 @@ int main(int argc, char** argv) {
   const int lds = argc > 3 ? atoi(argv[3]) : 0;
   const double kb = argc > 4 ? atof(argv[4]) : 0.0;
   const float scale = (argc > 5 && atoi(argv[5])) ? 0.f : 1.f;
-  const int units = (int)(kb * 1024.0 / 16.0);
+  const int units = ((int)(kb * 1024.0 / 16.0) + 1023) / 1024 * 1024;   // whole trips of 256 lanes x 4 loads
   float* o; unsigned long long* c; u32x4* hbm;
-  const unsigned long long hbm_bytes = 2ull << 30;             // 2 GB
+  const unsigned long long hbm_bytes = 4ull << 30;             // 4 GB (a power of two; >> the 256 MB Infinity Cache)
   hipMalloc(&o, 1 << 20); hipMalloc(&c, 64); hipMalloc(&hbm, hbm_bytes);
   hipMemset(hbm, 1, hbm_bytes);
   int cus = 256;
@@ -115,5 +119,6 @@ int main(int argc, char** argv) {
   printf("idle=%d lds=%d hbm_kb_per_period=%.1f%s | %.2f s | MFMA duty %.3f | shader clock %.3f GHz | issued %.1f TF/s | HBM %.2f TB/s\n",
          idle, lds, kb, scale == 0.f ? " ZERO-operands" : "", ms * 1e-3, nm * 32.0 / (double)h, (double)h / (ms * 1e6),
          flops / (ms * 1e-3) / 1e12, (double)periods * units * 16.0 * cus / (ms * 1e-3) / 1e12);
+  (void)kb;
   return 0;
 }
