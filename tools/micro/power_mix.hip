@@ -71,10 +71,11 @@ __global__ __launch_bounds__(512, 1) void k(float* out, unsigned long long* cyc,
 #pragma unroll 1
     for (long long it = 0; it < periods; ++it) {
       // units_per_period 16-byte units per workgroup: 256 lanes x nper loads, all issued before the first use
-      const u32x4* base = hbm + ((pos + ptid) & mask & ~255ull) + ptid;
+      const unsigned long long p0 = (pos & ~255ull) + (unsigned long long)ptid;
 #pragma unroll 1
       for (int u = 0; u < units_per_period; u += 256 * 4) {
-        const u32x4 v0 = base[(u + 0) & mask], v1 = base[(u + 256) & mask], v2 = base[(u + 512) & mask], v3 = base[(u + 768) & mask];
+        const u32x4 v0 = hbm[(p0 + u + 0) & mask], v1 = hbm[(p0 + u + 256) & mask], v2 = hbm[(p0 + u + 512) & mask],
+                    v3 = hbm[(p0 + u + 768) & mask];
         sink[0] ^= v0[0] ^ v1[1] ^ v2[2] ^ v3[3];
       }
       pos = (pos + 65536ull * 257ull) & mask;                  // next period: another region (every CU its own walk)
