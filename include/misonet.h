@@ -41,6 +41,12 @@ typedef struct {
   int en_ch[7];
   int de_ch[7];
   int n_freq;                 /* must be 129 (nperseg 256): the encoder must reduce F to one bin */
+  int tcn_norm;               /* ABI 400: `norm_type` of the constructors = the two OUTER norms of every TemporalBlock
+                               * (model.py:530,535, chose_norm model.py:570-581): 0 "IN" (nn.InstanceNorm1d, no parameters;
+                               * config/NN_BSS.yml:123), 1 "gLN" (GlobalLayerNorm: gamma, beta), 2 "cLN"
+                               * (ChannelwiseLayerNorm: gamma, beta), 3 anything else (nn.BatchNorm1d in eval mode: weight,
+                               * bias, running_mean, running_var).  The 2-D blocks hard-code InstanceNorm2d (model.py:413,430)
+                               * and the norm inside DepthwiseSeparableConv is always gLN (model.py:533,537). */
 } misonet_cfg;
 
 const char* misonet_strerror(int code);

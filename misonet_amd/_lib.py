@@ -23,7 +23,7 @@ class MisonetError(RuntimeError):
 
 class Cfg(C.Structure):
     _fields_ = [("in_ch", C.c_int), ("out_ch", C.c_int), ("en_ch", C.c_int * 7), ("de_ch", C.c_int * 7),
-                ("n_freq", C.c_int)]
+                ("n_freq", C.c_int), ("tcn_norm", C.c_int)]       # tcn_norm: 0 IN, 1 gLN, 2 cLN, 3 BatchNorm1d (ABI 400)
 
 
 # name -> (restype, argtypes); every symbol declared in include/misonet.h

@@ -120,9 +120,16 @@ int tcn_part_slots(int T);
 hipError_t launch_tcn_prepare(const float* raw, long long raw_bstride, int raw_c0, const dstat_t* raw_stats, int raw_sstride,
                               float* x, double2* x_part, int C, int T, int Tp, int n_samples, hipStream_t s,
                               int raw_oct3 = 0);   // raw_oct3: source in the bf16x6 oct3 layout
-// d = PReLU(dwconv_dilated(ELU(IN1d(x)))) ; gLN partials of d.  x_np: partials per row of x_part (1 or tcn_part_slots(T))
+// d = PReLU(dwconv_dilated(ELU(norm(x)))) ; gLN partials of d.  x_np: partials per row of x_part (1 or tcn_part_slots(T)).
+// norm = the TemporalBlock's outer norm (model.py:530,535; chose_norm model.py:570-581), norm_kind: 0 InstanceNorm1d;
+// 1 gLN over (C, T) of a sample with (nsc, nsh) = (gamma, beta) per channel; 2 cLN over the channels of every frame with
+// (gamma, beta) and fstat [n][Tp] (mean, rstd) from launch_tcn_cln_stats; 3 BatchNorm1d in eval mode with (nsc, nsh) = the
+// folded (weight / sqrt(running_var + eps), bias - running_mean * that) per channel.
 hipError_t launch_tcn_dw(const float* x, const double2* x_part, int x_np, const float* wdw /*[C][3]*/, const float* prelu /*[1]*/,
-                         float* d, double2* gln_part /*[n][C/4]*/, int C, int T, int Tp, int dilation, int n_samples, hipStream_t s);
+                         float* d, double2* gln_part /*[n][C/4]*/, int C, int T, int Tp, int dilation, int n_samples, hipStream_t s,
+                         int norm_kind = 0, const float* nsc = nullptr, const float* nsh = nullptr, const float2* fstat = nullptr);
+// per-frame mean / rstd over the C channels of x [n][C][Tp] (ChannelwiseLayerNorm, model.py:583-606): fstat [n][Tp]
+hipError_t launch_tcn_cln_stats(const float* x, float2* fstat, int C, int T, int Tp, int n_samples, hipStream_t s);
 // y = pwconv(gLN(d)) (+ residual) ; IN partials of y
 hipError_t launch_tcn_pw(const float* d, const double2* gln_part, const float* gamma, const float* beta,
                          const float* wpw /*packed [C/CK... see tcn.hip]*/, const float* residual /*or nullptr*/,

@@ -108,7 +108,13 @@ struct ConvL {
   float wscale = 1.f;               // f16x3: power of two that brings max |W| of the layer to [32, 64)
 };
 
-struct TcnHalf { int dw, prelu, gamma, beta, pw; long long o_dw, o_prelu, o_gamma, o_beta, o_pw; };
+struct TcnHalf {
+  int dw, prelu, gamma, beta, pw; long long o_dw, o_prelu, o_gamma, o_beta, o_pw;
+  // the OUTER norm in front of this half (model.py:530,535; cfg.tcn_norm): tensors (gLN / cLN: gamma, beta; BatchNorm1d:
+  // weight, bias, running_mean, running_var) and the per-channel (scale, shift) pair the kernels read
+  int on[4] = {-1, -1, -1, -1};
+  long long o_nsc = 0, o_nsh = 0;
+};
 struct TcnBlock { int dilation; TcnHalf h[2]; };
 
 struct Tap { std::string name; int buf, c0, C; bool normalised; };
@@ -126,6 +132,7 @@ struct Layout {
   long long data_base;           // bytes from ws start to the float arena
   long long wps_base, wps_nstride;   // bytes: per-sample folded weights of the layer in flight (DMA dataflow)
   long long btab_base, btab_nstride; // bytes / floats: per-sample border-aware shift table
+  long long fstat_base;              // bytes: [N][Tp] float2 per-frame (mean, rstd) of the cLN outer norm (cfg.tcn_norm == 2)
   long long total_bytes;
 };
 
@@ -197,6 +204,8 @@ static int freq_after_conv(int F, int sf) { return (F - 3) / sf + 1; }
 static int build_plan(misonet_net* n) {
   const misonet_cfg& c = n->cfg;
   if (c.n_freq != 129) return fail(MISONET_EINVAL, "n_freq must be 129 (got %d): the encoder must reduce F to one bin", c.n_freq);
+  if (c.tcn_norm < 0 || c.tcn_norm > 3)
+    return fail(MISONET_EINVAL, "tcn_norm must be 0 (IN), 1 (gLN), 2 (cLN) or 3 (BatchNorm1d, eval) (got %d)", c.tcn_norm);
   if (c.in_ch < 2 || c.in_ch % 2 || c.out_ch < 2 || c.out_ch % 2 || c.in_ch > 64 || c.out_ch > 32)
     return fail(MISONET_EINVAL, "in_ch/out_ch must be even and small (got %d/%d)", c.in_ch, c.out_ch);
   for (int i = 0; i < 7; ++i) {
@@ -271,6 +280,19 @@ static int build_plan(misonet_net* n) {
       TcnBlock tb;
       tb.dilation = 1 << x;
       for (int h = 0; h < 2; ++h) {
+        if (c.tcn_norm) {                          // state_dict order: the norm module precedes its DepthwiseSeparableConv
+          snprintf(nm, sizeof(nm), "TCN.temporal_conv_net.%d.%d.net.%d", r, x, h == 0 ? 0 : 3);
+          const std::string q(nm);
+          if (c.tcn_norm == 3) {
+            tb.h[h].on[0] = add_tensor(n, q + ".weight", 128);
+            tb.h[h].on[1] = add_tensor(n, q + ".bias", 128);
+            tb.h[h].on[2] = add_tensor(n, q + ".running_mean", 128);
+            tb.h[h].on[3] = add_tensor(n, q + ".running_var", 128);
+          } else {
+            tb.h[h].on[0] = add_tensor(n, q + ".gamma", 128);
+            tb.h[h].on[1] = add_tensor(n, q + ".beta", 128);
+          }
+        }
         snprintf(nm, sizeof(nm), "TCN.temporal_conv_net.%d.%d.net.%d.net", r, x, h == 0 ? 2 : 5);
         const std::string p(nm);
         tb.h[h].dw = add_tensor(n, p + ".0.weight", 128 * 3);
@@ -409,7 +431,8 @@ static Layout make_layout(const misonet_net* n, int N, int T, bool ext_in = fals
   L.wps_nstride = wmax;
   L.btab_base = align_up(L.wps_base + wmax * N, 256);
   L.btab_nstride = cmax * 9 * 4;                    // up to 4 shares of the shift table (conv_wprep6_k)
-  L.total_bytes = L.btab_base + L.btab_nstride * 4 * N;
+  L.fstat_base = align_up(L.btab_base + L.btab_nstride * 4 * N, 256);
+  L.total_bytes = L.fstat_base + (n->cfg.tcn_norm == 2 ? (long long)N * L.Tp * 8 : 0);
   return L;
 }
 
@@ -567,12 +590,16 @@ static int forward_planar(misonet_net* n, const Layout& L, void* ws, hipStream_t
     for (int k = 0; k < 14; ++k) {
       const TcnBlock& tb = n->tcn[k];
       const float* W = n->w_dev;
+      const int nk = n->cfg.tcn_norm;
+      float2* fstat = reinterpret_cast<float2*>(reinterpret_cast<char*>(ws) + L.fstat_base);
+      if (nk == 2) HIPCHK(launch_tcn_cln_stats(cur, fstat, 128, T, Tp, N, s));
       HIPCHK(launch_tcn_dw(cur, xs + k * per, k == 0 ? 1 : tslots, W + tb.h[0].o_dw, W + tb.h[0].o_prelu, td, gl + (2 * k) * gper,
-                           128, T, Tp, tb.dilation, N, s));
+                           128, T, Tp, tb.dilation, N, s, nk, W + tb.h[0].o_nsc, W + tb.h[0].o_nsh, fstat));
       HIPCHK(launch_tcn_pw(td, gl + (2 * k) * gper, W + tb.h[0].o_gamma, W + tb.h[0].o_beta, W + tb.h[0].o_pw,
                            nullptr, tp, 128LL * Tp, 0, ps + k * per, 128, T, Tp, N, s, 0, tcn_x6));
+      if (nk == 2) HIPCHK(launch_tcn_cln_stats(tp, fstat, 128, T, Tp, N, s));
       HIPCHK(launch_tcn_dw(tp, ps + k * per, tslots, W + tb.h[1].o_dw, W + tb.h[1].o_prelu, td,
-                           gl + (2 * k + 1) * gper, 128, T, Tp, tb.dilation, N, s));
+                           gl + (2 * k + 1) * gper, 128, T, Tp, tb.dilation, N, s, nk, W + tb.h[1].o_nsc, W + tb.h[1].o_nsh, fstat));
       const bool last = (k == 13);
       float* y = last ? buf_ptr(L, ws, B_D0) : nxt;
       HIPCHK(launch_tcn_pw(td, gl + (2 * k + 1) * gper, W + tb.h[1].o_gamma, W + tb.h[1].o_beta,
@@ -766,6 +793,8 @@ int misonet_net_commit(misonet_net* n) {
       tb.h[h].o_gamma = take(128);
       tb.h[h].o_beta = take(128);
       tb.h[h].o_pw = take(128 * 128);
+      tb.h[h].o_nsc = take(128);
+      tb.h[h].o_nsh = take(128);
     }
   std::vector<float> arena((size_t)off, 0.f);
   for (ConvL& c : n->enc) { pack_conv(n, c, arena); pack_conv_bf16(n, c, arena); pack_conv_wf6(n, c, arena); }
@@ -777,6 +806,18 @@ int misonet_net_commit(misonet_net* n) {
       arena[H.o_prelu] = n->tensors[H.prelu].host[0];
       memcpy(arena.data() + H.o_gamma, n->tensors[H.gamma].host.data(), 128 * sizeof(float));
       memcpy(arena.data() + H.o_beta, n->tensors[H.beta].host.data(), 128 * sizeof(float));
+      if (n->cfg.tcn_norm == 3) {                              // BatchNorm1d in eval mode (run.py:79,106): affine, eps 1e-5
+        const float *w = n->tensors[H.on[0]].host.data(), *b = n->tensors[H.on[1]].host.data(),
+                    *rm = n->tensors[H.on[2]].host.data(), *rv = n->tensors[H.on[3]].host.data();
+        for (int ch = 0; ch < 128; ++ch) {
+          const float sc = w[ch] / sqrtf(rv[ch] + 1e-5f);
+          arena[H.o_nsc + ch] = sc;
+          arena[H.o_nsh + ch] = b[ch] - rm[ch] * sc;
+        }
+      } else if (n->cfg.tcn_norm) {                            // gLN / cLN: gamma, beta
+        memcpy(arena.data() + H.o_nsc, n->tensors[H.on[0]].host.data(), 128 * sizeof(float));
+        memcpy(arena.data() + H.o_nsh, n->tensors[H.on[1]].host.data(), 128 * sizeof(float));
+      }
       const std::vector<float>& P = n->tensors[H.pw].host;     // [co][ci][1] -> [ci][co]
       for (int co = 0; co < 128; ++co)
         for (int ci = 0; ci < 128; ++ci) arena[H.o_pw + (long long)ci * 128 + co] = P[(long long)co * 128 + ci];

@@ -88,17 +88,48 @@ __global__ __launch_bounds__(256) void tcn_prepare_k(const float* raw, long long
 constexpr int DW_MAXT = 2048;                      // frames per row kept in LDS (4 rows x 8 KB)
 constexpr int DW_HALO = 64;                        // largest dilation of TemporalConvNet(2, 7, ...): 2^6
 constexpr int DW_SEG = DW_MAXT - 2 * DW_HALO;      // output frames per segment
+// NORM: the outer norm in front of the ELU (launch_tcn_dw): 0 IN, 1 gLN, 2 cLN, 3 BN (eval).  Every variant is
+// a[t] = ELU(x[t] * sc + sh) with a per-row (sc, sh), except cLN whose (mean, rstd) change per frame.
+template <int NORM>
 __global__ __launch_bounds__(256) void tcn_dw_k(const float* x, const double2* x_part, int x_np, int nps,
                                                 const float* wdw, const float* prelu, float* d, double2* gln_part,
-                                                int C, int T, int Tp, int dil, int seg_f) {
+                                                int C, int T, int Tp, int dil, int seg_f, const float* nsc, const float* nsh,
+                                                const float2* fstat) {
   __shared__ double s_tmp[4][2];
   extern __shared__ __align__(16) float s_a_dyn[];             // [4 rows][row_f]: row_f = frames of a segment + 2 halos
   const int row_f = seg_f + 2 * DW_HALO;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 4 + wave, n = blockIdx.y;
-  float mean, rstd;
-  in_params(tpart_sum(x_part + ((long long)n * C + c) * nps, x_np), T, mean, rstd);
-  const float sc = rstd, sh = -mean * rstd;
+  float sc, sh;
+  if (NORM == 0) {
+    float mean, rstd;
+    in_params(tpart_sum(x_part + ((long long)n * C + c) * nps, x_np), T, mean, rstd);
+    sc = rstd; sh = -mean * rstd;
+  } else if (NORM == 1) {
+    // gLN (model.py:609-632): mean / biased variance over all (C, T) of the sample, eps 1e-8.  The sample's C * x_np
+    // partials are added in a FIXED order: thread i takes rows i, i + 256, ... (their x_np partials in index order), then
+    // the deterministic shuffle / LDS tree of block_sum_256.
+    __shared__ double s_g[4];
+    double a1 = 0.0, a2 = 0.0;
+    for (int r = threadIdx.x; r < C; r += 256) {
+      const double2 q = tpart_sum(x_part + ((long long)n * C + r) * nps, x_np);
+      a1 += q.x; a2 += q.y;
+    }
+    a1 = block_sum_256(a1, s_g);
+    a2 = block_sum_256(a2, s_g);
+    const double cnt = (double)C * (double)T;
+    const double gm = a1 / cnt;
+    double gv = a2 / cnt - gm * gm;
+    gv = gv > 0.0 ? gv : 0.0;
+    const float rstd = (float)(1.0 / sqrt(gv + (double)GLN_EPS));
+    sc = nsc[c] * rstd;
+    sh = nsh[c] - sc * (float)gm;
+  } else if (NORM == 3) {
+    sc = nsc[c]; sh = nsh[c];                                  // BatchNorm1d in eval mode, folded on the host
+  } else {
+    sc = nsc[c]; sh = nsh[c];                                  // cLN: gamma, beta (the per-frame statistics come from fstat)
+  }
+  const float2* fs = NORM == 2 ? fstat + (long long)n * Tp : nullptr;
   const float w0 = wdw[c * 3 + 0], w1 = wdw[c * 3 + 1], w2 = wdw[c * 3 + 2];
   const float slope = prelu[0];
   const float* src = x + ((long long)n * C + c) * Tp;
@@ -113,7 +144,12 @@ __global__ __launch_bounds__(256) void tcn_dw_k(const float* x, const double2* x
       const int t = ts - DW_HALO + j;
       float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
       if (t >= 0 && t < Tq) {                                            // Tp is a multiple of 32 >= Tq
-        const float4 v = *reinterpret_cast<const float4*>(src + t);
+        float4 v = *reinterpret_cast<const float4*>(src + t);
+        if (NORM == 2) {                                       // (x - mean_t) * rstd_t, then gamma_c, beta_c
+          const float4 f01 = *reinterpret_cast<const float4*>(fs + t), f23 = *reinterpret_cast<const float4*>(fs + t + 2);
+          v.x = (v.x - f01.x) * f01.y; v.y = (v.y - f01.z) * f01.w;
+          v.z = (v.z - f23.x) * f23.y; v.w = (v.w - f23.z) * f23.w;
+        }
         o.x = (t + 0 < T) ? elu_fast(fmaf(v.x, sc, sh)) : 0.f;
         o.y = (t + 1 < T) ? elu_fast(fmaf(v.y, sc, sh)) : 0.f;
         o.z = (t + 2 < T) ? elu_fast(fmaf(v.z, sc, sh)) : 0.f;
@@ -413,16 +449,46 @@ hipError_t launch_tcn_prepare(const float* raw, long long raw_bstride, int raw_c
   return hipGetLastError();
 }
 
+// ChannelwiseLayerNorm statistics (model.py:583-606): one thread per frame, two passes over the C channels (mean, then
+// the biased variance about it, as torch.mean / torch.var(unbiased=False)); reads are coalesced along t.
+__global__ __launch_bounds__(256) void tcn_cln_stats_k(const float* x, float2* fstat, int C, int T, int Tp) {
+  const int t = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+  if (t >= Tp) return;
+  float2 o = make_float2(0.f, 0.f);
+  if (t < T) {
+    const float* p = x + (long long)n * C * Tp + t;
+    float m = 0.f;
+    for (int c = 0; c < C; ++c) m += p[(long long)c * Tp];
+    m /= (float)C;
+    float v = 0.f;
+    for (int c = 0; c < C; ++c) { const float dd = p[(long long)c * Tp] - m; v = fmaf(dd, dd, v); }
+    v /= (float)C;
+    o = make_float2(m, 1.f / sqrtf(v + GLN_EPS));
+  }
+  fstat[(long long)n * Tp + t] = o;
+}
+
+hipError_t launch_tcn_cln_stats(const float* x, float2* fstat, int C, int T, int Tp, int n_samples, hipStream_t s) {
+  hipLaunchKernelGGL(tcn_cln_stats_k, dim3((Tp + 255) / 256, n_samples), dim3(256), 0, s, x, fstat, C, T, Tp);
+  return hipGetLastError();
+}
+
 hipError_t launch_tcn_dw(const float* x, const double2* x_part, int x_np, const float* wdw, const float* prelu, float* d,
-                         double2* gln_part, int C, int T, int Tp, int dilation, int n_samples, hipStream_t s) {
+                         double2* gln_part, int C, int T, int Tp, int dilation, int n_samples, hipStream_t s, int norm_kind,
+                         const float* nsc, const float* nsh, const float2* fstat) {
   if (dilation < 1 || dilation > DW_HALO) return hipErrorInvalidValue;
   if (C % 4) return hipErrorInvalidValue;
+  if (norm_kind < 0 || norm_kind > 3 || (norm_kind && (!nsc || !nsh)) || (norm_kind == 2 && !fstat)) return hipErrorInvalidValue;
   // LDS row = the frames of one segment + two halos: a 4-second utterance (T = 1001) takes 18 KB per workgroup instead
   // of the 32 KB of a full 1920-frame segment, i.e. 8 instead of 5 workgroups per CU of this latency-bound kernel
   const int tq = (T + 3) & ~3;
   const int seg_f = tq < DW_SEG ? tq : DW_SEG;
-  hipLaunchKernelGGL(tcn_dw_k, dim3(C / 4, n_samples), dim3(256), (size_t)4 * (seg_f + 2 * DW_HALO) * sizeof(float), s, x,
-                     x_part, x_np, tcn_part_slots(T), wdw, prelu, d, gln_part, C, T, Tp, dilation, seg_f);
+  const dim3 g(C / 4, n_samples);
+  const size_t lds = (size_t)4 * (seg_f + 2 * DW_HALO) * sizeof(float);
+#define MN_DW(K) hipLaunchKernelGGL(tcn_dw_k<K>, g, dim3(256), lds, s, x, x_part, x_np, tcn_part_slots(T), wdw, prelu, d, gln_part, \
+                                    C, T, Tp, dilation, seg_f, nsc, nsh, fstat)
+  if (norm_kind == 0) MN_DW(0); else if (norm_kind == 1) MN_DW(1); else if (norm_kind == 2) MN_DW(2); else MN_DW(3);
+#undef MN_DW
   return hipGetLastError();
 }
 

@@ -32,14 +32,17 @@ class _Trunk:
     def __init__(self, num_spks, num_ch, num_bottleneck, en_bottleneck_channels, de_bottleneck_channels, norm_type):
         if num_bottleneck != 7 or len(en_bottleneck_channels) != 7 or len(de_bottleneck_channels) != 7:
             raise ValueError("misonet_amd supports the reference geometry num_bottleneck = 7 (model.py:40-73)")
-        if norm_type != "IN":
-            raise ValueError('misonet_amd supports norm_type "IN" only (config/NN_BSS.yml:123)')
+        if not isinstance(norm_type, str):
+            raise TypeError("norm_type must be a string (chose_norm, model.py:570-581)")
+        # norm_type selects the two OUTER norms of every TemporalBlock (model.py:530,535): "IN" (the committed config,
+        # config/NN_BSS.yml:123), "gLN", "cLN", anything else = BatchNorm1d (eval mode: running statistics)
+        self.norm_type = norm_type
         self.num_spks, self.num_ch, self.num_bottleneck = int(num_spks), int(num_ch), 7
         self.en_ch = tuple(int(c) for c in en_bottleneck_channels)
         self.de_ch = tuple(int(c) for c in de_bottleneck_channels)
         self.in_ch = 2 * (self.num_ch + self._extra_in)
         self.out_ch = 2 * self.num_spks
-        self.spec = W.tensor_spec(self.in_ch, self.out_ch, self.en_ch, self.de_ch)
+        self.spec = W.tensor_spec(self.in_ch, self.out_ch, self.en_ch, self.de_ch, norm_type)
         self._sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
         self._net = C.c_void_p()
         self._committed = False
@@ -49,10 +52,12 @@ class _Trunk:
         self._keep = False
         self.precision = "bf16x6"      # the library's default (misonet_net.precision in csrc/net.hip): fp32-faithful, the bench's mode
         L = _lib.lib()
-        cfg = _lib.Cfg(self.in_ch, self.out_ch, (C.c_int * 7)(*self.en_ch), (C.c_int * 7)(*self.de_ch), W.N_FREQ)
+        cfg = _lib.Cfg(self.in_ch, self.out_ch, (C.c_int * 7)(*self.en_ch), (C.c_int * 7)(*self.de_ch), W.N_FREQ,
+                       W.norm_kind(norm_type))
         _lib.check(L.misonet_net_create(C.byref(cfg), C.byref(self._net)))
         names = [L.misonet_net_tensor_name(self._net, i).decode() for i in range(L.misonet_net_num_tensors(self._net))]
-        if names != list(self.spec.keys()):
+        # (BatchNorm1d's int64 counter num_batches_tracked lives in the state_dict only: eval mode does not read it)
+        if names != [k for k in self.spec.keys() if not k.endswith(".num_batches_tracked")]:
             raise RuntimeError("library tensor list differs from weights.tensor_spec")
         default_prec = os.environ.get("MISONET_PRECISION")      # e.g. MISONET_PRECISION=bf16x3 for an unmodified harness
         if default_prec:
@@ -139,6 +144,9 @@ class _Trunk:
             v = state_dict[k]
             if isinstance(v, torch.Tensor):
                 v = v.detach().cpu().numpy()
+            if k.endswith(".num_batches_tracked"):                       # BatchNorm1d bookkeeping: kept, not used (eval mode)
+                self._sd[k] = np.asarray(v, dtype=np.int64)
+                continue
             v = np.ascontiguousarray(v, dtype=np.float32)
             if tuple(v.shape) != tuple(shape):
                 raise RuntimeError(f"size mismatch for {k}: copying a param with shape {tuple(v.shape)}, "

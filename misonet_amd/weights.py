@@ -25,13 +25,21 @@ N_FREQ = 129                                     # nperseg 256 (config/NN_BSS.ym
 TCN_REPEATS, TCN_BLOCKS, TCN_CH = 2, 7, 128      # reference model.py:31
 
 
+def norm_kind(norm_type: str) -> int:
+    """``norm_type`` of the reference constructors -> the two OUTER norms of every TemporalBlock (model.py:530,535 through
+    chose_norm, model.py:570-581): 0 "IN" (InstanceNorm1d, no parameters), 1 "gLN", 2 "cLN", 3 anything else (BatchNorm1d)."""
+    return {"IN": 0, "gLN": 1, "cLN": 2}.get(norm_type, 3)
+
+
 def tensor_spec(in_ch: int, out_ch: int,
                 en_ch: Sequence[int] = DEFAULT_EN_CH,
-                de_ch: Sequence[int] = DEFAULT_DE_CH) -> "OrderedDict[str, Tuple[int, ...]]":
+                de_ch: Sequence[int] = DEFAULT_DE_CH, norm_type: str = "IN") -> "OrderedDict[str, Tuple[int, ...]]":
     """Ordered {state_dict key: shape} for a MISO trunk.
 
     in_ch  = 2*num_ch (MISO_1, model.py:16) or 2*(num_ch+2) (MISO_3, model.py:290)
     out_ch = 2*num_spks (model.py:17 / 291)
+    norm_type: the constructors' argument; adds the parameters of the TemporalBlocks' outer norms (gLN / cLN: gamma, beta
+    [1, C, 1]; BatchNorm1d: weight, bias, running_mean, running_var [C] and the int64 scalar num_batches_tracked)
     """
     en = [in_ch] + list(en_ch)
     de = list(de_ch) + [out_ch]
@@ -73,9 +81,20 @@ def tensor_spec(in_ch: int, out_ch: int,
             spec[f"decoders.{b}.0.net.0.bias"] = (cout,)
     # TCN, model.py:486-567
     c = TCN_CH
+    nk = norm_kind(norm_type)
     for r in range(TCN_REPEATS):
         for x in range(TCN_BLOCKS):
             for half in (2, 5):
+                q = f"TCN.temporal_conv_net.{r}.{x}.net.{half - 2}"      # norm_1 = net.0, norm_2 = net.3 (model.py:530-539)
+                if nk in (1, 2):
+                    spec[f"{q}.gamma"] = (1, c, 1)
+                    spec[f"{q}.beta"] = (1, c, 1)
+                elif nk == 3:
+                    spec[f"{q}.weight"] = (c,)
+                    spec[f"{q}.bias"] = (c,)
+                    spec[f"{q}.running_mean"] = (c,)
+                    spec[f"{q}.running_var"] = (c,)
+                    spec[f"{q}.num_batches_tracked"] = ()       # int64 scalar: carried through state_dict, unused in eval
                 p = f"TCN.temporal_conv_net.{r}.{x}.net.{half}.net"
                 spec[f"{p}.0.weight"] = (c, 1, 3)       # depth-wise dilated conv
                 spec[f"{p}.1.weight"] = (1,)            # PReLU slope
@@ -85,12 +104,12 @@ def tensor_spec(in_ch: int, out_ch: int,
     return spec
 
 
-def miso1_spec(num_spks: int = 2, num_ch: int = 6, en_ch=DEFAULT_EN_CH, de_ch=DEFAULT_DE_CH):
-    return tensor_spec(2 * num_ch, 2 * num_spks, en_ch, de_ch)
+def miso1_spec(num_spks: int = 2, num_ch: int = 6, en_ch=DEFAULT_EN_CH, de_ch=DEFAULT_DE_CH, norm_type: str = "IN"):
+    return tensor_spec(2 * num_ch, 2 * num_spks, en_ch, de_ch, norm_type)
 
 
-def miso3_spec(num_spks: int = 1, num_ch: int = 6, en_ch=DEFAULT_EN_CH, de_ch=DEFAULT_DE_CH):
-    return tensor_spec(2 * (num_ch + 2), 2 * num_spks, en_ch, de_ch)
+def miso3_spec(num_spks: int = 1, num_ch: int = 6, en_ch=DEFAULT_EN_CH, de_ch=DEFAULT_DE_CH, norm_type: str = "IN"):
+    return tensor_spec(2 * (num_ch + 2), 2 * num_spks, en_ch, de_ch, norm_type)
 
 
 def _rng(seed: int, key: str) -> np.random.Generator:
@@ -107,7 +126,16 @@ def make_state_dict(spec: "OrderedDict[str, Tuple[int, ...]]", seed: int) -> "Or
     sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
     for key, shape in spec.items():
         r = _rng(seed, key)
-        if key.endswith(".bias"):
+        if key.endswith(".num_batches_tracked"):
+            sd[key] = np.asarray(7, dtype=np.int64)
+            continue
+        if key.endswith(".running_mean"):
+            v = 0.2 * r.standard_normal(shape)
+        elif key.endswith(".running_var"):
+            v = 0.5 + r.uniform(0.0, 1.0, shape)
+        elif len(shape) == 1 and key.endswith(".weight") and shape[0] > 1:      # BatchNorm1d weight
+            v = 1.0 + 0.1 * r.standard_normal(shape)
+        elif key.endswith(".bias"):
             v = 0.1 * r.standard_normal(shape)
         elif key.endswith(".gamma"):
             v = 1.0 + 0.1 * r.standard_normal(shape)

@@ -92,16 +92,36 @@ def _ds_conv(x, sd, p, dilation):
     return F.conv1d(y, _t(sd, f"{p}.3.weight"), None)
 
 
-def tcn_forward(x, sd, taps: Optional[Dict] = None):
-    # TemporalConvNet(2,7,128,128,128,"IN"), model.py:31,486-550
+def _cln(y, gamma, beta):
+    # ChannelwiseLayerNorm, model.py:583-606: statistics over the channels of every frame
+    mean = torch.mean(y, dim=1, keepdim=True)
+    var = torch.var(y, dim=1, keepdim=True, unbiased=False)
+    return gamma * (y - mean) / torch.pow(var + EPS_GLN, 0.5) + beta
+
+
+def _outer_norm(y, sd, q, kind):
+    """chose_norm(norm_type, C) of a TemporalBlock (model.py:530,535,570-581): "IN" = nn.InstanceNorm1d(affine=False),
+    "gLN", "cLN", anything else = nn.BatchNorm1d -- in eval mode (run.py:79,106: the test path calls .eval())."""
+    if kind == "IN":
+        return F.instance_norm(y, eps=1e-5)
+    if kind == "gLN":
+        return _gln(y, _t(sd, f"{q}.gamma"), _t(sd, f"{q}.beta"))
+    if kind == "cLN":
+        return _cln(y, _t(sd, f"{q}.gamma"), _t(sd, f"{q}.beta"))
+    return F.batch_norm(y, _t(sd, f"{q}.running_mean"), _t(sd, f"{q}.running_var"), _t(sd, f"{q}.weight"), _t(sd, f"{q}.bias"),
+                        training=False, eps=1e-5)
+
+
+def tcn_forward(x, sd, taps: Optional[Dict] = None, norm_type: str = "IN"):
+    # TemporalConvNet(2,7,128,128,128,norm_type), model.py:31,486-550
     for r in range(2):
         for blk in range(7):
             d = 2 ** blk
             p = f"TCN.temporal_conv_net.{r}.{blk}.net"
             res = x
-            y = F.elu(F.instance_norm(x, eps=1e-5))
+            y = F.elu(_outer_norm(x, sd, f"{p}.0", norm_type))
             y = _ds_conv(y, sd, f"{p}.2.net", d)
-            y = F.elu(F.instance_norm(y, eps=1e-5))
+            y = F.elu(_outer_norm(y, sd, f"{p}.3", norm_type))
             y = _ds_conv(y, sd, f"{p}.5.net", d)
             x = y + res
             if taps is not None and r == 0 and blk == 0:
@@ -109,7 +129,7 @@ def tcn_forward(x, sd, taps: Optional[Dict] = None):
     return x
 
 
-def trunk_forward(x, sd, taps: Optional[Dict] = None):
+def trunk_forward(x, sd, taps: Optional[Dict] = None, norm_type: str = "IN"):
     """x: float [B, Cin, T, 129] (real||imag channels) -> float [B, Cout, T, 129]."""
     xs = []
     for b in range(7):
@@ -132,7 +152,7 @@ def trunk_forward(x, sd, taps: Optional[Dict] = None):
     # model.py:89: torch.squeeze -> [B,128,T]; TemporalBlock re-adds the batch dim when B == 1 (model.py:546-547)
     assert x.shape[-1] == 1, "encoder must reduce the frequency axis to one bin (n_freq = 129)"
     x = x[..., 0]
-    x = tcn_forward(x, sd, taps)
+    x = tcn_forward(x, sd, taps, norm_type)
     if taps is not None:
         taps["tcn_out"] = x
     de = x.unsqueeze(-1)
@@ -161,17 +181,17 @@ def _split_complex(out):
 
 
 @torch.no_grad()
-def miso1_forward(mixture, sd, taps: Optional[Dict] = None):
+def miso1_forward(mixture, sd, taps: Optional[Dict] = None, norm_type: str = "IN"):
     """mixture complex [B,M,T,129] -> complex64 [B,num_spks,T,129]  (model.py:76-111)."""
     x = torch.cat((mixture.real.to(DTYPE), mixture.imag.to(DTYPE)), dim=1)
-    return _split_complex(trunk_forward(x, sd, taps))
+    return _split_complex(trunk_forward(x, sd, taps, norm_type))
 
 
 @torch.no_grad()
-def miso3_forward(mixture, a, b, sd, taps: Optional[Dict] = None):
+def miso3_forward(mixture, a, b, sd, taps: Optional[Dict] = None, norm_type: str = "IN"):
     """model.py:350-395.  Channel order: real(mix, a, b) then imag(mix, a, b); the reference's
     parameter names for a/b are swapped at the call site (tester.py:1242) -- order is what counts."""
     real = torch.cat((mixture.real.to(DTYPE), a.real.to(DTYPE), b.real.to(DTYPE)), dim=1)
     imag = torch.cat((mixture.imag.to(DTYPE), a.imag.to(DTYPE), b.imag.to(DTYPE)), dim=1)
     x = torch.cat((real, imag), dim=1)
-    return _split_complex(trunk_forward(x, sd, taps))
+    return _split_complex(trunk_forward(x, sd, taps, norm_type))

@@ -7,6 +7,7 @@ import re
 
 import numpy as np
 import pytest
+import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -32,9 +33,9 @@ def test_header_symbols_exported():
     assert lib.misonet_strerror(-4).decode() == "workspace too small"
 
 
-def _make(in_ch=12, out_ch=4, en=(24, 32, 32, 32, 32, 64, 128), de=(128, 64, 32, 32, 32, 32, 24), nf=129):
+def _make(in_ch=12, out_ch=4, en=(24, 32, 32, 32, 32, 64, 128), de=(128, 64, 32, 32, 32, 32, 24), nf=129, tcn_norm=0):
     L = _lib()
-    cfg = L.Cfg(in_ch, out_ch, (C.c_int * 7)(*en), (C.c_int * 7)(*de), nf)
+    cfg = L.Cfg(in_ch, out_ch, (C.c_int * 7)(*en), (C.c_int * 7)(*de), nf, tcn_norm)
     h = C.c_void_p()
     return L, L.lib().misonet_net_create(C.byref(cfg), C.byref(h)), h
 
@@ -95,8 +96,17 @@ def test_host_mirror_requires_library_and_validates():
     from misonet_amd import weights as W
     with pytest.raises(ValueError):
         mz.MISO_1(2, 6, 8, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN")
-    with pytest.raises(ValueError):
-        mz.MISO_1(2, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "BN")
+    # norm_type variants are accepted since round 4 (the outer norms of the TemporalBlocks, model.py:530,535,570-581):
+    # "BN" = BatchNorm1d, whose state_dict carries weight / bias / running statistics and the int64 counter
+    mb = mz.MISO_1(2, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "BN")
+    sdb = W.make_state_dict(W.miso1_spec(norm_type="BN"), 3)
+    mb.load_state_dict(sdb)
+    assert list(mb.state_dict().keys()) == list(sdb.keys())
+    assert mb.state_dict()["TCN.temporal_conv_net.0.0.net.0.num_batches_tracked"].dtype == torch.int64
+    with pytest.raises(RuntimeError):                           # an "IN" checkpoint does not fit a "BN" network
+        mb.load_state_dict(W.make_state_dict(W.miso1_spec(), 0))
+    with pytest.raises(TypeError):
+        mz.MISO_1(2, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), None)
     en = list(W.DEFAULT_EN_CH)
     m = mz.MISO_1(2, 6, 7, en, list(W.DEFAULT_DE_CH), "IN")
     assert en == list(W.DEFAULT_EN_CH)                           # no in-place mutation (model.py:16-17 mutates)
@@ -191,3 +201,21 @@ def test_workspace_plan_never_overlaps_live_buffers(prec):
                 block = max(b for _, b, _, _ in rects)
                 assert block < sum(b - a for a, b, _, _ in rects)      # something is shared
     lib.misonet_net_destroy(h)
+
+
+@pytest.mark.parametrize("nt,kind,extra", [("gLN", 1, 56), ("cLN", 2, 56), ("BN", 3, 112)])
+def test_tensor_registry_norm_type_variants(nt, kind, extra):
+    """norm_type of the constructors (model.py:9, 283) = the outer norms of the 14 TemporalBlocks (model.py:530,535,570-581):
+    the library's tensor list follows the reference's state_dict order for every variant (the float tensors of it; the int64
+    num_batches_tracked of BatchNorm1d stays on the Python side)."""
+    from misonet_amd import weights as W
+    L, rc, h = _make(tcn_norm=kind)
+    assert rc == 0
+    lib = L.lib()
+    names = [lib.misonet_net_tensor_name(h, i).decode() for i in range(lib.misonet_net_num_tensors(h))]
+    spec = W.miso1_spec(norm_type=nt)
+    want = [k for k in spec if not k.endswith(".num_batches_tracked")]
+    assert names == want and len(names) == 268 + extra
+    assert W.norm_kind(nt) == kind and W.norm_kind("IN") == 0 and W.norm_kind("whatever") == 3
+    lib.misonet_net_destroy(h)
+    assert _make(tcn_norm=4)[1] == L.EINVAL and _make(tcn_norm=-1)[1] == L.EINVAL

@@ -2,6 +2,7 @@
 CPU only.  Tolerances: the restatement calls the same ATen/LAPACK back-ends as the reference, so agreement
 is at float32 round-off (1e-5 relative), far inside the 1e-3 parity budget of the GPU path."""
 import numpy as np
+import pytest
 import torch
 
 from conftest import golden, rel_l2, mag_parity
@@ -125,3 +126,23 @@ def test_g10_three_speaker_pit():
     assert len({tuple(r) for r in sel.tolist()}) >= 3, sel
     assert rel_l2(est[:, :, ::2], g["est_even"]) < 2e-5
     assert rel_l2(np.abs(est).sum(-1), g["mag_sum"]) < 2e-5
+
+
+@pytest.mark.parametrize("nt", ["gLN", "cLN", "BN"])
+def test_g11_norm_type_variants(nt):
+    """G11: the real reference built with norm_type = gLN / cLN / anything else (BatchNorm1d, eval) -- the outer norms of the
+    TemporalBlocks (model.py:530,535,570-581).  The oracle restates chose_norm; the spec generator produced key names, order
+    and shapes the reference's own load_state_dict accepted (oracle/gen_golden_norm.py)."""
+    from misonet_amd import weights as W
+    g = golden(f"g11_norm_{nt}_T40.npz")
+    sd = W.make_state_dict(W.miso1_spec(norm_type=nt), seed=3)
+    y = miso_oracle.miso1_forward(torch.from_numpy(g["x"]), sd, norm_type=nt).numpy()
+    assert rel_l2(y, g["y"]) < 2e-5
+    # the variants are really different networks: the IN oracle on the same weights is far from the golden
+    y_in = miso_oracle.miso1_forward(torch.from_numpy(g["x"]), sd, norm_type="IN").numpy()
+    assert rel_l2(y_in, g["y"]) > 1e-2
+    if nt == "cLN":
+        sd3 = W.make_state_dict(W.miso3_spec(norm_type=nt), seed=4)
+        y3 = miso_oracle.miso3_forward(torch.from_numpy(g["x"]), torch.from_numpy(g["a"]), torch.from_numpy(g["b"]), sd3,
+                                       norm_type=nt).numpy()
+        assert rel_l2(y3, g["y3"]) < 2e-5
