@@ -29,7 +29,7 @@ HOT = [
     "mn::conv3x3_bf16x6<2, 8, false, 4, false, false>", "mn::conv3x3_bf16x6<2, 4, false, 4, false, false>",
     "mn::conv3x3_bf16x6<3, 8, false, 4, false, false>", "mn::conv_wprep6_k",
     "mn::tcn_pw_k<false, true>", "mn::tcn_pw_k<true, true>", "mn::tcn_pw_k<false, false>", "mn::tcn_pw_k<true, false>",
-    "mn::tcn_dw_k", "mn::tcn_prepare_k",
+    "mn::tcn_dw_k<0>", "mn::tcn_dw_k<1>", "mn::tcn_dw_k<2>", "mn::tcn_dw_k<3>", "mn::tcn_cln_stats_k", "mn::tcn_prepare_k",
     "mn::mvdr_scm_eig<6>", "mn::mvdr_solve<6>", "mn::mvdr_apply<6>",
     "mn::pack_k", "mn::unpack_k", "mn::assemble3_k", "mn::pit_dist_k<2>", "mn::pit_pick_k<2>", "mn::stft_pack_k",
 ]
