@@ -22,9 +22,9 @@ def main():
         a = agg.setdefault((short, ctr), [0, 0.0])
         a[0] += 1
         a[1] += val
-    lines = [f"{'kernel':44s} {'counter':28s} {'dispatches':>10s} {'sum':>18s} {'per_dispatch':>16s}"]
+    lines = [f"{"kernel":64s} {'counter':28s} {'dispatches':>10s} {'sum':>18s} {'per_dispatch':>16s}"]
     for (k, c), (n, v) in sorted(agg.items(), key=lambda kv: (-kv[1][1], kv[0])):
-        lines.append(f"{k[:44]:44s} {c:28s} {n:10d} {v:18.1f} {v / n:16.1f}")
+        lines.append(f"{k[:64]:64s} {c:28s} {n:10d} {v:18.1f} {v / n:16.1f}")
     out = "\n".join(lines)
     print(out)
     if len(sys.argv) > 2:
