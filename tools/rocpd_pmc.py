@@ -22,7 +22,7 @@ def main():
         a = agg.setdefault((short, ctr), [0, 0.0])
         a[0] += 1
         a[1] += val
-    lines = [f"{"kernel":64s} {'counter':28s} {'dispatches':>10s} {'sum':>18s} {'per_dispatch':>16s}"]
+    lines = [f"{'kernel':64s} {'counter':28s} {'dispatches':>10s} {'sum':>18s} {'per_dispatch':>16s}"]
     for (k, c), (n, v) in sorted(agg.items(), key=lambda kv: (-kv[1][1], kv[0])):
         lines.append(f"{k[:64]:64s} {c:28s} {n:10d} {v:18.1f} {v / n:16.1f}")
     out = "\n".join(lines)
