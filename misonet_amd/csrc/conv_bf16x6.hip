@@ -46,14 +46,6 @@ namespace mn {
 constexpr int X6_TW = 130;                  // staged frames per input row: slot j <-> frame t0 - 1 + j
 constexpr int X6_WPAIR = 3 * 3 * 2 * 32;    // units of the [kf][part][kt0 | kt1][co] image
 constexpr int X6_WU = X6_WPAIR + 3 * 3 * 32;   // + [kf][part][co] of kt = 2: 864 x 16 bytes per (chunk, group)
-// COMPACT images (round 4): a layer of <= 24 output channels (the F = 127 dense blocks) keeps 24 channels per row of the image
-// (27 rows x 24 = 648 units: the padded channels 24-31 were a quarter of its weight bytes), the 16-channel group of a
-// Cout % 32 == 16 layer 16 (432 units, followed by 80 ZERO units for the out-of-band lanes of chunk_mfma6_rm2): fewer
-// LDS-DMA pieces per chunk (11 / 8 instead of 14).  The images keep their X6_WU-unit slots in HBM; only the staged
-// prefix differs.  Lanes past the row width read the next row's units: their MFMA rows are padding nobody reads.
-constexpr int X6_G16_ZERO = 27 * 16;           // first zero unit of a 16-channel image
-constexpr int X6_G16_UNITS = 512;              // staged units of it (8 pieces): 432 + 80 zeros
-__host__ __device__ constexpr int x6_wunits(int cw) { return cw == 16 ? X6_G16_UNITS : 27 * cw; }
 
 template <int SF, bool TR2>
 __device__ __forceinline__ constexpr bool use6(int fr, int kf, int R) {
@@ -64,19 +56,19 @@ __device__ __forceinline__ constexpr bool use6(int fr, int kf, int R) {
 //   sx: the three input part images [part][NR][X6_TW] (16-byte units), sw: the weight image of the chunk.
 // Phase A (time taps 0|1 paired in K): per staged row R three B fragments (h, m, l) and per (fr, kf) six MFMAs;
 // phase B (time tap 2, parts paired in K): two B fragments and three MFMAs per (fr, kf).  Small terms first.
-template <int NR, int SF, bool TR2, int NROW, int CW = 32>
+template <int NR, int SF, bool TR2, int NROW>
 __device__ __forceinline__ void chunk_mfma6(f32x16 (&acc)[NROW], const bf16x8* sx, const bf16x8* sw, int wave, int half,
                                             int l31) {
   constexpr int XN = NR * X6_TW;
-  const int wa = half * CW + l31;                          // + ((kf * 3 + p) * 2) * CW   (CW: channels per image row)
+  const int wa = half * 32 + l31;                          // + ((kf * 3 + p) * 2) * 32
   const int xa = 32 * wave + l31 + half;                   // + p * XN + R * X6_TW     (kt = half)
   bf16x8 A[3][3], B[2][3];
 #pragma unroll
   for (int kf = 0; kf < 3; ++kf)
 #pragma unroll
-    for (int p = 0; p < 3; ++p) A[kf][p] = sw[((kf * 3 + p) * 2) * CW + wa];
+    for (int p = 0; p < 3; ++p) A[kf][p] = sw[((kf * 3 + p) * 2) * 32 + wa];
   // phase-B operands: A2[kf][0] = [w_h | w_h], [1] = [w_m | w_m], [2] = [w_h | w_l]; B2[0] = [x_h | x_m], [1] = [x_l | x_h]
-  const int w2 = 18 * CW + l31;                            // + (kf * 3 + p) * CW
+  const int w2 = X6_WPAIR + l31;                           // + (kf * 3 + p) * 32
   const int p2 = half ? 2 : 0;
   const int xb0 = (half ? XN : 0) + 32 * wave + l31 + 2;
   const int xb1 = (half ? 0 : 2 * XN) + 32 * wave + l31 + 2;
@@ -96,9 +88,9 @@ __device__ __forceinline__ void chunk_mfma6(f32x16 (&acc)[NROW], const bf16x8* s
       // the weight fragments of phase B, one step ahead of their first use
 #pragma unroll
       for (int kf = 0; kf < 3; ++kf) {
-        A2[kf][0] = sw[w2 + (kf * 3 + 0) * CW];
-        A2[kf][1] = sw[w2 + (kf * 3 + 1) * CW];
-        A2[kf][2] = sw[w2 + (kf * 3 + p2) * CW];
+        A2[kf][0] = sw[w2 + (kf * 3 + 0) * 32];
+        A2[kf][1] = sw[w2 + (kf * 3 + 1) * 32];
+        A2[kf][2] = sw[w2 + (kf * 3 + p2) * 32];
       }
     }
     __builtin_amdgcn_sched_barrier(0);     // keep the next step's ds_reads AHEAD of this step's MFMAs
@@ -142,8 +134,8 @@ __device__ __forceinline__ void chunk_mfma6(f32x16 (&acc)[NROW], const bf16x8* s
 // stores keep their layout), and a staged input row R is multiplied by the BANDED weight fragment
 // A_dR[(d, co)] = W[kf = dR - d][co], dR = R - 2j in 0..3 (zero outside 0 <= kf <= 2): 4 staged rows x 9 MFMAs per row pair
 // instead of 2 x 3 x 9 = 144 instead of 216 MFMAs per chunk and wave.
-//   sw: the 16-channel COMPACT image of the group (27 rows x 16 units) followed by 80 zero units: a lane outside the band
-//       reads zero units -- no masking instructions.
+//   sw: the STANDARD weight image of the group (channels 16-31 of it are zero padding): a lane outside the band reads the
+//       unit of padded channel co + 16, i.e. zeros -- no masking instructions.
 template <int NR, int NROW>
 __device__ __forceinline__ void chunk_mfma6_rm2(f32x16 (&acc)[NROW], const bf16x8* sx, const bf16x8* sw, int wave, int half,
                                                 int l31) {
@@ -164,14 +156,14 @@ __device__ __forceinline__ void chunk_mfma6_rm2(f32x16 (&acc)[NROW], const bf16x
   for (int dR = 0; dR < 4; ++dR) {
     const int kf = dR - d;
     const bool in_band = (unsigned)kf < 3u;
-    wa[dR] = in_band ? (kf * 3 * 2) * 16 + half * 16 + co : X6_G16_ZERO + co;            // + (p * 2) * 16  (zeros: .. + 64 + 15)
-    w2[dR] = in_band ? 18 * 16 + (kf * 3) * 16 + co : X6_G16_ZERO + co;                  // + p * 16
+    wa[dR] = in_band ? (kf * 3 * 2) * 32 + half * 32 + co : half * 32 + co + 16;         // + (p * 2) * 32
+    w2[dR] = X6_WPAIR + (in_band ? (kf * 3) * 32 + co : co + 16);                         // + p * 32
   }
   bf16x8 A[4][3], A2[4][3], B[2][3], B2[2][2];
 #pragma unroll
   for (int dR = 0; dR < 4; ++dR)
 #pragma unroll
-    for (int p = 0; p < 3; ++p) A[dR][p] = sw[wa[dR] + (p * 2) * 16];
+    for (int p = 0; p < 3; ++p) A[dR][p] = sw[wa[dR] + (p * 2) * 32];
   constexpr int NSTEP = 2 * NR;
 #pragma unroll
   for (int st = -1; st < NSTEP; ++st) {
@@ -187,9 +179,9 @@ __device__ __forceinline__ void chunk_mfma6_rm2(f32x16 (&acc)[NROW], const bf16x
       // the weight fragments of phase B: [w_h | w_h], [w_m | w_m], [w_h | w_l], one step ahead of their first use
 #pragma unroll
       for (int dR = 0; dR < 4; ++dR) {
-        A2[dR][0] = sw[w2[dR] + 0 * 16];
-        A2[dR][1] = sw[w2[dR] + 1 * 16];
-        A2[dR][2] = sw[w2[dR] + p2 * 16];
+        A2[dR][0] = sw[w2[dR] + 0 * 32];
+        A2[dR][1] = sw[w2[dR] + 1 * 32];
+        A2[dR][2] = sw[w2[dR] + p2 * 32];
       }
     }
     __builtin_amdgcn_sched_barrier(0);     // keep the next step's ds_reads AHEAD of this step's MFMAs
@@ -368,7 +360,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
   static_assert(!G16 || (MODE == 0 && FTR == 8 && !OUT16 && NQ == 4), "two-rows-in-M groups: stride-1 8-row tiles, oct3 output");
   static_assert(!U2 || (MODE == 0 && FTR == 8 && !OUT16 && NQ == 4 && !G16), "two statistic units: stride-1 8-row tiles, oct3 output");
   constexpr int NU = U2 ? 2 : 1;                               // statistic units (partial sets) per tile
-  constexpr int CW = (NQ == 3 && MODE == 0 && FTR == 8 && !OUT16) ? 24 : 32;   // channels per row of the staged weight image
   constexpr int NR = (MODE == 0 || RM) ? FTR + 2 : (MODE == 1 ? 9 : FTR / 2 + 1);   // staged input rows of an FTR-row tile
   constexpr int NS = 2;                                        // stages
   constexpr int XN = NR * X6_TW;                               // units per input part image
@@ -449,7 +440,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
     }
     const int btab_parts = nchunk >= 8 ? 4 : (nchunk >= 4 ? 2 : 1);          // conv_bf16x6_btab_parts
     __amdgpu_buffer_rsrc_t rs_x0, rs_x1, rs_x2, rs_w;
-    int wu_n = X6_WU;
     unsigned xo[NXI];
     int xr_[NXI], xj_[NXI];                                    // staged row / slot of this lane's units (the same in every tile)
 #pragma unroll
@@ -469,7 +459,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
     rs_x2 = make_rsrc_e(in_b_ + 2 * part_b, in_rec);                                                            \
     rs_w = make_rsrc_e(reinterpret_cast<unsigned long long>(a.wps) + (unsigned long long)n * a.wps_nstride +    \
                            (unsigned long long)cg * wbytes, wbytes);                                            \
-    wu_n = x6_wunits((G16 && cg == a.ncg - 1) ? 16 : CW);       /* staged units of this tile's weight image */  \
     _Pragma("unroll") for (int i = 0; i < NXI; ++i) {                                                           \
       const int fin = fin0_ + xr_[i];                                                                           \
       const int t = t0 - 1 + xj_[i];                                                                            \
@@ -500,8 +489,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
     } else                                                                                                      \
     _Pragma("unroll") for (int i = 0; i < NWI; ++i) {                                                           \
       const int ub = (i * 4 + rw) * 64;                                                                         \
-      if (ub < wu_n && !(a.dbg & 128)) {                                                                        \
-        if (ub + 64 <= wu_n || ub + lane < wu_n)                                                                \
+      if (ub < X6_WU && !(a.dbg & 128)) {                                                                       \
+        if (ub + 64 <= X6_WU || ub + lane < X6_WU)                                                              \
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, MN_LDS(st_ + 3 * XN + ub), 16, wo + (unsigned)i * 4096u, \
                                                    wsoff_, 0, 0);                                               \
       }                                                                                                         \
@@ -690,7 +679,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
           else if constexpr (G16) {
             if (g16) chunk_mfma6_rm2<NR, FTR>(acc, st, st + 3 * XN, wave, half, l31);
             else chunk_mfma6<NR, SF, TR2, FTR>(acc, st, st + 3 * XN, wave, half, l31);
-          } else chunk_mfma6<NR, SF, TR2, FTR, CW>(acc, st, st + 3 * XN, wave, half, l31);
+          } else chunk_mfma6<NR, SF, TR2, FTR>(acc, st, st + 3 * XN, wave, half, l31);
           __builtin_amdgcn_s_setprio(0);
         }
         STAMP(ti);
@@ -735,7 +724,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
 __global__ __launch_bounds__(288) void conv_wprep6_k(const float* wf, const dstat_t* in_stats, int in_sstride, int in_c0,
                                                      int Cin, int ident_c, int Fin, int T, int nchunk, int ncg,
                                                      u32x4_t* wps, long long wps_nstride_b, float* btab,
-                                                     long long btab_nstride, int nparts, int wrow, int wrow_last) {
+                                                     long long btab_nstride, int nparts) {
   extern __shared__ float2 s_nrm[];                  // [nchunk*8] (scale, shift)
   const int n = blockIdx.x / ncg, cg = blockIdx.x - n * ncg;
   const int tid = threadIdx.x;
@@ -763,14 +752,8 @@ __global__ __launch_bounds__(288) void conv_wprep6_k(const float* wf, const dsta
   const float* wsrc = wf + ((long long)cg * nchunk * 9 + tap) * (32 * 8) + co * 8;
   u32x4_t* wdst = reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(wps) + (long long)n * wps_nstride_b) +
                   (long long)cg * nchunk * X6_WU;
-  // channels per image row of THIS group (compact images: conv_bf16x6_weight_rows); channels past it are padding and are
-  // not written -- except behind a 16-channel image, where 80 of those threads keep the zero units zero (the per-sample
-  // image buffer is shared by all layers, so whatever the previous layer left there has to go)
-  const int cw = (cg == ncg - 1) ? wrow_last : wrow;
-  const bool live = co < cw;
-  const int ubase = kt < 2 ? (kf * 3 * 2 + kt) * cw + co : 18 * cw + (kf * 3) * cw + co;
-  const int ustep = kt < 2 ? 2 * cw : cw;            // units between the parts
-  const int zunit = (cw == 16 && !live && tap * 16 + (co - 16) < X6_G16_UNITS - X6_G16_ZERO) ? X6_G16_ZERO + tap * 16 + (co - 16) : -1;
+  const int ubase = kt < 2 ? (kf * 3 * 2 + kt) * 32 + co : X6_WPAIR + (kf * 3) * 32 + co;
+  const int ustep = kt < 2 ? 2 * 32 : 32;            // units between the parts
   double bsum = 0.0;
   constexpr int U = 4;                               // chunks per batch: the loads of a batch are issued together
   for (int kc0 = kc_lo; kc0 < kc_hi; kc0 += U) {
@@ -805,13 +788,9 @@ __global__ __launch_bounds__(288) void conv_wprep6_k(const float* wf, const dsta
           ph[e2] = a_; pm[e2] = b_; pl[e2] = c_;
         }
         u32x4_t* d = wdst + (long long)kc * X6_WU + ubase;
-        if (live) {
-          d[0] = ph;
-          d[ustep] = pm;
-          d[2 * ustep] = pl;
-        } else if (zunit >= 0) {
-          wdst[(long long)kc * X6_WU + zunit] = u32x4_t{0u, 0u, 0u, 0u};
-        }
+        d[0] = ph;
+        d[ustep] = pm;
+        d[2 * ustep] = pl;
       }
     }
   }
@@ -853,34 +832,13 @@ int conv_bf16x6_btab_parts(int Cin) {                // shares of the shift tabl
   return nchunk >= 8 ? 4 : (nchunk >= 4 ? 2 : 1);
 }
 
-// Tile / image geometry of a layer: a function of the LAYER (and of the A/B environment switches) only -- never of the
-// sample count -- shared by the weight fold and the conv launch so that both agree on the image the producers stage.
-struct X6Geom { int mode, ftr; bool rows_in_m, g16, q3; int wrow, wrow_last; };
-static X6Geom x6_geom(const ConvArgs& a) {
-  static const int ft8 = [] { const char* e = getenv("MISONET_X6_ROWS8"); return e ? atoi(e) : 3; }();   // bit 0: stride-1, bit 1: transposed
-  static const int rm_env = [] { const char* e = getenv("MISONET_X6_RM"); return e ? atoi(e) : 1; }();
-  static const int g16_env = [] { const char* e = getenv("MISONET_X6_G16"); return e ? atoi(e) : 1; }();
-  static const int q3_env = [] { const char* e = getenv("MISONET_X6_Q3"); return e ? atoi(e) : 1; }();
-  static const int cw_env = [] { const char* e = getenv("MISONET_X6_COMPACT"); return e ? atoi(e) : 1; }();   // 0: 32-wide images (A/B runs)
-  X6Geom g;
-  g.mode = a.tr2 ? 2 : (a.sf == 2 ? 1 : 0);
-  g.rows_in_m = rm_env && g.mode == 0 && a.padf == 2 && !a.act && !a.out_oct && a.Cout <= 4 && a.ncg == 1 && a.Fout > 4;
-  g.ftr = g.rows_in_m ? 8 : ((g.mode != 1 && a.Fout > 4 && (ft8 & (g.mode == 0 ? 1 : 2))) ? 8 : 4);
-  g.g16 = g16_env && g.mode == 0 && g.ftr == 8 && a.out_oct == 3 && a.ncg >= 2 && (a.Cout & 31) == 16;
-  g.q3 = q3_env && g.mode == 0 && g.ftr == 8 && a.ncg == 1 && a.Cout <= 24 && a.out_oct == 3;
-  g.wrow = (cw_env && g.q3) ? 24 : 32;
-  g.wrow_last = g.g16 ? 16 : g.wrow;
-  return g;
-}
-
 hipError_t launch_conv_wprep6(const ConvArgs& a, const float* wf, int n_samples, hipStream_t s) {
   const int nchunk = a.Cin >> 3;
   const int nparts = conv_bf16x6_btab_parts(a.Cin);
-  const X6Geom gm = x6_geom(a);
   hipLaunchKernelGGL(conv_wprep6_k, dim3(n_samples * a.ncg, nparts), dim3(288), (size_t)nchunk * 8 * sizeof(float2), s, wf,
                      a.in_stats, a.in_sstride, a.in_c0, a.Cin, a.ident_c, a.Fin, a.T, nchunk, a.ncg,
                      reinterpret_cast<u32x4_t*>(const_cast<void*>(a.wps)), a.wps_nstride, const_cast<float*>(a.btab),
-                     a.btab_nstride, nparts, gm.wrow, gm.wrow_last);
+                     a.btab_nstride, nparts);
   return hipGetLastError();
 }
 
@@ -904,13 +862,14 @@ hipError_t launch_conv_bf16x6(const ConvArgs& a_in, int n_samples, hipStream_t s
     if (!tl_buf && hipMalloc(reinterpret_cast<void**>(&tl_buf), 64 * 8) != hipSuccess) tl_buf = nullptr;
     if (tl_buf) { (void)hipMemsetAsync(tl_buf, 0, 64 * 8, s); a.dbg_buf = tl_buf; }
   }
-  const X6Geom gm = x6_geom(a);
-  const int mode = gm.mode;
+  const int mode = a.tr2 ? 2 : (a.sf == 2 ? 1 : 0);
   // tile geometry: 128 frames x 8 rows for the stride-1 layers with more than 4 rows (10 staged rows per 8 instead of
-  // 6 per 4 and one weight image per 216 instead of 108 MFMAs: 25 % fewer staged bytes per MFMA), else x 4 rows; rows-in-M
-  // tiles (MODE 3) for the raw 4-channel output layer (x6_geom)
-  const bool rows_in_m = gm.rows_in_m;
-  int ftr = gm.ftr;
+  // 6 per 4 and one weight image per 216 instead of 108 MFMAs: 25 % fewer staged bytes per MFMA), else x 4 rows
+  static const int ft8 = [] { const char* e = getenv("MISONET_X6_ROWS8"); return e ? atoi(e) : 3; }();   // bit 0: stride-1, bit 1: transposed
+  // rows-in-M tiles (MODE 3) for the raw 4-channel output layer (MISONET_X6_RM=0: the 32-channel tiles, for A/B runs)
+  static const int rm_env = [] { const char* e = getenv("MISONET_X6_RM"); return e ? atoi(e) : 1; }();
+  const bool rows_in_m = rm_env && mode == 0 && a.padf == 2 && !a.act && !a.out_oct && a.Cout <= 4 && a.ncg == 1 && a.Fout > 4;
+  int ftr = rows_in_m ? 8 : ((mode != 1 && a.Fout > 4 && (ft8 & (mode == 0 ? 1 : 2))) ? 8 : 4);
   // "flexible" layers: stride-1, oct3 in and out, 4 < F <= 31.  Their 8-row kernel forms the statistics per half tile (U2), so
   // 4-row tiles give the same bits: the launch takes 4-row tiles when 8-row tiles would leave CUs without work (one utterance:
   // 48 frame-tile columns x ceil(F / 8) row tiles).  MISONET_X6_FLEX=0: always 8-row tiles with one statistic unit (A/B runs).
@@ -938,10 +897,12 @@ hipError_t launch_conv_bf16x6(const ConvArgs& a_in, int n_samples, hipStream_t s
   }
   const dim3 pgrid((unsigned)(8 * nslots), 1, 1);
   // <= 24 output channels in one group: the epilogue variant that skips the padded register quad (MISONET_X6_Q3=0: A/B runs)
-  const bool q3 = gm.q3 && gm.wrow == 24;      // (MISONET_X6_COMPACT=0 runs the 32-wide image on the NQ = 4 instantiation)
+  static const int q3_env = [] { const char* e = getenv("MISONET_X6_Q3"); return e ? atoi(e) : 1; }();
+  const bool q3 = q3_env && a.ncg == 1 && a.Cout <= 24 && a.out_oct == 3;
   // Cout % 32 == 16 (the 48-channel conv of the last decoder's dense block): its 16-channel group as two rows in M
   // (MISONET_X6_G16=0: the padded 32-channel tiles, for A/B runs)
-  const bool g16 = gm.g16;
+  static const int g16_env = [] { const char* e = getenv("MISONET_X6_G16"); return e ? atoi(e) : 1; }();
+  const bool g16 = g16_env && mode == 0 && ftr == 8 && a.out_oct == 3 && a.ncg >= 2 && (a.Cout & 31) == 16;
   if (g16) hipLaunchKernelGGL((conv3x3_bf16x6<0, 8, false, 4, true>), pgrid, dim3(512), x6_lds_bytes(10, 8), s, a, nslots);
   else if (flex && ftr == 8) hipLaunchKernelGGL((conv3x3_bf16x6<0, 8, false, 4, false, true>), pgrid, dim3(512), x6_lds_bytes(10, 8, 2), s, a, nslots);
   else if (a.out_oct == 4 && ftr == 8) hipLaunchKernelGGL((conv3x3_bf16x6<0, 8, true>), pgrid, dim3(512), x6_lds_bytes(10, 8), s, a, nslots);

@@ -55,9 +55,6 @@ struct ConvArgs {
   long long wps_nstride;    // bytes between samples (0: one image shared by all samples)
   const float* btab;        // [n][ncg*32][9] border-aware shift table: sum_ci W[co][ci][tap] * shift[ci], or nullptr
   long long btab_nstride;   // floats between samples
-  int wrow, wrow_last;      // bf16x6: output channels per row of the folded weight image (conv_bf16x6_weight_rows): 32; 24 for a
-                            // layer of <= 24 output channels; wrow_last = 16 for the LAST group of a Cout % 32 == 16 layer
-                            // (its image is followed by 80 zero units: the out-of-band lanes of the two-rows-in-M tiles)
   int xcd;                  // 1: 1-D grid with the XCD-aware tile order of conv_tile() (ntx, nty, nsamp valid)
   int ntx, nty, nsamp;      // frame tiles, row tiles, samples of this launch
   unsigned long long* dbg_buf;   // timeline stamps of one workgroup (MISONET_TIMELINE=1, experiments only)
