@@ -185,7 +185,7 @@ def _pmc_read_db(db_path):
     return ctr, dur
 
 
-def pmc_live(precision, B, T, timeout_s=300):
+def pmc_live(precision, B, T, timeout_s=150):
     """Hardware counters of THIS box at THIS tree: re-executes this script (1 warm-up + 1 timed step, nothing else) under
     ``rocprofv3 --pmc ... --kernel-trace`` once per counter group -- FETCH_SIZE, WRITE_SIZE (they do not fit one pass),
     SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE -- and derives, over the conv3x3_* launches, as the guide's HBM / rocprofv3
