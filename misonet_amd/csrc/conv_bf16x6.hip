@@ -56,7 +56,11 @@ __device__ __forceinline__ constexpr bool use6(int fr, int kf, int R) {
 //   sx: the three input part images [part][NR][X6_TW] (16-byte units), sw: the weight image of the chunk.
 // Phase A (time taps 0|1 paired in K): per staged row R three B fragments (h, m, l) and per (fr, kf) six MFMAs;
 // phase B (time tap 2, parts paired in K): two B fragments and three MFMAs per (fr, kf).  Small terms first.
-template <int NR, int SF, bool TR2, int NROW>
+// RMASK / VR (the F = 1 bottleneck pair, round 4): bit R of RMASK = staged row R holds an input row that EXISTS in every tile
+// of the layer, VR = output rows that exist.  Steps of staged rows outside the mask and output rows >= VR are compiled
+// out: the products they would add are exact zeros (zero-filled rows) or belong to rows nobody stores, so the results are
+// bit-identical to the full tile's.  Defaults = the full tile.
+template <int NR, int SF, bool TR2, int NROW, unsigned RMASK = 0xffffffffu, int VR = NROW>
 __device__ __forceinline__ void chunk_mfma6(f32x16 (&acc)[NROW], const bf16x8* sx, const bf16x8* sw, int wave, int half,
                                             int l31) {
   constexpr int XN = NR * X6_TW;
@@ -77,12 +81,16 @@ __device__ __forceinline__ void chunk_mfma6(f32x16 (&acc)[NROW], const bf16x8* s
 #pragma unroll
   for (int st = -1; st < NSTEP; ++st) {
     if (st + 1 < NR) {
+      if ((RMASK >> (st + 1)) & 1u) {
 #pragma unroll
-      for (int p = 0; p < 3; ++p) B[(st + 1) & 1][p] = sx[p * XN + (st + 1) * X6_TW + xa];
+        for (int p = 0; p < 3; ++p) B[(st + 1) & 1][p] = sx[p * XN + (st + 1) * X6_TW + xa];
+      }
     } else if (st + 1 < NSTEP) {
       const int R_ = st + 1 - NR;
-      B2[(st + 1) & 1][0] = sx[xb0 + R_ * X6_TW];
-      B2[(st + 1) & 1][1] = sx[xb1 + R_ * X6_TW];
+      if ((RMASK >> R_) & 1u) {
+        B2[(st + 1) & 1][0] = sx[xb0 + R_ * X6_TW];
+        B2[(st + 1) & 1][1] = sx[xb1 + R_ * X6_TW];
+      }
     }
     if (st == NR - 2 || (NR == 1 && st == -1)) {
       // the weight fragments of phase B, one step ahead of their first use
@@ -102,10 +110,10 @@ __device__ __forceinline__ void chunk_mfma6(f32x16 (&acc)[NROW], const bf16x8* s
         const int ap = term == 0 ? 2 : ((term == 2 || term == 3) ? 1 : 0);
         const int bp = term == 1 ? 2 : ((term == 2 || term == 4) ? 1 : 0);
 #pragma unroll
-        for (int fr = 0; fr < NROW; ++fr)
+        for (int fr = 0; fr < VR; ++fr)
 #pragma unroll
           for (int kf = 0; kf < 3; ++kf)
-            if (use6<SF, TR2>(fr, kf, R))
+            if (use6<SF, TR2>(fr, kf, R) && ((RMASK >> R) & 1u))
               acc[fr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[kf][ap], B[cur][bp], acc[fr], 0, 0, 0);
       }
     } else if (st >= NR) {
@@ -115,10 +123,10 @@ __device__ __forceinline__ void chunk_mfma6(f32x16 (&acc)[NROW], const bf16x8* s
         const int aq = 2 - term;
         const int bq = term == 0 ? 1 : 0;
 #pragma unroll
-        for (int fr = 0; fr < NROW; ++fr)
+        for (int fr = 0; fr < VR; ++fr)
 #pragma unroll
           for (int kf = 0; kf < 3; ++kf)
-            if (use6<SF, TR2>(fr, kf, R))
+            if (use6<SF, TR2>(fr, kf, R) && ((RMASK >> R) & 1u))
               acc[fr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2[kf][aq], B2[cur][bq], acc[fr], 0, 0, 0);
       }
     }
@@ -348,7 +356,12 @@ __device__ __forceinline__ void x6_wait_vm() {
 // run the two-rows-in-M mapping (chunk_mfma6_rm2), the other groups the standard one.
 // U2: two statistic units per 8-row tile (conv_epilogue_rows_nb): the instantiation for the F <= 31 stride-1 layers, which run
 // on 4-row tiles (<0, 4>) instead when the launch has fewer 8-row tiles than CUs -- bit-identical either way.
-template <int MODE, int FTR, bool OUT16 = false, int NQ = 4, bool G16 = false, bool U2 = false>
+// BN: the two stride-1 layers around the F = 1 bottleneck (reference model.py:50-52, 64: encoder 6, 3 -> 1 bins; decoder 0's
+// transposed conv, 1 -> 3 bins) on 4-row tiles of which only some staged rows hold input rows and some output rows exist:
+// BN = 1: staged rows 0-2 real, output row 0 exists; BN = 2: staged row 2 real, output rows 0-2 exist.  The MFMA steps, the
+// operand reads and the LDS-DMA pieces of everything else are compiled out (chunk_mfma6's RMASK / VR): 27 instead of 108
+// MFMAs and 33 / 20 instead of 51 KB per chunk.
+template <int MODE, int FTR, bool OUT16 = false, int NQ = 4, bool G16 = false, bool U2 = false, int BN = 0>
 __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int nslots) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (the LDS-DMA builtin has no host form)
   constexpr int COP = 32;
@@ -360,6 +373,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
   static_assert(!G16 || (MODE == 0 && FTR == 8 && !OUT16 && NQ == 4), "two-rows-in-M groups: stride-1 8-row tiles, oct3 output");
   static_assert(!U2 || (MODE == 0 && FTR == 8 && !OUT16 && NQ == 4 && !G16), "two statistic units: stride-1 8-row tiles, oct3 output");
   constexpr int NU = U2 ? 2 : 1;                               // statistic units (partial sets) per tile
+  static_assert(BN == 0 || (MODE == 0 && FTR == 4 && !OUT16 && NQ == 4 && !G16 && !U2), "bottleneck variants: stride-1 4-row tiles");
+  constexpr unsigned RMASK = BN == 1 ? 0x7u : (BN == 2 ? 0x4u : 0xffffffffu);   // staged rows that hold input rows
+  constexpr int VR = BN == 1 ? 1 : (BN == 2 ? 3 : FTR);        // output rows that exist
   constexpr int NR = (MODE == 0 || RM) ? FTR + 2 : (MODE == 1 ? 9 : FTR / 2 + 1);   // staged input rows of an FTR-row tile
   constexpr int NS = 2;                                        // stages
   constexpr int XN = NR * X6_TW;                               // units per input part image
@@ -473,7 +489,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
     bf16x8* st_ = s_stage + (SB) * SN;                                                                          \
     _Pragma("unroll") for (int i = 0; i < NXI; ++i) {                                                           \
       const int ub = (i * 4 + rw) * 64;                                                                         \
-      if (ub < XN) {                                                                                            \
+      /* (bottleneck variants: pieces that lie entirely in staged rows nobody reads are not fetched) */         \
+      const bool need_ = BN == 0 || (((RMASK >> (ub / X6_TW)) | (RMASK >> ((ub + 63) / X6_TW))) & 1u);          \
+      if (ub < XN && need_) {                                                                                   \
         if (ub + 64 <= XN || ub + lane < XN) {                                                                  \
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x0, MN_LDS(st_ + ub), 16, xo[i], 0, 0, 0);                \
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x1, MN_LDS(st_ + XN + ub), 16, xo[i], 0, 0, 0);           \
@@ -679,7 +697,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
           else if constexpr (G16) {
             if (g16) chunk_mfma6_rm2<NR, FTR>(acc, st, st + 3 * XN, wave, half, l31);
             else chunk_mfma6<NR, SF, TR2, FTR>(acc, st, st + 3 * XN, wave, half, l31);
-          } else chunk_mfma6<NR, SF, TR2, FTR>(acc, st, st + 3 * XN, wave, half, l31);
+          } else chunk_mfma6<NR, SF, TR2, FTR, RMASK, VR>(acc, st, st + 3 * XN, wave, half, l31);
           __builtin_amdgcn_s_setprio(0);
         }
         STAMP(ti);
@@ -699,7 +717,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
         } else if constexpr (U2)
           conv_epilogue_rows_nb<3, false, NQ, false, true>(a, acc, n, cg, f0, t0 + 32 * wave, lane, sr, FTR, sc, 4 * COP * 2);
         else
-          conv_epilogue_rows_nb<3, false, NQ>(a, acc, n, cg, f0, t0 + 32 * wave, lane, sr, FTR, sc);
+          conv_epilogue_rows_nb<3, false, NQ, false, false, (BN ? VR : 0)>(a, acc, n, cg, f0, t0 + 32 * wave, lane, sr, FTR, sc);
       }
       ++ti;
       k += (unsigned)nslots;
@@ -802,9 +820,9 @@ static size_t x6_lds_bytes(int NR, int ftr, int nu = 1) {
   return (size_t)(ns * (3 * NR * X6_TW + X6_WU)) * 16 + (size_t)(ns * 3 * ftr * 32 + 2 * nu * 4 * 32 * 2 + 4 * 32) * sizeof(float);
 }
 
-template <int MODE, int FTR, bool OUT16 = false, int NQ = 4, bool G16 = false, bool U2 = false>
+template <int MODE, int FTR, bool OUT16 = false, int NQ = 4, bool G16 = false, bool U2 = false, int BN = 0>
 static hipError_t x6_set_attr() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6<MODE, FTR, OUT16, NQ, G16, U2>),
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6<MODE, FTR, OUT16, NQ, G16, U2, BN>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -819,6 +837,8 @@ hipError_t conv_bf16x6_init() {
   if ((e = x6_set_attr<0, 8, false, 3>()) != hipSuccess) return e;
   if ((e = x6_set_attr<0, 8, false, 4, true>()) != hipSuccess) return e;
   if ((e = x6_set_attr<0, 8, false, 4, false, true>()) != hipSuccess) return e;
+  if ((e = x6_set_attr<0, 4, false, 4, false, false, 1>()) != hipSuccess) return e;
+  if ((e = x6_set_attr<0, 4, false, 4, false, false, 2>()) != hipSuccess) return e;
   if ((e = x6_set_attr<0, 4, true>()) != hipSuccess) return e;
   return x6_set_attr<2, 4>();
 }
@@ -899,6 +919,10 @@ hipError_t launch_conv_bf16x6(const ConvArgs& a_in, int n_samples, hipStream_t s
   // <= 24 output channels in one group: the epilogue variant that skips the padded register quad (MISONET_X6_Q3=0: A/B runs)
   static const int q3_env = [] { const char* e = getenv("MISONET_X6_Q3"); return e ? atoi(e) : 1; }();
   const bool q3 = q3_env && a.ncg == 1 && a.Cout <= 24 && a.out_oct == 3;
+  // the F = 1 bottleneck pair on their reduced 4-row tiles (MISONET_X6_BN=0: the full tiles, for A/B runs)
+  static const int bn_env = [] { const char* e = getenv("MISONET_X6_BN"); return e ? atoi(e) : 1; }();
+  const int bn = (!bn_env || mode != 0 || ftr != 4 || a.out_oct != 3 || a.nty != 1) ? 0
+                 : ((a.Fin == 3 && a.Fout == 1 && a.padf == 0) ? 1 : ((a.Fin == 1 && a.Fout == 3 && a.padf == 2) ? 2 : 0));
   // Cout % 32 == 16 (the 48-channel conv of the last decoder's dense block): its 16-channel group as two rows in M
   // (MISONET_X6_G16=0: the padded 32-channel tiles, for A/B runs)
   static const int g16_env = [] { const char* e = getenv("MISONET_X6_G16"); return e ? atoi(e) : 1; }();
@@ -910,6 +934,8 @@ hipError_t launch_conv_bf16x6(const ConvArgs& a_in, int n_samples, hipStream_t s
   else if (rows_in_m) hipLaunchKernelGGL((conv3x3_bf16x6<3, 8>), pgrid, dim3(512), x6_lds_bytes(10, 8), s, a, nslots);
   else if (mode == 0 && ftr == 8 && q3) hipLaunchKernelGGL((conv3x3_bf16x6<0, 8, false, 3>), pgrid, dim3(512), x6_lds_bytes(10, 8), s, a, nslots);
   else if (mode == 0 && ftr == 8) hipLaunchKernelGGL((conv3x3_bf16x6<0, 8>), pgrid, dim3(512), x6_lds_bytes(10, 8), s, a, nslots);
+  else if (mode == 0 && bn == 1) hipLaunchKernelGGL((conv3x3_bf16x6<0, 4, false, 4, false, false, 1>), pgrid, dim3(512), x6_lds_bytes(6, 4), s, a, nslots);
+  else if (mode == 0 && bn == 2) hipLaunchKernelGGL((conv3x3_bf16x6<0, 4, false, 4, false, false, 2>), pgrid, dim3(512), x6_lds_bytes(6, 4), s, a, nslots);
   else if (mode == 0) hipLaunchKernelGGL((conv3x3_bf16x6<0, 4>), pgrid, dim3(512), x6_lds_bytes(6, 4), s, a, nslots);
   else if (mode == 1) hipLaunchKernelGGL((conv3x3_bf16x6<1, 4>), pgrid, dim3(512), x6_lds_bytes(9, 4), s, a, nslots);
   else if (ftr == 8) hipLaunchKernelGGL((conv3x3_bf16x6<2, 8>), pgrid, dim3(512), x6_lds_bytes(5, 8), s, a, nslots);

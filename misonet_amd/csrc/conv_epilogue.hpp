@@ -731,7 +731,9 @@ __device__ __forceinline__ void conv_epilogue_rows_nb_impl(const ConvArgs& a, f3
 // 4-row tiles when it has fewer 8-row tiles than the chip has CUs (a single utterance) without changing one bit of the result
 // (the batch-invariance tests compare B = 1 with B = 9 bit for bit).  Used for the F <= 31 stride-1 layers only: the
 // second pair of reductions costs ~1.5 % of a tile.
-template <int NP = 2, bool F16 = false, int NQ = 4, bool RM2 = false, bool U2 = false, int NROW>
+// VR: output rows of the tile that can exist at all (default: all): rows >= VR are not post-processed (the F = 1 bottleneck
+// layers run 4-row tiles of which 1 / 3 rows exist).
+template <int NP = 2, bool F16 = false, int NQ = 4, bool RM2 = false, bool U2 = false, int VR = 0, int NROW>
 __device__ __forceinline__ void conv_epilogue_rows_nb(const ConvArgs& a, f32x16_t (&acc)[NROW], int n, int cg, int f0, int tw,
                                                       int lane, float* s_red, int rows = NROW, const float* s_ctr = nullptr,
                                                       int u2_stride = 0) {
@@ -773,7 +775,8 @@ __device__ __forceinline__ void conv_epilogue_rows_nb(const ConvArgs& a, f32x16_
       dst[co_l * 2 + 1] = x2;
     }
   };
-  constexpr int RMID = U2 ? NROW / 2 : NROW;
+  constexpr int RMID = U2 ? NROW / 2 : (VR > 0 ? VR : NROW);
+  static_assert(!(U2 && VR > 0), "either two statistic units or a reduced row count");
 
   if (a.act) {
     if (fast) conv_epilogue_rows_nb_impl<false, true, NP, F16, NROW, NQ, RM2, 0, RMID>(a, acc, cg, f0, tw, lane, rs, s1, s2, rows, s_ctr);

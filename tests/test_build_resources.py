@@ -22,12 +22,13 @@ HOT = [
     "mn::conv3x3_mfma<1, 2, 0, false>",                                            # f32: stride-2 transposed convs
     "mn::conv3x3_mfma<1, 0, 0, true>", "mn::conv3x3_mfma<1, 0, 3, true>",          # first layer (12 input channels)
     "mn::conv3x3_mfma<1, 0, 3, false>",                                            # MISO3 first layer in bf16x6
-    "mn::conv3x3_bf16x6<0, 8, false, 4, false, false>", "mn::conv3x3_bf16x6<0, 8, false, 3, false, false>",    # 38 % + 28 % of the bf16x6 step
-    "mn::conv3x3_bf16x6<0, 8, false, 4, false, true>",                             # F <= 31 layers (two statistic units)
-    "mn::conv3x3_bf16x6<0, 8, false, 4, true, false>",                             # the 48-channel layer (10 %)
-    "mn::conv3x3_bf16x6<0, 4, false, 4, false, false>", "mn::conv3x3_bf16x6<1, 4, false, 4, false, false>",
-    "mn::conv3x3_bf16x6<2, 8, false, 4, false, false>", "mn::conv3x3_bf16x6<2, 4, false, 4, false, false>",
-    "mn::conv3x3_bf16x6<3, 8, false, 4, false, false>", "mn::conv_wprep6_k",
+    "mn::conv3x3_bf16x6<0, 8, false, 4, false, false, 0>", "mn::conv3x3_bf16x6<0, 8, false, 3, false, false, 0>",    # 38 % + 28 % of the bf16x6 step
+    "mn::conv3x3_bf16x6<0, 8, false, 4, false, true, 0>",                             # F <= 31 layers (two statistic units)
+    "mn::conv3x3_bf16x6<0, 8, false, 4, true, false, 0>",                             # the 48-channel layer (10 %)
+    "mn::conv3x3_bf16x6<0, 4, false, 4, false, false, 0>", "mn::conv3x3_bf16x6<1, 4, false, 4, false, false, 0>",
+    "mn::conv3x3_bf16x6<2, 8, false, 4, false, false, 0>", "mn::conv3x3_bf16x6<2, 4, false, 4, false, false, 0>",
+    "mn::conv3x3_bf16x6<3, 8, false, 4, false, false, 0>", "mn::conv_wprep6_k",
+    "mn::conv3x3_bf16x6<0, 4, false, 4, false, false, 1>", "mn::conv3x3_bf16x6<0, 4, false, 4, false, false, 2>",   # F = 1 pair
     "mn::tcn_pw_k<false, true>", "mn::tcn_pw_k<true, true>", "mn::tcn_pw_k<false, false>", "mn::tcn_pw_k<true, false>",
     "mn::tcn_dw_k<0>", "mn::tcn_dw_k<1>", "mn::tcn_dw_k<2>", "mn::tcn_dw_k<3>", "mn::tcn_cln_stats_k", "mn::tcn_prepare_k",
     "mn::mvdr_scm_eig<6>", "mn::mvdr_solve<6>", "mn::mvdr_apply<6>",
@@ -40,7 +41,7 @@ TOLERATED = {
     "mn::conv3x3_mfma<2, 0, 3, false>": 64, "mn::conv3x3_mfma<2, 0, 4, false>": 32,      # 64-channel planar-in / oct-out: unused
     "mn::conv3x3_mfma<2, 2, 0, false>": 400, "mn::conv3x3_mfma<2, 2, 3, false>": 480,    # stride-2 transposed, > 32 channels: unused
     "mn::conv3x3_mfma<2, 2, 4, false>": 320,
-    "mn::conv3x3_bf16x6<0, 8, true, 4, false, false>": 224,                                     # f16x3 hand-over layer (alt mode)
+    "mn::conv3x3_bf16x6<0, 8, true, 4, false, false, 0>": 224,                                     # f16x3 hand-over layer (alt mode)
     "mn::conv3x3_bf16x3<2, 1>": 32,                                                      # bf16x3p (alt mode)
     "mn::mvdr_scm_eig<8>": 600,                                                          # M = 8 microphones (tests only)
 }
@@ -61,7 +62,7 @@ def table():
 # The G16 instantiation (two chunk bodies and two epilogues in one persistent kernel) keeps 26 loop-invariant values of its
 # tile set-up in scratch: they are written once per workgroup and re-loaded a few times per TILE (~150 k cycles); its two
 # MFMA loops contain no scratch access (checked on the ISA, LAB.md round 4).
-HOT_SCRATCH_ALLOWED = {"mn::conv3x3_bf16x6<2, 8, false, 4, false, false>": 8, "mn::conv3x3_bf16x6<0, 8, false, 4, true, false>": 112}
+HOT_SCRATCH_ALLOWED = {"mn::conv3x3_bf16x6<2, 8, false, 4, false, false, 0>": 8, "mn::conv3x3_bf16x6<0, 8, false, 4, true, false, 0>": 112}
 
 
 def test_hot_kernels_do_not_spill(table):
@@ -88,8 +89,8 @@ def test_no_other_kernel_spills_unnoticed(table):
 
 def test_headline_kernel_occupancy(table):
     # the persistent bf16x6 kernels are written for ONE 512-thread workgroup per CU = 2 waves per SIMD: <= 256 VGPRs
-    for k in ("mn::conv3x3_bf16x6<0, 8, false, 4, false, false>", "mn::conv3x3_bf16x6<0, 8, false, 3, false, false>",
-              "mn::conv3x3_bf16x6<0, 8, false, 4, false, true>"):
+    for k in ("mn::conv3x3_bf16x6<0, 8, false, 4, false, false, 0>", "mn::conv3x3_bf16x6<0, 8, false, 3, false, false, 0>",
+              "mn::conv3x3_bf16x6<0, 8, false, 4, false, true, 0>"):
         assert table[k]["vgprs"] <= 256 and table[k]["occupancy"] >= 2, table[k]
     # the f32 32-channel kernel is tuned for three workgroups per CU (<= 168 VGPRs)
     assert table["mn::conv3x3_mfma<1, 0, 0, false>"]["vgprs"] <= 168
