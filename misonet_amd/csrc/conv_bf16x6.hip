@@ -224,6 +224,25 @@ __device__ __forceinline__ void chunk_mfma6_rm2(f32x16 (&acc)[NROW], const bf16x
   }
 }
 
+// Same-padded stride-1 8-row tiles (padf = 1): the first row tile's staged row 0 and the last row tile's staged rows 8, 9
+// are the zero padding of the image, and with F = 8 k + 7 (every dense-block level: F = 127 ... 7) the last tile's output
+// row 7 does not exist.  One body per tile position (chosen per tile, wave-uniform) with those steps compiled out: 4 % /
+// 17 % / 21 % fewer MFMAs in a first / last / only tile -- 1.3 % of a level's MFMAs at F = 127, 10 % at F = 15 -- and
+// bit-identical results (the skipped products are exact zeros or belong to the missing row).  padf != 1 (the stride-1
+// transposed layers: padf = 2) runs the full body.
+template <int NR, int SF, bool TR2, int NROW, bool EDGE>
+__device__ __forceinline__ void chunk_mfma6_pos(f32x16 (&acc)[NROW], const bf16x8* sx, const bf16x8* sw, int wave, int half,
+                                                int l31, int tpos) {
+  if constexpr (EDGE && NROW == 8 && NR == 10) {
+    if (tpos == 0) chunk_mfma6<NR, SF, TR2, NROW>(acc, sx, sw, wave, half, l31);
+    else if (tpos == 1) chunk_mfma6<NR, SF, TR2, NROW, 0x3FEu, 8>(acc, sx, sw, wave, half, l31);
+    else if (tpos == 2) chunk_mfma6<NR, SF, TR2, NROW, 0x0FFu, 7>(acc, sx, sw, wave, half, l31);
+    else chunk_mfma6<NR, SF, TR2, NROW, 0x0FEu, 7>(acc, sx, sw, wave, half, l31);
+  } else {
+    chunk_mfma6<NR, SF, TR2, NROW>(acc, sx, sw, wave, half, l31);
+  }
+}
+
 // MODE 3, "rows in M": a stride-1 layer with Cout <= 4 -- the network's last transposed conv, 48 -> 2 * num_spks channels at
 // F = 129 (reference model.py:418-423, 64).  With channels on the 32 MFMA rows it uses 4 of them.  Here the rows are
 // (output row d = 0..7) x (channel co = 0..3): ONE accumulator tile holds a wave's whole 8-row x 4-channel x 32-frame
@@ -375,6 +394,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
   constexpr int NU = U2 ? 2 : 1;                               // statistic units (partial sets) per tile
   static_assert(BN == 0 || (MODE == 0 && FTR == 4 && !OUT16 && NQ == 4 && !G16 && !U2), "bottleneck variants: stride-1 4-row tiles");
   constexpr unsigned RMASK = BN == 1 ? 0x7u : (BN == 2 ? 0x4u : 0xffffffffu);   // staged rows that hold input rows
+  // same-padded stride-1 8-row tiles (the dense blocks: padf = 1, F = 2^k - 1): edge tiles skip their padding rows
+  constexpr bool EDGE = MODE == 0 && FTR == 8 && !OUT16 && BN == 0;
   constexpr int VR = BN == 1 ? 1 : (BN == 2 ? 3 : FTR);        // output rows that exist
   constexpr int NR = (MODE == 0 || RM) ? FTR + 2 : (MODE == 1 ? 9 : FTR / 2 + 1);   // staged input rows of an FTR-row tile
   constexpr int NS = 2;                                        // stages
@@ -681,6 +702,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
       f32x16 acc[RM ? 1 : FTR];
       const bool wave_live = (t0 + 32 * wave < T) && !(a.dbg & 1);   // this consumer's frames exist (ragged last tile)
       const bool g16 = G16 && (cg == a.ncg - 1);                    // uniform: this tile is the 16-channel group
+      // position of the tile in the frequency axis (uniform): bit 0 = it holds output row 0 (its staged row 0 is the zero
+      // padding above the image), bit 1 = it is the last row tile of an F = 8 k + 7 layer (output row 7 does not exist and
+      // staged rows 8, 9 are the padding below) -- chunk_mfma6_pos compiles those steps out
+      // (only for padf = 1, Fin = Fout: the same-padded convs; anything else runs the full body)
+      const int tpos = (EDGE && a.padf == 1 && a.Fin == a.Fout) ? ((f0 == 0 ? 1 : 0) | ((f0 + FTR == a.Fout + 1) ? 2 : 0)) : 0;
       // (two-rows-in-M tiles use the first FTR / 2 accumulators)
       {
         const float* tb = s_tab + (ti % NS) * (3 * FTR * COP);  // accumulators start at bias + folded shift
@@ -696,8 +722,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
           if constexpr (RM) chunk_mfma6_rm<NR>(acc[0], st, st + 3 * XN, wave, half, l31);
           else if constexpr (G16) {
             if (g16) chunk_mfma6_rm2<NR, FTR>(acc, st, st + 3 * XN, wave, half, l31);
-            else chunk_mfma6<NR, SF, TR2, FTR>(acc, st, st + 3 * XN, wave, half, l31);
-          } else chunk_mfma6<NR, SF, TR2, FTR, RMASK, VR>(acc, st, st + 3 * XN, wave, half, l31);
+            else chunk_mfma6_pos<NR, SF, TR2, FTR, EDGE>(acc, st, st + 3 * XN, wave, half, l31, tpos);
+          } else if constexpr (BN != 0) chunk_mfma6<NR, SF, TR2, FTR, RMASK, VR>(acc, st, st + 3 * XN, wave, half, l31);
+          else chunk_mfma6_pos<NR, SF, TR2, FTR, EDGE>(acc, st, st + 3 * XN, wave, half, l31, tpos);
           __builtin_amdgcn_s_setprio(0);
         }
         STAMP(ti);
