@@ -62,7 +62,7 @@ def table():
 # The G16 instantiation (two chunk bodies and two epilogues in one persistent kernel) keeps 26 loop-invariant values of its
 # tile set-up in scratch: they are written once per workgroup and re-loaded a few times per TILE (~150 k cycles); its two
 # MFMA loops contain no scratch access (checked on the ISA, LAB.md round 4).
-HOT_SCRATCH_ALLOWED = {"mn::conv3x3_bf16x6<2, 8, false, 4, false, false, 0>": 8, "mn::conv3x3_bf16x6<0, 8, false, 4, true, false, 0>": 112}
+HOT_SCRATCH_ALLOWED = {"mn::conv3x3_bf16x6<2, 8, false, 4, false, false, 0>": 8, "mn::conv3x3_bf16x6<0, 8, false, 4, true, false, 0>": 120}
 
 
 def test_hot_kernels_do_not_spill(table):
