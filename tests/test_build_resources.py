@@ -73,7 +73,7 @@ def test_hot_kernels_do_not_spill(table):
     assert not bad, f"(VGPR spills, scratch bytes) of hot kernels: {bad}"
     # SGPR spills go to VGPR lanes (v_writelane, no memory): the persistent kernels' producer bookkeeping has 13-41 of them.
     # They are bounded here so that a jump is seen.
-    sg = {k: table[k]["sgpr_spill"] for k in HOT if table[k]["sgpr_spill"] > (72 if k.endswith("4, true, false, 0>") else 48)}
+    sg = {k: table[k]["sgpr_spill"] for k in HOT if table[k]["sgpr_spill"] > (80 if k.endswith("4, true, false, 0>") else 56)}
     assert not sg, f"SGPR spills: {sg}"
 
 
