@@ -225,29 +225,11 @@ __global__ __launch_bounds__(256) void tcn_pw_k(const float* d, const double2* g
   const float rstd = (float)(1.0 / sqrt(gv + (double)GLN_EPS));
   const float* dn = d + (long long)n * C * Tp;
 
-  // The accumulators START at the residual tile (this lane's (channel, frame) elements in accumulator order; zeros when
-  // there is no residual: num_records = 0): its 64 loads are in flight during the gLN sum and the first chunk instead of
-  // being waited for behind the last MFMA.
   f32x16 acc[4];
-  {
-    const float* rn = residual ? residual + (long long)n * C * Tp : nullptr;
-    const unsigned long long pa = reinterpret_cast<unsigned long long>(rn ? rn : dn);
-    const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pa);
-    const unsigned phi = __builtin_amdgcn_readfirstlane((unsigned)(pa >> 32));
-    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<void*>(((unsigned long long)phi << 32) | plo), 0,
-        __builtin_amdgcn_readfirstlane(rn ? (int)((unsigned)C * (unsigned)Tp * 4u) : 0), 0x00020000);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int t = t0 + s * 32 + l31;
-      const unsigned vo = (t < T) ? (unsigned)((wave * 32 + 4 * half) * Tp + t) * 4u : 0x80000000u;
+  for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co_off = (r & 3) + 8 * (r >> 2);
-        acc[s][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, vo + (unsigned)(co_off * Tp) * 4u, 0, 0));
-      }
-    }
-  }
+    for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
 
   if constexpr (X6) {
     typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -381,6 +363,28 @@ __global__ __launch_bounds__(256) void tcn_pw_k(const float* d, const double2* g
   }
 
   // ---- epilogue ----
+  // residual tile: this lane's (channel, frame) elements in accumulator order, all loads issued together
+  float rv[4][16];
+  const float* rn = residual ? residual + (long long)n * C * Tp : nullptr;
+  {
+    const unsigned long long pa = reinterpret_cast<unsigned long long>(rn ? rn : dn);
+    const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pa);
+    const unsigned phi = __builtin_amdgcn_readfirstlane((unsigned)(pa >> 32));
+    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void*>(((unsigned long long)phi << 32) | plo), 0,
+        __builtin_amdgcn_readfirstlane(rn ? (int)((unsigned)C * (unsigned)Tp * 4u) : 0), 0x00020000);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int t = t0 + s * 32 + l31;
+      const unsigned vo = (t < T) ? (unsigned)((wave * 32 + 4 * half) * Tp + t) * 4u : 0x80000000u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co_off = (r & 3) + 8 * (r >> 2);
+        rv[s][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, vo + (unsigned)(co_off * Tp) * 4u, 0, 0));
+      }
+    }
+  }
+
   float* yn = y + (long long)n * y_bstride + (long long)y_c0 * Tp;
   const unsigned long long pa = reinterpret_cast<unsigned long long>(yn);
   const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pa);
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(256) void tcn_pw_k(const float* d, const double2* g
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co_off = (r & 3) + 8 * (r >> 2);
-      const float v = acc[s][r];                 // (the residual is the accumulators' start value)
+      const float v = acc[s][r] + rv[s][r];
       vrow[r] = v;
       if (!Y_OCT3)
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, vo + (unsigned)(co_off * Tp) * 4u, 0, 0);
