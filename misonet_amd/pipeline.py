@@ -307,9 +307,9 @@ class Enhancer:
                 return rec["pcm_h"].numpy().copy()
 
             def staged(sl, name, host):
-                """pinned source for the H2D copy of `host` (itself if already pinned)"""
+                """pinned source for the H2D copy of `host` (itself if already pinned, or already on a device)"""
                 host = host.to(torch.float32).contiguous() if host.dtype != torch.float32 or not host.is_contiguous() else host
-                if host.is_pinned():
+                if host.is_cuda or host.is_pinned():
                     return host
                 pin = sl.get("pin_" + name)
                 if pin is None or pin.shape != host.shape:
