@@ -925,8 +925,15 @@ hipError_t launch_conv_bf16x6(const ConvArgs& a_in, int n_samples, hipStream_t s
   if (flex) {
     const int g_cus_ = device_cus();
     const long long ntx_ = (a.T + TT - 1) / TT;
+    // rounds of tiles per CU x relative cost of a tile (a 4-row tile takes ~0.54 of an 8-row tile's time: 108 instead of
+    // 216 MFMAs per chunk at a quarter more staged bytes per MFMA): the geometry with the shorter critical path.  Batch 16
+    // (thousands of tiles) always takes 8-row tiles; one to three utterances take 4-row tiles on most of these layers.
     const long long tiles8 = (long long)n_samples * ntx_ * ((a.Fout + 7) / 8) * a.ncg;
-    if (g_cus_ > 0 && tiles8 < g_cus_) ftr = 4;
+    const long long tiles4 = (long long)n_samples * ntx_ * ((a.Fout + 3) / 4) * a.ncg;
+    if (g_cus_ > 0) {
+      const long long r8 = (tiles8 + g_cus_ - 1) / g_cus_, r4 = (tiles4 + g_cus_ - 1) / g_cus_;
+      if (r4 * 54 < r8 * 100) ftr = 4;
+    }
   }
   (void)conv_grid(a, n_samples, TT, ftr, 1);
   if (n_samples % 8) a.xcd = 2;                                    // columns, not samples, are dealt to the XCDs
