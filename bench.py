@@ -446,6 +446,8 @@ def main():
                          "iSTFT, x 32767 -> int16), device-resident and host-resident with overlapped copies; runs by default "
                          "at N = 1 unless --no-alt, this flag forces it")
     ap.add_argument("--no-profile", action="store_true", help="skip the event-instrumented pass (no roofline object)")
+    ap.add_argument("--pmc", action="store_true",
+                    help="force the live rocprofv3 --pmc passes (they run by default at N = 1 unless --no-alt / --no-pmc)")
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not re-execute under rocprofv3 --pmc for the live counters of the roofline object (traffic, matrix-"
                          "pipe busy fraction, observed clock): ~2 min; the fields then come from profiles/*_traffic.json")
@@ -566,7 +568,7 @@ def main():
         if prof and prof[3][0] > 0:
             kp, dtp, ms, cnt = prof
             live = None
-            if world == 1 and not args.no_pmc and not args.no_alt:      # (--no-alt = the quick A/B form of this script)
+            if world == 1 and not args.no_pmc and (args.pmc or not args.no_alt):   # (--no-alt = the quick A/B form of this script)
                 live = pmc_live(args.precision, B, T)
             roof, roof2 = roofline_objects(args.precision, B, T, kp, ms[0], cnt[0], live)
             roof["time_share"] = {"conv_ms_per_step": round(ms[0] / kp, 2), "tcn_ms_per_step": round(ms[1] / kp, 2),
