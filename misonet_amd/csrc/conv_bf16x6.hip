@@ -759,6 +759,106 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x6(const ConvArgs a, int n
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// conv3x3_x6_first: the network's FIRST layer (reference model.py:44, init_Conv2d_ model.py:401-406: 3x3 conv, padding
+// (1, 0), no activation, no norm; 2 num_ch (+4) -> 24 channels at F = 129 -> 127) in the bf16x6 arithmetic.  Its input is the
+// PLANAR float32 network input (the STFT planes that MVDR and the MISO3 assembly also read), so nothing can be staged by
+// LDS-DMA: the workgroup loads the patch with plain buffer loads, splits every value EXACTLY into three bf16 pieces on the way
+// into the LDS (split3_pair_t) and then runs the same tap-paired MFMA mapping as the persistent kernel (chunk_mfma6 on a 4-row
+// x 128-frame tile: 108 MFMAs per 8-channel chunk and wave).  Rounds 1-3 ran this layer on the exact-f32 MFMA kernel
+// (conv3x3_mfma<1, 0, 3>: 64-cycle MFMAs, 55 % busy, 1.06 + 0.41 ms per step).  The weights are NOT per sample (the input is
+// consumed as it is: ident_c = Cin), so one 3-part image per chunk is packed on the host at commit (net.hip, pack_conv_w6s).
+//   wimg: [nchunk][X6_WU] 16-byte units in conv_wprep6_k's image order.
+// 256 threads = 4 waves x (4 output rows x 32 frames); single-buffered, 53 KB of LDS: 2-3 workgroups per CU overlap one
+// workgroup's staging with another's MFMAs.  Output: oct3 (or planar) through the tile epilogue of the persistent kernel.
+template <int NQ>
+__global__ __launch_bounds__(256, 3) void conv3x3_x6_first(const ConvArgs a, const u32x4_t* wimg) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NR = 6, FTR = 4, COP = 32;
+  constexpr int XN = NR * X6_TW;
+  extern __shared__ __align__(16) unsigned char smem_b[];
+  bf16x8* s_x = reinterpret_cast<bf16x8*>(smem_b);             // [3 parts][NR][X6_TW]
+  bf16x8* s_w = s_x + 3 * XN;                                  // [X6_WU]
+  float* s_bs = reinterpret_cast<float*>(s_w + X6_WU);         // [FTR][2][16] bias in accumulator order
+  float* s_z = s_bs + FTR * COP;                               // [FTR][2][16] zeros (no folded shift: the input is not normalised)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int t0 = blockIdx.x * TT, f0 = blockIdx.y * FTR, n = blockIdx.z;
+  const int T = a.T, Tp = a.Tp, Fin = a.Fin, Cin = a.Cin;
+  const int nchunk = (Cin + 7) >> 3;
+  if (tid < FTR * COP) {
+    // slot (r, h, i) <-> channel (i & 3) + 8 (i >> 2) + 4 h of row r
+    const int i = tid & 15, h = (tid >> 4) & 1;
+    const int co = (i & 3) + 8 * (i >> 2) + 4 * h;
+    s_bs[tid] = co < a.Cout ? a.bias[co] : 0.f;
+    s_z[tid] = 0.f;
+  }
+  const float* in_n = a.in + (long long)n * a.in_bstride + (long long)a.in_c0 * Fin * Tp;
+  const __amdgpu_buffer_rsrc_t rs_in = make_rsrc_e(reinterpret_cast<unsigned long long>(in_n), (unsigned)Cin * (unsigned)Fin * (unsigned)Tp * 4u);
+  const unsigned plane_b = (unsigned)Fin * (unsigned)Tp * 4u;
+  f32x16 acc[FTR];
+  __syncthreads();
+  conv_acc_init_rows(acc, t0 + 32 * wave, T, lane, s_bs, s_z, s_z);
+  const bool wave_live = t0 + 32 * wave < T;
+  for (int kc = 0; kc < nchunk; ++kc) {
+    if (kc) __syncthreads();                                   // the previous chunk's images are consumed
+    // ---- stage: 780 (row, frame) units x 8 channels -> three bf16 part images; out-of-image units are zeros ----
+#pragma unroll
+    for (int it = 0; it < (XN + 255) / 256; ++it) {
+      const int u = tid + 256 * it;
+      if (u < XN) {
+        const int r = u / X6_TW, j = u - r * X6_TW;
+        const int fin = f0 - a.padf + r, t = t0 - 1 + j;
+        const bool ok = fin >= 0 && fin < Fin && t >= 0 && t < T;
+        const unsigned vo = ok ? ((unsigned)fin * (unsigned)Tp + (unsigned)t) * 4u : 0x80000000u;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = kc * 8 + e;                            // (the SGPR offset is not bounds-checked: clamp the channel)
+          const int cc = c < Cin ? c : Cin - 1;
+          v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, vo, (unsigned)cc * plane_b, 0));
+          if (c >= Cin) v[e] = 0.f;
+        }
+        u32x4_t ph, pm, pl;
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+          unsigned a_, b_, c_;
+          split3_pair_t(v[2 * e2], v[2 * e2 + 1], a_, b_, c_);
+          ph[e2] = a_; pm[e2] = b_; pl[e2] = c_;
+        }
+        reinterpret_cast<u32x4_t*>(s_x)[u] = ph;
+        reinterpret_cast<u32x4_t*>(s_x)[XN + u] = pm;
+        reinterpret_cast<u32x4_t*>(s_x)[2 * XN + u] = pl;
+      }
+    }
+    const u32x4_t* wsrc = wimg + (long long)kc * X6_WU;
+#pragma unroll
+    for (int it = 0; it < (X6_WU + 255) / 256; ++it) {
+      const int u = tid + 256 * it;
+      if (u < X6_WU) reinterpret_cast<u32x4_t*>(s_w)[u] = wsrc[u];
+    }
+    __syncthreads();
+    if (wave_live) chunk_mfma6<NR, 1, false, FTR>(acc, s_x, s_w, wave, half, l31);
+  }
+  if (wave_live && !(a.dbg & 4))
+    conv_epilogue_rows_nb<3, false, NQ>(a, acc, n, 0, f0, t0 + 32 * wave, lane, s_z /*unused: act = 0*/, FTR, nullptr);
+#endif
+}
+
+hipError_t launch_conv_x6_first(const ConvArgs& a_in, const void* wimg, int n_samples, hipStream_t s) {
+  ConvArgs a = a_in;
+  if (a.in_oct || a.sf != 1 || a.tr2 || a.act || a.Cin > 16 || a.Cout > 32 || a.ident_c < a.Cin || !wimg) return hipErrorInvalidValue;
+  if (a.out_oct && a.out_oct != 3) return hipErrorInvalidValue;
+  static const int dbg = [] { const char* e = getenv("MISONET_WS_DEBUG"); return e ? atoi(e) : 0; }();
+  a.dbg = dbg;
+  const dim3 grid((a.T + TT - 1) / TT, (a.Fout + 3) / 4, n_samples);
+  const size_t lds = (size_t)(3 * 6 * X6_TW + X6_WU) * 16 + (size_t)(2 * 4 * 32) * sizeof(float);
+  if (a.Cout <= 24 && a.out_oct == 3) hipLaunchKernelGGL((conv3x3_x6_first<3>), grid, dim3(256), lds, s, a, reinterpret_cast<const u32x4_t*>(wimg));
+  else hipLaunchKernelGGL((conv3x3_x6_first<4>), grid, dim3(256), lds, s, a, reinterpret_cast<const u32x4_t*>(wimg));
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // conv_wprep6_k: fold the instance norm of a layer's input into per-sample weights, split exactly into three bf16 parts.
 //   wf   : [ncg][nchunk][9 taps][32 co][8 ci] float32 (zero padded), shared by all samples; tap = kt * 3 + kf
 //   wps  : [n][ncg][nchunk][X6_WU] 16-byte units: unit ((kf*3 + p)*2 + kt)*32 + co for kt < 2, X6_WPAIR + (kf*3 + p)*32 + co
@@ -855,6 +955,8 @@ static hipError_t x6_set_attr() {
 
 hipError_t conv_bf16x6_init() {
   hipError_t e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_x6_first<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_x6_first<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)) != hipSuccess) return e;
   if ((e = x6_set_attr<0, 4>()) != hipSuccess) return e;
   if ((e = x6_set_attr<0, 8>()) != hipSuccess) return e;
   if ((e = x6_set_attr<1, 4>()) != hipSuccess) return e;

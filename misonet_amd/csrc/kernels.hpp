@@ -110,6 +110,9 @@ hipError_t launch_conv_bf16x6(const ConvArgs& a, int n_samples, hipStream_t s);
 hipError_t launch_conv_wprep6(const ConvArgs& a, const float* wf6, int n_samples, hipStream_t s);
 hipError_t conv_bf16x6_init();
 long long conv_bf16x6_wps_bytes(int Cin, int Cout);   // per-sample folded-weight bytes of one layer
+// the network's first layer in the bf16x6 arithmetic: planar float32 in (consumed as it is), oct3 / planar out; wimg = the
+// layer's weights as ONE 3-part image per 8-channel chunk (864 16-byte units each, conv_wprep6_k's order; net.hip packs it)
+hipError_t launch_conv_x6_first(const ConvArgs& a, const void* wimg, int n_samples, hipStream_t s);
 
 // ---- TCN (reference model.py:486-632) -----------------------------------------------------------------------------
 // Statistics travel as float64 (sum, sum of squares) PARTIALS, one per producing workgroup, added by the consumer in index

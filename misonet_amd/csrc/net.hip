@@ -105,6 +105,7 @@ struct ConvL {
   long long w16_off = 0;            // offset (floats) of the bf16 hi/lo packed weights
   long long wf_off = 0;             // offset (floats) of the float32 weights in bf16-image order (conv_wprep_k source)
   long long wf6_off = 0;            // offset (floats) of the float32 weights [cg][chunk of 8][tap][32][8] (conv_wprep6_k source)
+  long long w6s_off = -1;           // first layer only: offset (floats) of the SHARED 3-part bf16 image [chunk][864 units]
   float wscale = 1.f;               // f16x3: power of two that brings max |W| of the layer to [32, 64)
 };
 
@@ -490,6 +491,14 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
       fprintf(stderr, "%s\n", hipGetErrorString(e));
     }
   } sync_guard{s, a, sync_dbg};
+  // bf16x6 / f16x3 networks: the planar-input first layer in the bf16x6 arithmetic (MISONET_X6_FIRST=0: the exact-f32 kernel
+  // of rounds 1-3, for A/B runs)
+  static const int x6first_env = [] { const char* e = getenv("MISONET_X6_FIRST"); return e ? atoi(e) : 1; }();
+  if (x6first_env && n->precision >= 3 && !a.in_oct && a.out_oct == 3 && c.w6s_off >= 0 && !a.act) {
+    ProfScope ps(s, PK_CONV);
+    HIPCHK(launch_conv_x6_first(a, n->w_dev + c.w6s_off, nb, s));
+    return MISONET_OK;
+  }
   if (a.in_oct == 3) {
     a.wps = reinterpret_cast<char*>(ws) + L.wps_base + (long long)n0 * L.wps_nstride;
     a.wps_nstride = L.wps_nstride;
@@ -768,6 +777,32 @@ static void pack_conv_wf6(const misonet_net* n, const ConvL& c, std::vector<floa
             }
 }
 
+// the first layer's weights as one exact 3-part bf16 image per 8-channel chunk, in conv_wprep6_k's unit order (unit
+// ((kf*3 + p)*2 + kt)*32 + co for kt < 2, 576 + (kf*3 + p)*32 + co for kt = 2; 8 channels per unit): w = hi + mid + lo exactly
+static void pack_conv_w6s(const misonet_net* n, const ConvL& c, std::vector<float>& arena) {
+  if (c.w6s_off < 0) return;
+  const std::vector<float>& W = n->tensors[c.wt].host;
+  const int nchunk = (c.Cin + 7) / 8;
+  unsigned short* img = reinterpret_cast<unsigned short*>(arena.data() + c.w6s_off);
+  for (int kc = 0; kc < nchunk; ++kc)
+    for (int kt = 0; kt < 3; ++kt)
+      for (int kf = 0; kf < 3; ++kf)
+        for (int co = 0; co < 32; ++co)
+          for (int e = 0; e < 8; ++e) {
+            const int ci = kc * 8 + e;
+            const float v = (ci < c.Cin && co < c.Cout) ? W[(((long long)co * c.Cin + ci) * 3 + kt) * 3 + kf] : 0.f;
+            const unsigned short h = f32_to_bf16_rne(v);
+            const float r1 = v - bf16_to_f32(h);
+            const unsigned short m = f32_to_bf16_rne(r1);
+            const unsigned short l = f32_to_bf16_rne(r1 - bf16_to_f32(m));
+            const unsigned short part[3] = {h, m, l};
+            for (int p = 0; p < 3; ++p) {
+              const long long unit = kt < 2 ? ((kf * 3 + p) * 2 + kt) * 32 + co : 576 + (kf * 3 + p) * 32 + co;
+              img[((long long)kc * 864 + unit) * 8 + e] = part[p];
+            }
+          }
+}
+
 int misonet_net_commit(misonet_net* n) {
   if (!n) return fail(MISONET_EINVAL, "null argument");
   for (const Tensor& t : n->tensors)
@@ -782,6 +817,9 @@ int misonet_net_commit(misonet_net* n) {
       c.w16_off = take((long long)((c.Cout + 31) / 32) * ((c.Cin + 15) / 16) * 2 * 9 * 2 * 32 * 8 / 2);   // u16 -> floats
       c.wf_off = take((long long)((c.Cout + 31) / 32) * ((c.Cin + 15) / 16) * 9 * 2 * 32 * 8);
       c.wf6_off = take((long long)((c.Cout + 31) / 32) * ((c.Cin + 7) / 8) * 9 * 32 * 8);
+      // the first layer (planar network input, consumed un-normalised, <= 16 in / <= 32 out channels): shared 3-part image
+      if (c.in_buf == B_IN && !c.transposed && c.sf == 1 && c.Cin <= 16 && c.Cout <= 32 && c.ident_c >= c.Cin)
+        c.w6s_off = take((long long)((c.Cin + 7) / 8) * 864 * 4);          // 864 units x 16 bytes = x 4 floats
     }
   };
   place(n->enc);
@@ -797,7 +835,7 @@ int misonet_net_commit(misonet_net* n) {
       tb.h[h].o_nsh = take(128);
     }
   std::vector<float> arena((size_t)off, 0.f);
-  for (ConvL& c : n->enc) { pack_conv(n, c, arena); pack_conv_bf16(n, c, arena); pack_conv_wf6(n, c, arena); }
+  for (ConvL& c : n->enc) { pack_conv(n, c, arena); pack_conv_bf16(n, c, arena); pack_conv_wf6(n, c, arena); pack_conv_w6s(n, c, arena); }
   for (ConvL& c : n->dec) { pack_conv(n, c, arena); pack_conv_bf16(n, c, arena); pack_conv_wf6(n, c, arena); }
   for (const TcnBlock& tb : n->tcn)
     for (int h = 0; h < 2; ++h) {

@@ -21,7 +21,8 @@ HOT = [
     "mn::conv3x3_mfma<1, 1, 0, false>", "mn::conv3x3_mfma<2, 1, 0, false>",        # f32: stride-2 convs
     "mn::conv3x3_mfma<1, 2, 0, false>",                                            # f32: stride-2 transposed convs
     "mn::conv3x3_mfma<1, 0, 0, true>", "mn::conv3x3_mfma<1, 0, 3, true>",          # first layer (12 input channels)
-    "mn::conv3x3_mfma<1, 0, 3, false>",                                            # MISO3 first layer in bf16x6
+    "mn::conv3x3_mfma<1, 0, 3, false>",                                            # (first layer on the f32 kernel: MISONET_X6_FIRST=0)
+    "mn::conv3x3_x6_first<3>", "mn::conv3x3_x6_first<4>",                          # first layer in bf16x6 (round 4)
     "mn::conv3x3_bf16x6<0, 8, false, 4, false, false, 0>", "mn::conv3x3_bf16x6<0, 8, false, 3, false, false, 0>",    # 38 % + 28 % of the bf16x6 step
     "mn::conv3x3_bf16x6<0, 8, false, 4, false, true, 0>",                             # F <= 31 layers (two statistic units)
     "mn::conv3x3_bf16x6<0, 8, false, 4, true, false, 0>",                             # the 48-channel layer (10 %)
@@ -95,3 +96,5 @@ def test_headline_kernel_occupancy(table):
     # the f32 32-channel kernel is tuned for three workgroups per CU (<= 168 VGPRs)
     assert table["mn::conv3x3_mfma<1, 0, 0, false>"]["vgprs"] <= 168
     assert table["mn::conv3x3_mfma<1, 0, 0, false>"]["occupancy"] >= 3
+    # the first-layer kernel is latency-bound: three workgroups per CU (<= 168 VGPRs, 52 KB of LDS each)
+    assert table["mn::conv3x3_x6_first<3>"]["vgprs"] <= 168 and table["mn::conv3x3_x6_first<3>"]["occupancy"] >= 3
