@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_l2, mag_parity
+from conftest import golden, rel_l2, mag_parity
 from test_gpu_parity import _assert_parity, _utt_inputs, _need_gpu
 
 pytestmark = pytest.mark.gpu
@@ -61,6 +61,57 @@ def test_full_size_batch16_pipeline_vs_oracle(bench_batch, sd1, sd3, mode):
         _assert_parity(out[u].cpu().numpy(), r["out"], f"[{mode}] utt {u} miso3 T=1001 B=16")
         e = mag_parity(out[u].cpu().numpy(), r["out"])[0]
         assert e <= tol, f"[{mode}] utt {u}: end-to-end rel-L2 {e:.3e} above the mode's measured bound {tol:.0e}"
+    # utterance 0 of the batch against the REAL reference at full size (G12, oracle/gen_golden_full.py)
+    _check_g12(extra["miso1"][0].cpu().numpy()[:, 0], extra["bf"][0].cpu().numpy(), out[0].cpu().numpy(),
+               f"[{mode}] utt 0 of the batch of 16", ms_tol=max(1e-4, 3 * tol))
+    del enh, m1, m3
+    torch.cuda.empty_cache()
+
+
+def _check_g12(miso1_ref, bf, out, what, ms_tol=1e-4):
+    """stage outputs [2, T, F] of bench utterance 0 against the reference's own run (every 16th frame + all magnitude sums)"""
+    g = golden("g12_fullsize_T1001.npz")
+    st = int(g["frame_step"])
+    assert int(g["frames"]) == T_FULL and int(g["utt"]) == 0
+    for name, got in (("miso1_ref", miso1_ref), ("bf", bf), ("out", out)):
+        _assert_parity(got[:, ::st], g[name + "_frames"], f"{what}: {name} vs reference golden G12")
+        ms = np.abs(got).astype(np.float64).sum(-1)
+        e = rel_l2(ms, g[name + "_magsum"])
+        print(f"[parity] {what}: {name} per-frame magnitude sums of all {T_FULL} frames vs G12: {e:.3e}")
+        assert e <= ms_tol, f"{what}: {name} per-frame magnitude sums differ by {e:.3e}"
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x6"])
+def test_full_size_single_utterance_vs_reference_golden(sd1, sd3, mode):
+    """B = 1 (the reference harness' own batch size, config/NN_BSS.yml:108-111) at T = 1001 against G12: MISO_1.forward
+    (model.py:76-111) and the whole body of Tester_Enhance.inference (tester.py:846-975) incl. the int16 waves, all from
+    the real reference run on the bench's utterance 0 in the build container."""
+    _need_gpu()
+    import misonet_amd as mz
+    from misonet_amd import weights as W
+    g = golden("g12_fullsize_T1001.npz")
+    st = int(g["frame_step"])
+    mx, cl = _utt_inputs(0, T_FULL)
+    m1 = mz.MISO_1(2, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN").cuda(0)
+    m1.load_state_dict(sd1)
+    m3 = mz.MISO_3(1, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN").cuda(0)
+    m3.load_state_dict(sd3)
+    m1.eval().set_precision(mode)
+    m3.eval().set_precision(mode)
+    y = m1(torch.from_numpy(mx[None]).cuda()).cpu().numpy()[0]
+    _assert_parity(y[:, ::st], g["miso1_fwd_frames"], f"[{mode}] MISO_1.forward T=1001 vs reference golden G12")
+    assert rel_l2(np.abs(y).astype(np.float64).sum(-1), g["miso1_fwd_magsum"]) <= 1e-4
+    enh = mz.Enhancer(m1, m3, num_spks=2, ref_ch=0)
+    out, extra = enh.enhance(torch.from_numpy(mx[None]).cuda(), torch.from_numpy(cl[None]).cuda(), want_bf=True, want_miso1=True)
+    _check_g12(extra["miso1"][0].cpu().numpy()[:, 0], extra["bf"][0].cpu().numpy(), out[0].cpu().numpy(), f"[{mode}] B = 1")
+    wav = enh.to_wav_int16([out[0]], gap=0)                              # [2, 64000] int16
+    assert wav.shape == (2, (T_FULL - 1) * 64)
+    for s in range(2):
+        d = np.abs(wav[s][::16].astype(np.int32) - g["wav_dec16"][s].astype(np.int32))
+        print(f"[wav] [{mode}] spk{s} vs the reference's int16 wave (every 16th sample): max |diff| = {d.max()} LSB")
+        assert d.max() <= 1
+        a = np.abs(wav[s].astype(np.int64)).reshape(-1, 1000).sum(-1)
+        assert np.max(np.abs(a - g["wav_abssum_1000"][s])) <= 1000        # all samples: <= 1 LSB each
     del enh, m1, m3
     torch.cuda.empty_cache()
 

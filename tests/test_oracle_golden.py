@@ -84,6 +84,34 @@ def test_g6_pipeline(sd1, sd3):
         assert np.max(np.abs(w.astype(np.int32) - g[f"wav{s}"].astype(np.int32))) <= 2
 
 
+def test_g12_full_size_reference(sd1, sd3):
+    """G12: the real reference at the FULL bench geometry (utterance 0 of BASELINE configs[1..3], T = 1001): one
+    MISO_1.forward and the whole Tester_Enhance.inference (oracle/gen_golden_full.py).  The fixture keeps every 16th frame,
+    the magnitude sums of all frames and the decimated int16 waves."""
+    from misonet_amd.weights import synthetic_utterance
+    g = golden("g12_fullsize_T1001.npz")
+    T, st = int(g["frames"]), int(g["frame_step"])
+    obs, s0, s1 = synthetic_utterance(int(g["utt"]), (T - 1) * 64)
+    mix = pipeline_oracle.stft_chunk(obs)
+    clean = np.stack([pipeline_oracle.stft_chunk(s0)[0], pipeline_oracle.stft_chunk(s1)[0]])
+    y = miso_oracle.miso1_forward(torch.from_numpy(mix[None]), sd1).numpy()[0]
+    assert rel_l2(y[:, ::st], g["miso1_fwd_frames"]) < 5e-5
+    assert rel_l2(np.abs(y).astype(np.float64).sum(-1), g["miso1_fwd_magsum"]) < 2e-5
+    r = pipeline_oracle.enhance_utterance(mix, clean, sd1, sd3, ref_ch=0)
+    assert rel_l2(r["miso1"][:, 0, ::st], g["miso1_ref_frames"]) < 5e-5
+    assert rel_l2(np.abs(r["miso1"][:, 0]).astype(np.float64).sum(-1), g["miso1_ref_magsum"]) < 2e-5
+    assert rel_l2(r["bf"][:, ::st], g["bf_frames"]) < 5e-4
+    rl2, bad = mag_parity(r["out"][:, ::st], g["out_frames"])
+    assert rl2 < 2e-4 and bad < 1e-3
+    assert rel_l2(np.abs(r["out"]).astype(np.float64).sum(-1), g["out_magsum"]) < 1e-4
+    for s in range(2):
+        w = pipeline_oracle.istft_int16(r["out"][s])
+        assert w.shape == ((T - 1) * 64,)
+        assert np.max(np.abs(w[::16].astype(np.int32) - g["wav_dec16"][s].astype(np.int32))) <= 2
+        a = np.abs(w.astype(np.int64)).reshape(-1, 1000).sum(-1)
+        assert np.max(np.abs(a - g["wav_abssum_1000"][s])) <= 2 * 1000
+
+
 def test_g8_sample_clean_config1(sd1):
     """BASELINE.json configs[0]: first 4 s of sample/Clean (8 kHz, 6 mics) through one MISO_1 forward."""
     g = golden("g8_sample_clean_miso1.npz")
