@@ -190,6 +190,11 @@ class _Trunk:
         for s in segs[1:]:
             if s.shape[0] != B or s.shape[2] != T or s.shape[3] != F:
                 raise ValueError("input segments disagree in B/T/F")
+        if T < 2:
+            # the reference fails here too: nn.InstanceNorm2d at the F = 1 bottleneck sees ONE element per (sample, channel)
+            # and torch raises this ValueError (model.py:89, 413) -- a variance of one value is not a statistic
+            raise ValueError(f"Expected more than 1 spatial element when training, got input size "
+                             f"torch.Size([{B}, 128, {T}, 1]) (the network needs T >= 2 frames)")
         if sum(s.shape[1] for s in segs) * 2 != self.in_ch:
             raise ValueError(f"expected {self.in_ch // 2} complex input channels, got {sum(s.shape[1] for s in segs)}")
         ws = self._workspace(B, T)

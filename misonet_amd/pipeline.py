@@ -170,6 +170,8 @@ class Enhancer:
             raise ValueError(f"expected {self.num_ch} microphones, got {M}")
         if F != N_FREQ:
             raise ValueError(f"the networks are defined for F = {N_FREQ} frequency bins, got {F}")
+        if T < 2:                              # as the reference: InstanceNorm over one element (model.py:89, 413)
+            raise ValueError(f"Expected more than 1 spatial element when training, got T = {T} frame(s)")
         if clean is not None:
             clean = self._check_c64(clean, "clean", (B, self.num_spks, T, F))
         ws = self.workspace(B, T)
@@ -373,6 +375,8 @@ class Enhancer:
             raise ValueError(f"expected {self.num_ch} microphones, got {M}")
         if F != N_FREQ:
             raise ValueError(f"the networks are defined for F = {N_FREQ} frequency bins, got {F}")
+        if T < 2:                              # as the reference: InstanceNorm over one element (model.py:89, 413)
+            raise ValueError(f"Expected more than 1 spatial element when training, got T = {T} frame(s)")
         if clean is not None:
             clean = self._check_c64(clean, "clean", (B, self.num_spks, T, F))
         ws = self.workspace(B, T)

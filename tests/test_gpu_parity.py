@@ -111,8 +111,25 @@ def test_miso1_ragged_batched_vs_oracle(nets, sd1, B, T):
     _assert_parity(y, y_ref, f"miso1 B={B} T={T} vs oracle")
 
 
+@pytest.mark.parametrize("T", [2, 3, 4])
+def test_miso1_shortest_inputs_vs_oracle(nets, sd1, T):
+    """The shortest inputs the reference accepts (T = 2: its instance norms need more than one element at the F = 1
+    bottleneck, model.py:89): every tile is ragged in T and the dilated TCN taps (dilation up to 64) fall outside the signal."""
+    from oracle import miso_oracle
+    m1, _ = nets
+    r = np.random.default_rng(77 + T)
+    x = (r.standard_normal((2, 6, T, 129)) + 1j * r.standard_normal((2, 6, T, 129))).astype(np.complex64)
+    y = m1(torch.from_numpy(x).cuda()).cpu().numpy()
+    y_ref = np.concatenate([miso_oracle.miso1_forward(torch.from_numpy(x[b:b + 1]), sd1).numpy() for b in range(2)])
+    _assert_parity(y, y_ref, f"miso1 T={T} vs oracle")
+
+
 def test_forward_errors(nets):
     m1, m3 = nets
+    with pytest.raises(ValueError):                                                 # T = 1: the reference raises the same
+        m1(torch.zeros((1, 6, 1, 129), dtype=torch.complex64, device="cuda"))       # ValueError (InstanceNorm, one element)
+    with pytest.raises(Exception):
+        m1(torch.zeros((0, 6, 8, 129), dtype=torch.complex64, device="cuda"))       # empty batch
     with pytest.raises(ValueError):
         m1(torch.zeros((1, 6, 8, 257), dtype=torch.complex64, device="cuda"))       # F != 129
     with pytest.raises(ValueError):
