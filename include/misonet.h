@@ -148,7 +148,10 @@ int misonet_pit_select(const void* anchor_dev, const void* cand_dev, int B, int 
  * alignment (tester.py:889-915; skipped when clean_dev == NULL) -> MVDR per speaker (tester.py:917-924) ->
  * MISO3 per speaker (tester.py:936-939).  Everything stays in HBM in the kernels' own layout. */
 /* 2 <= num_mic <= 8; 1 <= num_spk <= 4 (the reference's own clean-reference alignment stacks exactly s0 and s1,
- * tester.py:889-891, i.e. its harness is 2-speaker; here clean_dev simply carries num_spk sources). */
+ * tester.py:889-891, i.e. its harness is 2-speaker; here clean_dev simply carries num_spk sources).
+ * miso3 == NULL creates a SEPARATION-ONLY pipeline (the body the reference's Tester_Beamforming shares with
+ * Tester_Enhance, tester.py:340-449: MISO1_Inference + alignments, no MISO3 memory): misonet_pipeline_run then needs
+ * out_dev == NULL and bf_dev == NULL (MISONET_ESTATE otherwise). */
 int misonet_pipeline_create(misonet_net* miso1, misonet_net* miso3, int num_mic, int num_spk, int ref_ch,
                             float epsi, misonet_pipeline** out);
 int misonet_pipeline_destroy(misonet_pipeline* p);

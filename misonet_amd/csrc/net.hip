@@ -1096,7 +1096,8 @@ static PipeLayout pipe_layout(const misonet_pipeline* p, int B, int T) {
   // and output planes -- is consumed before the MISO3 forward writes anything): only the MISO3 INPUT, which those steps
   // build while MISO1's planes are still being read, has its own memory
   P.L1 = make_layout(p->n1, B * p->M, T);
-  P.L3 = make_layout(p->n3, B * p->S, T, true);
+  if (p->n3) P.L3 = make_layout(p->n3, B * p->S, T, true);
+  else { P.L3 = Layout(); P.L3.total_bytes = 0; }       // separation-only pipeline: no MISO3 workspace, no MISO3 input
   const int F = p->n1->cfg.n_freq, Tp = P.L1.Tp;
   long long o = 256;                                   // [0]: nan flag
   // PIT distances [B*M + B][S][S] followed by their per-bin partials [B*M + B][F][S][S] (mvdr.hip pit_dist_k)
@@ -1105,7 +1106,7 @@ static PipeLayout pipe_layout(const misonet_pipeline* p, int B, int T) {
   P.off_mvdr = o;  o += align_up(mvdr_ws_bytes(B, p->S, F, p->M), 256);
   P.clean_bstride = (long long)2 * p->S * F * Tp;
   P.off_clean = o; o += align_up(P.clean_bstride * B * 4, 256);
-  P.L3.in_ext_bstride = (long long)p->n3->cfg.in_ch * F * Tp;
+  P.L3.in_ext_bstride = p->n3 ? (long long)p->n3->cfg.in_ch * F * Tp : 0;
   const long long in3_bytes = align_up(P.L3.in_ext_bstride * B * p->S * 4, 256);
   P.off_ws1 = o;   o += align_up(std::max(P.L1.total_bytes, P.L3.total_bytes), 256);
   P.off_ws3 = P.off_ws1;
@@ -1117,13 +1118,15 @@ static PipeLayout pipe_layout(const misonet_pipeline* p, int B, int T) {
 
 int misonet_pipeline_create(misonet_net* n1, misonet_net* n3, int num_mic, int num_spk, int ref_ch, float epsi,
                             misonet_pipeline** out) {
-  if (!n1 || !n3 || !out) return fail(MISONET_EINVAL, "null argument");
+  // n3 == NULL: a separation-only pipeline (MISO1_Inference + alignments: the body shared by the reference's
+  // Tester_Beamforming, tester.py:340-449) -- misonet_pipeline_run then only accepts out == NULL, bf_out == NULL
+  if (!n1 || !out) return fail(MISONET_EINVAL, "null argument");
   if (num_spk < 1 || num_spk > 4) return fail(MISONET_EINVAL, "num_spk must be in [1, 4] (PIT enumerates num_spk! permutations)");
   if (num_mic < 2 || num_mic > 8) return fail(MISONET_EINVAL, "num_mic must be in [2, 8]");
   if (ref_ch < 0 || ref_ch >= num_mic) return fail(MISONET_EINVAL, "ref_ch out of range");
   if (n1->cfg.in_ch != 2 * num_mic || n1->cfg.out_ch != 2 * num_spk)
     return fail(MISONET_EINVAL, "MISO_1 geometry does not match num_mic/num_spk");
-  if (n3->cfg.in_ch != 2 * (num_mic + 2) || n3->cfg.out_ch != 2)
+  if (n3 && (n3->cfg.in_ch != 2 * (num_mic + 2) || n3->cfg.out_ch != 2))
     return fail(MISONET_EINVAL, "MISO_3 geometry must be in_ch = 2*(num_mic+2), out_ch = 2");
   misonet_pipeline* p = new misonet_pipeline{n1, n3, num_mic, num_spk, ref_ch, epsi};
   *out = p;
@@ -1140,7 +1143,9 @@ static int pipeline_run_impl(misonet_pipeline* p, const void* mix, const void* c
                              const float* clean_wav, int n_samples, int B, int T, void* out, void* bf_out,
                              void* miso1_out, void* ws, long long ws_bytes, misonet_stream stream) {
   if (!p || (!mix && !wav) || (!out && !miso1_out) || !ws) return fail(MISONET_EINVAL, "null argument");
-  if (!p->n1->committed || !p->n3->committed) return fail(MISONET_ESTATE, "networks not committed");
+  if (!p->n1->committed || (p->n3 && !p->n3->committed)) return fail(MISONET_ESTATE, "networks not committed");
+  if (!p->n3 && (out || bf_out))
+    return fail(MISONET_ESTATE, "this pipeline was created without MISO_3 (separation only): out and bf_out must be NULL");
   if (B <= 0 || T <= 0) return fail(MISONET_EINVAL, "B and T must be positive");
   const PipeLayout P = pipe_layout(p, B, T);
   if (ws_bytes < P.total) return fail(MISONET_ENOMEM, "workspace %lld < %lld bytes", ws_bytes, P.total);

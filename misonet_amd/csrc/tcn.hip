@@ -100,11 +100,14 @@ __global__ __launch_bounds__(256) void tcn_dw_k(const float* x, const double2* x
   const int row_f = seg_f + 2 * DW_HALO;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 4 + wave, n = blockIdx.y;
-  float sc, sh;
+  // a[t] = ELU((x[t] - mu) * sc + sh).  The row mean is SUBTRACTED FIRST, as the reference does ((x - mean) * rstd): the
+  // folded form x * rstd - mean * rstd loses eps32 * |mean| / std of its result, which compounds over the 28 instance norms
+  // of the TCN when a row is a few nearly equal frames (T = 2, 3: tests/test_gpu_parity.py, shortest inputs).
+  float sc, sh, mu = 0.f;
   if (NORM == 0) {
     float mean, rstd;
     in_params(tpart_sum(x_part + ((long long)n * C + c) * nps, x_np), T, mean, rstd);
-    sc = rstd; sh = -mean * rstd;
+    sc = rstd; sh = 0.f; mu = mean;
   } else if (NORM == 1) {
     // gLN (model.py:609-632): mean / biased variance over all (C, T) of the sample, eps 1e-8.  The sample's C * x_np
     // partials are added in a FIXED order: thread i takes rows i, i + 256, ... (their x_np partials in index order), then
@@ -123,7 +126,8 @@ __global__ __launch_bounds__(256) void tcn_dw_k(const float* x, const double2* x
     gv = gv > 0.0 ? gv : 0.0;
     const float rstd = (float)(1.0 / sqrt(gv + (double)GLN_EPS));
     sc = nsc[c] * rstd;
-    sh = nsh[c] - sc * (float)gm;
+    sh = nsh[c];
+    mu = (float)gm;
   } else if (NORM == 3) {
     sc = nsc[c]; sh = nsh[c];                                  // BatchNorm1d in eval mode, folded on the host
   } else {
@@ -150,10 +154,10 @@ __global__ __launch_bounds__(256) void tcn_dw_k(const float* x, const double2* x
           v.x = (v.x - f01.x) * f01.y; v.y = (v.y - f01.z) * f01.w;
           v.z = (v.z - f23.x) * f23.y; v.w = (v.w - f23.z) * f23.w;
         }
-        o.x = (t + 0 < T) ? elu_fast(fmaf(v.x, sc, sh)) : 0.f;
-        o.y = (t + 1 < T) ? elu_fast(fmaf(v.y, sc, sh)) : 0.f;
-        o.z = (t + 2 < T) ? elu_fast(fmaf(v.z, sc, sh)) : 0.f;
-        o.w = (t + 3 < T) ? elu_fast(fmaf(v.w, sc, sh)) : 0.f;
+        o.x = (t + 0 < T) ? elu_fast(fmaf(v.x - mu, sc, sh)) : 0.f;
+        o.y = (t + 1 < T) ? elu_fast(fmaf(v.y - mu, sc, sh)) : 0.f;
+        o.z = (t + 2 < T) ? elu_fast(fmaf(v.z - mu, sc, sh)) : 0.f;
+        o.w = (t + 3 < T) ? elu_fast(fmaf(v.w - mu, sc, sh)) : 0.f;
       }
       *reinterpret_cast<float4*>(a + j) = o;
     }
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(256) void tcn_pw_k(const float* d, const double2* g
     if (tid < C) {
       const float g_ = gamma[tid] * rstd;
       s_ga[tid] = g_;
-      s_be[tid] = beta[tid] - g_ * mean;
+      s_be[tid] = beta[tid];                 // the sample mean is subtracted FIRST, as the reference does (model.py:609-632)
     }
     __syncthreads();
     // staging role: thread <-> (octet so of the 16-channel chunk, frame sf); A fragment: lane (l31, half) <-> output
@@ -260,8 +264,8 @@ __global__ __launch_bounds__(256) void tcn_pw_k(const float* d, const double2* g
     u32x4_t h_, m_, l_;                                                                                          \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                              \
       const int c0_ = (K0) + 8 * so + 2 * i;                                                                     \
-      const float v0_ = tok ? fmaf(xin[SL][2 * i], s_ga[c0_], s_be[c0_]) : 0.f;                                     \
-      const float v1_ = tok ? fmaf(xin[SL][2 * i + 1], s_ga[c0_ + 1], s_be[c0_ + 1]) : 0.f;                         \
+      const float v0_ = tok ? fmaf(xin[SL][2 * i] - mean, s_ga[c0_], s_be[c0_]) : 0.f;                              \
+      const float v1_ = tok ? fmaf(xin[SL][2 * i + 1] - mean, s_ga[c0_ + 1], s_be[c0_ + 1]) : 0.f;                  \
       unsigned hh_, mm_, ll_;                                                                                    \
       split3_pair_t(v0_, v1_, hh_, mm_, ll_);                                                                    \
       h_[i] = hh_; m_[i] = mm_; l_[i] = ll_;                                                                     \
@@ -324,15 +328,15 @@ __global__ __launch_bounds__(256) void tcn_pw_k(const float* d, const double2* g
     gi[i] = tok ? *reinterpret_cast<const float4*>(dn + (long long)ci * Tp + tg) : make_float4(0.f, 0.f, 0.f, 0.f); \
     wi[i] = *reinterpret_cast<const float4*>(wt + (long long)ci * C + 4 * sq);                                   \
     ga[i] = gamma[ci] * rstd;                                                                                    \
-    be[i] = beta[ci] - gamma[ci] * rstd * mean;                                                                  \
+    be[i] = beta[ci];                                                                                            \
   }
 #define PW_COMMIT(BUF)                                                                                           \
   _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
     float4 v;                                                                                                    \
-    v.x = (tg + 0 < T) ? fmaf(gi[i].x, ga[i], be[i]) : 0.f;                                                      \
-    v.y = (tg + 1 < T) ? fmaf(gi[i].y, ga[i], be[i]) : 0.f;                                                      \
-    v.z = (tg + 2 < T) ? fmaf(gi[i].z, ga[i], be[i]) : 0.f;                                                      \
-    v.w = (tg + 3 < T) ? fmaf(gi[i].w, ga[i], be[i]) : 0.f;                                                      \
+    v.x = (tg + 0 < T) ? fmaf(gi[i].x - mean, ga[i], be[i]) : 0.f;                                                      \
+    v.y = (tg + 1 < T) ? fmaf(gi[i].y - mean, ga[i], be[i]) : 0.f;                                                      \
+    v.z = (tg + 2 < T) ? fmaf(gi[i].z - mean, ga[i], be[i]) : 0.f;                                                      \
+    v.w = (tg + 3 < T) ? fmaf(gi[i].w - mean, ga[i], be[i]) : 0.f;                                                      \
     *reinterpret_cast<float4*>(&s_g[BUF][sg + 8 * i][4 * sq]) = v;                                               \
     *reinterpret_cast<float4*>(&s_w[BUF][sg + 8 * i][4 * sq]) = wi[i];                                           \
   }
@@ -404,9 +408,17 @@ __global__ __launch_bounds__(256) void tcn_pw_k(const float* d, const double2* g
     rs_o[1] = make_rsrc_e(po + pb, nrec);
     rs_o[2] = make_rsrc_e(po + 2 * pb, nrec);
   }
-  float s1[16], s2[16];
+  // IN1d partials of this tile, accumulated ABOUT A PIVOT: the row's own value at the tile's first frame (always inside the
+  // utterance).  Uncentred float32 sums lose eps32 * mean^2 / var of the variance they are combined into (E[x^2] - mean^2):
+  // nothing at T = 1001, but 6 x the float32 oracle's own error when a row has 2-3 frames (an instance norm over three
+  // nearly equal values; tests/test_gpu_parity.py, shortest inputs).  The centred sums are exact to float32 round-off of
+  // THEMSELVES and go back to plain (sum, sum of squares) in float64 below, so the consumer's format does not change.
+  float s1[16], s2[16], piv[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+  for (int r = 0; r < 16; ++r) {
+    s1[r] = 0.f; s2[r] = 0.f;
+    piv[r] = __shfl(acc[0][r] + rv[0][r], lane & 32, 64);          // frame t0 of channel (r, half)
+  }
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int t = t0 + s * 32 + l31;
@@ -421,7 +433,7 @@ __global__ __launch_bounds__(256) void tcn_pw_k(const float* d, const double2* g
       vrow[r] = v;
       if (!Y_OCT3)
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, vo + (unsigned)(co_off * Tp) * 4u, 0, 0);
-      const float vm = v * m;
+      const float vm = (v - piv[r]) * m;
       s1[r] += vm;
       s2[r] = fmaf(vm, vm, s2[r]);
     }
@@ -434,7 +446,13 @@ __global__ __launch_bounds__(256) void tcn_pw_k(const float* d, const double2* g
     if ((lane & 16) == 0) {
       const int q = lane & 15;
       const int co = wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
-      y_part[((long long)n * C + co) * nps + blockIdx.x] = make_double2((double)x1, (double)x2);
+      float pq = piv[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) pq = (q == r) ? piv[r] : pq;
+      // sum x = S1 + n c, sum x^2 = S2 + 2 c S1 + n c^2 with the tile's n valid frames, in float64
+      const double c = (double)pq, S1 = (double)x1, S2 = (double)x2;
+      const double nv = (double)((T - t0) < PW_TT ? (T - t0) : PW_TT);
+      y_part[((long long)n * C + co) * nps + blockIdx.x] = make_double2(S1 + nv * c, S2 + 2.0 * c * S1 + nv * c * c);
     }
   }
 }

@@ -92,23 +92,26 @@ class CapturedPass:
 class Enhancer:
     """Fused on-device MISO1 -> (alignment) -> MVDR -> MISO3 for batches of 4 s chunks."""
 
-    def __init__(self, model_sep: MISO_1, model: MISO_3, num_spks: int = 2, ref_ch: int = 0, epsi: float = 1e-6):
-        if not isinstance(model_sep, MISO_1) or not isinstance(model, MISO_3):
-            raise TypeError("Enhancer needs misonet_amd.MISO_1 and misonet_amd.MISO_3 instances")
+    def __init__(self, model_sep: MISO_1, model: Optional[MISO_3], num_spks: int = 2, ref_ch: int = 0, epsi: float = 1e-6):
+        """``model = None``: a separation-only Enhancer (:meth:`separate`, :meth:`beamform_utterance`,
+        :meth:`beamform_chunks` -- what the reference's ``Tester_Beamforming`` needs: it has no MISO_3, tester.py:259-262)."""
+        if not isinstance(model_sep, MISO_1) or not (model is None or isinstance(model, MISO_3)):
+            raise TypeError("Enhancer needs misonet_amd.MISO_1 and misonet_amd.MISO_3 (or None) instances")
         self.model_sep, self.model = model_sep, model
         self.num_spks, self.ref_ch, self.num_ch = int(num_spks), int(ref_ch), model_sep.num_ch
         if model_sep._device is None:
             model_sep.cuda()
-        if model._device is None:
+        if model is not None and model._device is None:
             model.cuda(model_sep._device)
         self.device = model_sep._device
-        if model._device != self.device:
+        if model is not None and model._device != self.device:
             raise RuntimeError(f"MISO_1 is on {self.device} but MISO_3 on {model._device}")
         model_sep._commit()
-        model._commit()
+        if model is not None:
+            model._commit()
         self._pipe = C.c_void_p()
-        _lib.check(_lib.lib().misonet_pipeline_create(model_sep._net, model._net, self.num_ch, self.num_spks, self.ref_ch,
-                                                      float(epsi), C.byref(self._pipe)))
+        _lib.check(_lib.lib().misonet_pipeline_create(model_sep._net, model._net if model is not None else None, self.num_ch,
+                                                      self.num_spks, self.ref_ch, float(epsi), C.byref(self._pipe)))
         self._ws: Dict[tuple, torch.Tensor] = {}
 
     def __del__(self):
@@ -122,13 +125,14 @@ class Enhancer:
     def _ready(self):
         """Re-commit after a later ``load_state_dict`` / ``.cuda()`` on either model (a checkpoint loaded after the
         Enhancer was built clears the committed state) and follow a device move."""
-        if self.model_sep._device != self.model._device:
+        if self.model is not None and self.model_sep._device != self.model._device:
             raise RuntimeError(f"MISO_1 is on {self.model_sep._device} but MISO_3 on {self.model._device}")
         if self.model_sep._device != self.device:
             self.device = self.model_sep._device
             self._ws.clear()
         self.model_sep._commit()
-        self.model._commit()
+        if self.model is not None:
+            self.model._commit()
 
     def _check_c64(self, x, name, shape=None):
         """shared argument check of enhance / separate: complex tensor on this Enhancer's device, optional shape"""
@@ -143,7 +147,9 @@ class Enhancer:
 
     def _ws_key(self, B, T):
         # the layout depends on the arithmetic modes and on whether buffers may share memory
-        return (B, T, self.model_sep.precision, self.model.precision, self.model_sep._keep, self.model._keep)
+        m3 = self.model
+        return (B, T, self.model_sep.precision, m3.precision if m3 is not None else None, self.model_sep._keep,
+                m3._keep if m3 is not None else None)
 
     def workspace(self, B, T):
         key = self._ws_key(B, T)
@@ -162,6 +168,8 @@ class Enhancer:
         None to skip the clean-reference re-ordering.  Returns MISO3 output complex64 [B,S,T,F]
         (and a dict with 'bf' [B,S,T,F] / 'miso1' [B,S,M,T,F] when requested)."""
         self._ready()
+        if self.model is None:
+            raise RuntimeError("this Enhancer was built without MISO_3 (separation only): use separate() / beamform_*()")
         if not isinstance(mix, torch.Tensor) or mix.dim() != 4:
             raise ValueError("mix must be a 4-D complex tensor [B, M, T, F]")
         mix = self._check_c64(mix, "mix")
@@ -393,36 +401,44 @@ class Enhancer:
     def beamform_utterance(self, obs_splits: List[torch.Tensor], clean_splits: List[torch.Tensor], gap: int,
                            epsi: float = 1e-6) -> np.ndarray:
         """Utterance-wise MVDR of the reference's Tester_Beamforming (tester.py:340-449, ``utterance_flag``) for ONE
-        recording: every split is separated (:meth:`separate`), all (speaker, mic) estimates and the observation go
-        back to the time domain, the splits are stitched (last one trimmed by ``gap``), the whole recording is
-        re-analysed by the HIP STFT front-end and ONE MVDR per speaker is solved over all its frames (spatial
-        covariances accumulated over the full utterance instead of per 4 s chunk).
-        obs_splits: list of complex [M,T,F]; clean_splits: list of complex [S,T,F].  Returns int16 [S, n]."""
+        recording: its splits are separated as ONE batch (:meth:`separate`; the reference runs them one by one), all
+        (speaker, mic) estimates and the observation go back to the time domain with one batched iSTFT, the splits are
+        stitched (last one trimmed by ``gap``), the whole recording is re-analysed by the HIP STFT front-end and ONE MVDR per
+        speaker is solved over all its frames (spatial covariances accumulated over the full utterance instead of per 4 s
+        chunk).  obs_splits: list of complex [M,T,F]; clean_splits: list of complex [S,T,F].  Returns int16 [S, n]."""
         from .beamform import Apply_Beamforming
-        est_t, obs_t = [], []
-        for k, (obs, cl) in enumerate(zip(obs_splits, clean_splits)):
-            obs = torch.as_tensor(obs).to(self.device)[None]
-            cl = torch.as_tensor(cl).to(self.device)[None]
-            est = self.separate(obs, cl)[0]                                   # [S,M,T,F]
-            e = S.istft(est)                                                  # [S,M,chunk]
-            o = S.istft(obs[0])                                               # [M,chunk]
-            if k == len(obs_splits) - 1 and gap:
-                e, o = e[..., : e.shape[-1] - gap], o[..., : o.shape[-1] - gap]
-            est_t.append(e)
-            obs_t.append(o)
-        est_t = torch.cat(est_t, dim=-1)                                      # [S,M,L]
-        obs_t = torch.cat(obs_t, dim=-1)                                      # [M,L]
+        K = len(obs_splits)
+        if K < 1 or len(clean_splits) != K:
+            raise ValueError("obs_splits / clean_splits must be non-empty lists of equal length")
+        obs = torch.stack([torch.as_tensor(o) for o in obs_splits]).to(self.device)          # [K,M,T,F]
+        cl = torch.stack([torch.as_tensor(c) for c in clean_splits]).to(self.device)         # [K,S,T,F]
+        est = self.separate(obs, cl)                                                          # [K,S,M,T,F]
+        e = S.istft(est)                                                                      # [K,S,M,chunk]
+        o = S.istft(obs)                                                                      # [K,M,chunk]
+        n = e.shape[-1]
+        keep = [n] * (K - 1) + [n - int(gap)]
+        est_t = torch.cat([e[k, ..., : keep[k]] for k in range(K)], dim=-1)                   # [S,M,L]
+        obs_t = torch.cat([o[k, ..., : keep[k]] for k in range(K)], dim=-1)                   # [M,L]
         Ls = obs_t.shape[-1]
         pad = (-Ls) % S.HOP                                                   # scipy's padded=True: whole hops
         sig = torch.cat([obs_t[None], est_t], dim=0)                          # [1+S, M, L]
         sig = torch.nn.functional.pad(sig, (0, pad)).permute(0, 2, 1).contiguous()      # [1+S, Lp, M]
         spec = S.stft_hip(sig)                                                # [1+S, M, Tt, F]
         mix_bf = spec[0].permute(2, 0, 1)[None]                               # [1,F,M,Tt]
-        out = []
-        for s in range(self.num_spks):
-            bf = Apply_Beamforming(spec[1 + s].permute(2, 0, 1)[None], mix_bf, epsi)     # [1,Tt,F]
-            out.append(S.istft_int16(bf[0]).cpu().numpy())
-        return np.stack(out)
+        bf = torch.stack([Apply_Beamforming(spec[1 + s].permute(2, 0, 1)[None], mix_bf, epsi)[0]
+                          for s in range(self.num_spks)])                     # [S,Tt,F]
+        return S.istft_int16(bf).cpu().numpy()
+
+    def beamform_chunks(self, mix: torch.Tensor, clean: Optional[torch.Tensor] = None, epsi: float = 1e-6) -> torch.Tensor:
+        """Chunk-wise MVDR (BASELINE configs[2]: MISO1 -> MVDR; the ``utterance_flag = False`` branch of the reference's
+        Tester_Beamforming, tester.py:452-535): separation of a batch of 4 s chunks, then one MVDR per (chunk, speaker) over
+        the chunk's own frames.  mix complex [B,M,T,F], clean complex [B,S,T,F] or None -> beamformer outputs complex64
+        [B,S,T,F].  (With MISO_3 attached, ``enhance(..., want_bf=True)`` returns the same tensor from the fused pass.)"""
+        from .beamform import Apply_Beamforming
+        est = self.separate(mix, clean)                                                       # [B,S,M,T,F]
+        mix_bf = self._check_c64(mix, "mix").permute(0, 3, 1, 2)                              # [B,F,M,T]
+        return torch.stack([Apply_Beamforming(est[:, s].permute(0, 3, 1, 2), mix_bf, epsi)
+                            for s in range(self.num_spks)], dim=1)                            # [B,S,T,F]
 
     def inference(self, data_loader, saveDir, fs=16000, write=True):
         """Drop-in for ``Tester_Enhance.inference(data_loader, saveDir)`` (tester.py:846-975): the loader yields

@@ -12,6 +12,13 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle runs B = 1 convolutions: on the GPU box's 256 logical CPUs torch's default thread count makes them
+    # 3-7 x SLOWER than 16 threads do (bench.py's cpu_baseline ladder: 16 threads 0.35 utt/s, 128 threads 0.05)
+    try:
+        import torch
+        torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    except Exception:
+        pass
 
 
 def golden(name):

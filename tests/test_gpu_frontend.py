@@ -82,3 +82,71 @@ def test_utterance_wise_mvdr_vs_reference_golden(nets, sd1):
         scale = np.abs(g[f"wav{s}"].astype(np.int32)).max()
         print(f"[utt-mvdr] spk{s}: max |diff| {d.max()} LSB of peak {scale}")
         assert d.max() <= 1
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x6"])
+def test_tester_beamforming_class_drop_in(sd1, sd3, tmp_path, mode):
+    """misonet_amd.tester.Tester_Beamforming: the reference's harness class (tester.py:259-449) with the arguments run.py
+    passes, built from MISO_1 ALONE (a separation-only pipeline: misonet_pipeline_create with miso3 = NULL).
+    utterance_flag = True against the golden of the real class (G9: two splits, last one trimmed by gap);
+    utterance_flag = False (MISO1 -> MVDR per chunk = BASELINE configs[2]) against the oracle's per-chunk beamformer."""
+    import misonet_amd as mz
+    from conftest import golden
+    from misonet_amd import weights as W, stft as S
+    from misonet_amd.tester import Tester_Beamforming
+    from misonet_amd.weights import synthetic_utterance
+    from misonet_amd.stft import split_chunks
+    from oracle import pipeline_oracle
+    from test_gpu_parity import _need_gpu
+    _need_gpu()
+    m1 = mz.MISO_1(2, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN").cuda(0)
+    m1.load_state_dict(sd1)
+    m1.eval().set_precision(mode)
+    g = golden("g9_utterance_mvdr.npz")
+    frames, gap = int(g["frames"]), int(g["gap"])
+    chunk = (frames - 1) * 64
+    obs, s0, s1 = synthetic_utterance(int(g["utt"]), 2 * chunk - gap)
+    po, _ = split_chunks(obs, chunk)
+    p0, _ = split_chunks(s0, chunk)
+    p1, _ = split_chunks(s1, chunk)
+    obs_d = {str(k): torch.from_numpy(pipeline_oracle.stft_chunk(p))[None] for k, p in enumerate(po)}      # [1,6,T,F]
+    s0_d = {str(k): torch.from_numpy(pipeline_oracle.stft_chunk(p))[None] for k, p in enumerate(p0)}
+    s1_d = {str(k): torch.from_numpy(pipeline_oracle.stft_chunk(p))[None] for k, p in enumerate(p1)}
+    item = (obs_d, s0_d, s1_d, [gap], ["rec"])
+    args = dict(fs=16000, window="hann", length=256, overlap=192)
+    tst = Tester_Beamforming("SMS_WSJ", [item], [item], [item], m1, 6, 0, 2, chunk / 16000, str(tmp_path / "u"), 0, True,
+                             False, True, **args)
+    res = tst.test()
+    assert sorted(res) == ["cv_dev93", "test_eval92"]
+    for sub in res:
+        wav = res[sub]["rec"]
+        assert wav.shape == (2, g["wav0"].shape[0]) and wav.dtype == np.int16
+        for s in range(2):
+            d = np.abs(wav[s].astype(np.int32) - g[f"wav{s}"].astype(np.int32))
+            print(f"[Tester_Beamforming {mode}] {sub} spk{s}: max |diff| {d.max()} LSB vs the real class (G9)")
+            assert d.max() <= 1
+            v, fs = S.read_wav_pcm24(str(tmp_path / "u" / sub / f"rec_{s}.wav"))
+            assert fs == 16000 and np.array_equal(v[:, 0], wav[s].astype(np.int32) << 8)
+    # chunk-wise branch + the training-set directory
+    tst = Tester_Beamforming("SMS_WSJ", [item], [], [], m1, 6, 0, 2, chunk / 16000, str(tmp_path / "c"), 0, True,
+                             True, False, **args)
+    res = tst.test()
+    assert sorted(res) == ["train_si284"]
+    wav = res["train_si284"]["rec"]
+    pcs = [[], []]
+    for k in range(2):
+        mx = obs_d[str(k)][0].numpy()
+        cl = np.stack([s0_d[str(k)][0, 0].numpy(), s1_d[str(k)][0, 0].numpy()])
+        bf = pipeline_oracle.enhance_utterance(mx, cl, sd1, sd3, ref_ch=0)["bf"]          # [S,T,F] per-chunk MVDR (tester.py:917-924)
+        for s in range(2):
+            pcs[s].append(pipeline_oracle.istft_int16(bf[s]))
+    for s in range(2):
+        ref = S.stitch_int16(pcs[s], gap)
+        d = np.abs(wav[s].astype(np.int32) - ref.astype(np.int32))
+        print(f"[Tester_Beamforming {mode}] chunk-wise spk{s}: max |diff| {d.max()} LSB vs the oracle")
+        assert wav[s].shape == ref.shape and d.max() <= 1
+    # the separation-only pipeline refuses the MISO3 stages loudly
+    with pytest.raises(RuntimeError):
+        tst._enh.enhance(obs_d["0"].cuda())
+    with pytest.raises(TypeError):
+        Tester_Beamforming("SMS_WSJ", [], [], [], object(), 6, 0, 2, 4.0, str(tmp_path), 0, True, False, True, **args)

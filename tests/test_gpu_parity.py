@@ -112,16 +112,49 @@ def test_miso1_ragged_batched_vs_oracle(nets, sd1, B, T):
 
 
 @pytest.mark.parametrize("T", [2, 3, 4])
-def test_miso1_shortest_inputs_vs_oracle(nets, sd1, T):
+def test_miso1_shortest_inputs_vs_oracle(nets, sd1, T, request):
     """The shortest inputs the reference accepts (T = 2: its instance norms need more than one element at the F = 1
-    bottleneck, model.py:89): every tile is ragged in T and the dilated TCN taps (dilation up to 64) fall outside the signal."""
+    bottleneck, model.py:89): every tile is ragged in T and the dilated TCN taps (dilation up to 64) fall outside the signal.
+    From T = 4 on the usual bound against the float32 oracle holds.  At T = 2, 3 the FUNCTION ITSELF is ill-conditioned: the
+    TCN is 28 instance norms over 2-3 values, and a channel whose frames nearly coincide is re-amplified by 1 / sqrt(eps) =
+    316 at every norm until it saturates -- the float64 oracle turns the 5e-5 difference between this build's and its own
+    encoder output into 2e-2 at the TCN output (and the float32 oracle's 8e-5 difference into 2e-5: the direction of the
+    round-off decides), the float32 oracle moves by 9e-4 at T = 3 when only its thread count changes (all measured,
+    tools/tmp experiments of round 4).  A bound on the END result is therefore meaningless there; what is checked instead
+    is every part on ITS OWN input, against the oracle in float64: the encoder (well-conditioned) end to end, the TCN on the
+    encoder output this build produced, and that the result is finite and of the right size.  (This case made the TCN subtract
+    its means before scaling and accumulate its statistics about a pivot -- tcn.hip -- which took the TCN's own error at
+    T = 2 from 4e-4 to 2e-5 ... 1e-4.)"""
     from oracle import miso_oracle
     m1, _ = nets
     r = np.random.default_rng(77 + T)
     x = (r.standard_normal((2, 6, T, 129)) + 1j * r.standard_normal((2, 6, T, 129))).astype(np.complex64)
+    if T >= 4:
+        y = m1(torch.from_numpy(x).cuda()).cpu().numpy()
+        y_ref = np.concatenate([miso_oracle.miso1_forward(torch.from_numpy(x[b:b + 1]), sd1).numpy() for b in range(2)])
+        _assert_parity(y, y_ref, f"miso1 T={T} vs oracle")
+        return
+    m1.keep_activations(True)
+    request.addfinalizer(lambda: m1.keep_activations(False))
     y = m1(torch.from_numpy(x).cuda()).cpu().numpy()
-    y_ref = np.concatenate([miso_oracle.miso1_forward(torch.from_numpy(x[b:b + 1]), sd1).numpy() for b in range(2)])
-    _assert_parity(y, y_ref, f"miso1 T={T} vs oracle")
+    assert y.shape == (2, 2, T, 129) and np.isfinite(y.view(np.float32)).all()
+    enc5 = m1.tap("enc5", 2, T).cpu().numpy().astype(np.float64)
+    enc6 = m1.tap("enc6", 2, T).cpu().numpy().astype(np.float64)[..., 0]               # [B,128,T]
+    tcn = m1.tap("tcn_out", 2, T).cpu().numpy().astype(np.float64)[..., 0]
+    for b in range(2):
+        t64 = {}
+        with miso_oracle.precision(torch.float64):
+            truth = miso_oracle.miso1_forward(torch.from_numpy(x[b:b + 1]).to(torch.complex128), sd1, t64).numpy()
+            tcn_local = miso_oracle.tcn_forward(torch.from_numpy(enc6[b:b + 1]), sd1).numpy()
+        e5 = rel_l2(enc5[b:b + 1], t64["enc5"].numpy())
+        e6 = rel_l2(enc6[b:b + 1], t64["enc6"].numpy()[..., 0])
+        et = rel_l2(tcn[b:b + 1], tcn_local)
+        eo = mag_parity(y[b:b + 1], truth)[0]
+        print(f"[parity] miso1 T={T} sample {b}: encoder 5 {e5:.2e}, encoder 6 {e6:.2e} vs float64 truth; TCN on its own input "
+              f"{et:.2e}; end result {eo:.2e} (ill-conditioned, not bounded at 1e-3)")
+        assert e5 <= 2e-5 and e6 <= 1e-3, (T, b, e5, e6)      # encoder 6 is one instance norm over T values per channel
+        assert et <= 5e-3, (T, b, et)
+        assert eo <= 0.2, (T, b, eo)
 
 
 def test_forward_errors(nets):
