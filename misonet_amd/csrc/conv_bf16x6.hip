@@ -878,6 +878,19 @@ __global__ __launch_bounds__(288) void conv_wprep6_k(const float* wf, const dsta
   const int per_part = (nchunk + nparts - 1) / nparts;
   const int kc_lo = blockIdx.y * per_part;
   const int kc_hi = (kc_lo + per_part) < nchunk ? (kc_lo + per_part) : nchunk;
+  // the first batch of weight loads does not depend on the statistics: put it in flight AHEAD of them (one global round trip
+  // less in a kernel that is two dependent round trips and a launch long)
+  const int tap = tid >> 5, co = tid & 31;
+  const float* wsrc = wf + ((long long)cg * nchunk * 9 + tap) * (32 * 8) + co * 8;
+  constexpr int U = 4;                               // chunks per batch: the loads of a batch are issued together
+  float4 wl[U][2];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int kc = (kc_lo + u < kc_hi) ? kc_lo + u : kc_hi - 1;
+    const float4* src = reinterpret_cast<const float4*>(wsrc + (long long)kc * (9 * 32 * 8));
+    wl[u][0] = src[0];
+    wl[u][1] = src[1];
+  }
   for (int c = kc_lo * 8 + tid; c < kc_hi * 8; c += 288) {
     float mean = 0.f, rstd = (c < Cin) ? 1.f : 0.f;
     if (c >= ident_c && c < Cin) {
@@ -892,23 +905,21 @@ __global__ __launch_bounds__(288) void conv_wprep6_k(const float* wf, const dsta
     s_nrm[c] = make_float2(rstd, -mean * rstd);
   }
   __syncthreads();
-  const int tap = tid >> 5, co = tid & 31;
   const int kt = tap / 3, kf = tap - 3 * kt;
-  const float* wsrc = wf + ((long long)cg * nchunk * 9 + tap) * (32 * 8) + co * 8;
   u32x4_t* wdst = reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(wps) + (long long)n * wps_nstride_b) +
                   (long long)cg * nchunk * X6_WU;
   const int ubase = kt < 2 ? (kf * 3 * 2 + kt) * 32 + co : X6_WPAIR + (kf * 3) * 32 + co;
   const int ustep = kt < 2 ? 2 * 32 : 32;            // units between the parts
   double bsum = 0.0;
-  constexpr int U = 4;                               // chunks per batch: the loads of a batch are issued together
   for (int kc0 = kc_lo; kc0 < kc_hi; kc0 += U) {
-    float4 wl[U][2];
+    if (kc0 != kc_lo) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int kc = (kc0 + u < kc_hi) ? kc0 + u : kc_hi - 1;
-      const float4* src = reinterpret_cast<const float4*>(wsrc + (long long)kc * (9 * 32 * 8));
-      wl[u][0] = src[0];
-      wl[u][1] = src[1];
+      for (int u = 0; u < U; ++u) {
+        const int kc = (kc0 + u < kc_hi) ? kc0 + u : kc_hi - 1;
+        const float4* src = reinterpret_cast<const float4*>(wsrc + (long long)kc * (9 * 32 * 8));
+        wl[u][0] = src[0];
+        wl[u][1] = src[1];
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {

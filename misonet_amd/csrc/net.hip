@@ -636,7 +636,7 @@ const char* misonet_strerror(int code) {
   }
 }
 const char* misonet_last_error(void) { return g_err; }
-int misonet_version(void) { return 400; }
+int misonet_version(void) { return 410; }   // 410: misonet_pipeline_create accepts miso3 == NULL (separation-only pipeline)
 
 int misonet_net_create(const misonet_cfg* cfg, misonet_net** out) {
   if (!cfg || !out) return fail(MISONET_EINVAL, "null argument");
