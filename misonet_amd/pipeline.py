@@ -440,7 +440,7 @@ class Enhancer:
         return torch.stack([Apply_Beamforming(est[:, s].permute(0, 3, 1, 2), mix_bf, epsi)
                             for s in range(self.num_spks)], dim=1)                            # [B,S,T,F]
 
-    def inference(self, data_loader, saveDir, fs=16000, write=True):
+    def inference(self, data_loader, saveDir, fs=16000, write=True, max_batch=32):
         """Drop-in for ``Tester_Enhance.inference(data_loader, saveDir)`` (tester.py:846-975): the loader yields
         ``(split_observe_dict, split_clean_s0_dict, split_clean_s1_dict, gap, wav_name)`` with dict values complex
         ``[B, Ch, T, F]`` keyed '0', '1', ... (dataloader/data.py:524-597).  Every split runs through
@@ -480,13 +480,22 @@ class Enhancer:
             prev = None
             for (obs_d, s0_d, s1_d, gap, wav_name) in data_loader:
                 n_split = len(obs_d)
-                outs = []
+                obs, cl = [], []
                 for k in range(n_split):
-                    obs = h2d(obs_d[str(k)])
+                    obs.append(h2d(obs_d[str(k)]))
                     s0 = h2d(torch.as_tensor(s0_d[str(k)])[:, self.ref_ch])                   # tester.py:889-890
                     s1 = h2d(torch.as_tensor(s1_d[str(k)])[:, self.ref_ch])
-                    outs.append(self.enhance(obs, torch.stack((s0, s1), dim=1)))              # [B,S,T,F]
-                pcm = S.istft_int16(torch.stack(outs))           # ONE batched iSTFT over n_split * B * S spectrograms
+                    cl.append(torch.stack((s0, s1), dim=1))
+                # the 4 s splits of a loader item are independent chunks of equal length (dataloader/data.py:558-595): they run
+                # as ONE batch of n_split * B utterances (the reference: one pass per split), in groups of at most
+                # ``max_batch``.  Bit-identical to split-by-split (results do not depend on the batch).
+                Bk = obs[0].shape[0]
+                obs, cl = torch.cat(obs), torch.cat(cl)                                        # [n_split * B, ...]
+                out = torch.empty((obs.shape[0], self.num_spks) + tuple(obs.shape[2:]), dtype=torch.complex64, device=dev)
+                for lo in range(0, obs.shape[0], max_batch):
+                    self.enhance(obs[lo:lo + max_batch], cl[lo:lo + max_batch], out=out[lo:lo + max_batch])
+                outs = out.reshape((n_split, Bk) + tuple(out.shape[1:]))                       # [n_split,B,S,T,F]
+                pcm = S.istft_int16(outs)                        # ONE batched iSTFT over n_split * B * S spectrograms
                 ev_done = torch.cuda.Event()
                 ev_done.record(torch.cuda.current_stream(dev))
                 rec = {"pcm_h": torch.empty(pcm.shape, dtype=torch.int16, pin_memory=True), "gap": gap, "name": wav_name}
