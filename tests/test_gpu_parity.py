@@ -261,6 +261,48 @@ def test_pipeline_vs_golden_and_oracle(nets, sd1, sd3):
         assert d.max() <= 1
 
 
+def test_pipeline_8khz_and_ref_ch_vs_reference_goldens(nets):
+    """G13 / G14 (oracle/gen_golden_more.py): the REAL ``Tester_Enhance.inference`` at the committed config's 8 kHz geometry
+    (T = 501; the STFT scaling does not depend on fs, only the frame count does) and with ``ref_ch = 2`` (alignment anchor,
+    clean-reference microphone and MISO3 input all move with it, tester.py:874, 889-890, 937, 1030-1038)."""
+    import misonet_amd as mz
+    from misonet_amd.weights import synthetic_utterance
+    from oracle import pipeline_oracle
+    m1, m3 = nets
+    # ---- G13 ----
+    g = golden("g13_pipeline_8k_T501.npz")
+    T, st = int(g["frames"]), int(g["frame_step"])
+    obs, s0, s1 = synthetic_utterance(int(g["utt"]), (T - 1) * 64)
+    mix = pipeline_oracle.stft_chunk(obs, 8000)
+    clean = np.stack([pipeline_oracle.stft_chunk(s0, 8000)[0], pipeline_oracle.stft_chunk(s1, 8000)[0]])
+    enh = mz.Enhancer(m1, m3, num_spks=2, ref_ch=0)
+    out, ex = enh.enhance(torch.from_numpy(mix[None]).cuda(), torch.from_numpy(clean[None]).cuda(), want_bf=True, want_miso1=True)
+    _assert_parity(ex["miso1"][0].cpu().numpy()[:, 0, ::st], g["miso1_ref_frames"], "8 kHz T=501 miso1@ref vs golden G13")
+    _assert_parity(ex["bf"][0].cpu().numpy()[:, ::st], g["bf_frames"], "8 kHz T=501 bf vs golden G13")
+    _assert_parity(out[0].cpu().numpy()[:, ::st], g["out_frames"], "8 kHz T=501 miso3 vs golden G13")
+    assert rel_l2(np.abs(out[0].cpu().numpy()).astype(np.float64).sum(-1), g["out_magsum"]) <= 1e-4
+    wav = enh.to_wav_int16([out[0]], gap=0)
+    for s in range(2):
+        d = np.abs(wav[s][::8].astype(np.int32) - g["wav_dec8"][s].astype(np.int32))
+        assert d.max() <= 1, d.max()
+        a = np.abs(wav[s].astype(np.int64)).reshape(-1, 1000).sum(-1)
+        assert np.max(np.abs(a - g["wav_abssum_1000"][s])) <= 1000
+    # ---- G14 ----
+    g = golden("g14_pipeline_refch2_T64.npz")
+    T, rc = int(g["frames"]), int(g["ref_ch"])
+    obs, s0, s1 = synthetic_utterance(int(g["utt"]), (T - 1) * 64)
+    mix = pipeline_oracle.stft_chunk(obs)
+    clean = np.stack([pipeline_oracle.stft_chunk(s0)[rc], pipeline_oracle.stft_chunk(s1)[rc]])
+    enh = mz.Enhancer(m1, m3, num_spks=2, ref_ch=rc)
+    out, ex = enh.enhance(torch.from_numpy(mix[None]).cuda(), torch.from_numpy(clean[None]).cuda(), want_bf=True, want_miso1=True)
+    _assert_parity(ex["miso1"][0].cpu().numpy()[:, rc], g["miso1_ref"], "ref_ch=2 miso1@ref vs golden G14")
+    _assert_parity(ex["bf"][0].cpu().numpy(), g["bf"], "ref_ch=2 bf vs golden G14")
+    _assert_parity(out[0].cpu().numpy(), g["out"], "ref_ch=2 miso3 vs golden G14")
+    wav = enh.to_wav_int16([out[0]], gap=0)
+    for s in range(2):
+        assert np.abs(wav[s].astype(np.int32) - g["wav"][s].astype(np.int32)).max() <= 1
+
+
 def test_pipeline_without_clean_and_ref_ch(nets, sd1, sd3):
     """clean=None skips the clean re-ordering; ref_ch != 0 changes the alignment anchor and the MISO3 input."""
     import misonet_amd as mz

@@ -112,6 +112,49 @@ def test_g12_full_size_reference(sd1, sd3):
         assert np.max(np.abs(a - g["wav_abssum_1000"][s])) <= 2 * 1000
 
 
+def _g13_inputs(g, fs):
+    from misonet_amd.weights import synthetic_utterance
+    T = int(g["frames"])
+    obs, s0, s1 = synthetic_utterance(int(g["utt"]), (T - 1) * 64)
+    rc = int(g["ref_ch"]) if "ref_ch" in g.files else 0
+    mix = pipeline_oracle.stft_chunk(obs, fs)
+    clean = np.stack([pipeline_oracle.stft_chunk(s0, fs)[rc], pipeline_oracle.stft_chunk(s1, fs)[rc]])
+    return mix, clean, rc
+
+
+def test_g13_8khz_pipeline_reference(sd1, sd3):
+    """G13: the real Tester_Enhance.inference at the committed config's 8 kHz geometry (T = 501), oracle/gen_golden_more.py."""
+    g = golden("g13_pipeline_8k_T501.npz")
+    st = int(g["frame_step"])
+    mix, clean, _ = _g13_inputs(g, 8000)
+    assert mix.shape == (6, 501, 129)
+    r = pipeline_oracle.enhance_utterance(mix, clean, sd1, sd3, ref_ch=0)
+    assert rel_l2(r["miso1"][:, 0, ::st], g["miso1_ref_frames"]) < 5e-5
+    assert rel_l2(r["bf"][:, ::st], g["bf_frames"]) < 5e-4
+    rl2, bad = mag_parity(r["out"][:, ::st], g["out_frames"])
+    assert rl2 < 2e-4 and bad < 1e-3
+    assert rel_l2(np.abs(r["out"]).astype(np.float64).sum(-1), g["out_magsum"]) < 1e-4
+    for s in range(2):
+        w = pipeline_oracle.istft_int16(r["out"][s], 8000)
+        assert np.max(np.abs(w[::8].astype(np.int32) - g["wav_dec8"][s].astype(np.int32))) <= 2
+
+
+def test_g14_ref_ch2_pipeline_reference(sd1, sd3):
+    """G14: the real Tester_Enhance.inference with ref_ch = 2 (anchor of the shift alignment, microphone of the clean
+    references and of the MISO3 input: tester.py:874, 889-890, 937, 1030-1038)."""
+    g = golden("g14_pipeline_refch2_T64.npz")
+    mix, clean, rc = _g13_inputs(g, 16000)
+    assert rc == 2
+    r = pipeline_oracle.enhance_utterance(mix, clean, sd1, sd3, ref_ch=rc)
+    assert rel_l2(r["miso1"][:, rc], g["miso1_ref"]) < 5e-5
+    assert rel_l2(r["bf"], g["bf"]) < 5e-4
+    rl2, bad = mag_parity(r["out"], g["out"])
+    assert rl2 < 2e-4 and bad < 1e-3
+    for s in range(2):
+        w = pipeline_oracle.istft_int16(r["out"][s])
+        assert np.max(np.abs(w.astype(np.int32) - g["wav"][s].astype(np.int32))) <= 2
+
+
 def test_g8_sample_clean_config1(sd1):
     """BASELINE.json configs[0]: first 4 s of sample/Clean (8 kHz, 6 mics) through one MISO_1 forward."""
     g = golden("g8_sample_clean_miso1.npz")
