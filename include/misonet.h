@@ -181,6 +181,14 @@ long long misonet_stft_workspace_bytes(int B, int M, int n_samples);
 int misonet_stft(const float* wav_dev, int B, int n_samples, int M, void* out_dev, void* ws_dev, long long ws_bytes,
                  misonet_stream stream);
 
+/* ---- iSTFT + int16: Tester_Enhance.ISTFT and the post-processing of tester.py:949-952, 979-990 ("x scale" ->
+ * scipy.signal.istft(hann, 256, 192) -> "x 32767" -> astype(int16)) (ABI 420) ---------------------------------------- */
+/* spec_dev complex64 [N, T, 129] (the boundary layout of every output above, T >= 2) -> 64 (T - 1) samples per row:
+ * out_i16_dev int16 [N, 64 (T - 1)] (truncating cast of y * 32767) and / or out_f32_dev float32 of the same shape (either
+ * may be NULL).  The windowed inverse DFT runs on the fp32 matrix cores, overlap-add and the division by the window
+ * envelope follow on chip.  Its table (267 KB) is allocated once per device, on first use there. */
+int misonet_istft(const void* spec_dev, int N, int T, void* out_i16_dev, float* out_f32_dev, misonet_stream stream);
+
 /* ---- per-launch timing (bench.py roofline leg): while enabled, the library brackets every conv launch, the TCN
  * section and the MVDR section of each forward with HIP events on the caller's stream.  kinds: 0 = 3x3 conv kernel
  * launches, 1 = TCN sections, 2 = MVDR sections, 3 = other (conv_wprep_k, the per-sample weight preparation of the

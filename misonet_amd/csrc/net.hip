@@ -24,6 +24,10 @@ hipError_t launch_assemble3(const float* in1, long long in1_bstride, const float
 hipError_t launch_stft_pack(const float* wav, int B, int L, int Mw, int T, const float* twid, float* dst,
                             long long dst_bstride, int Tp, int F, int c_re, int c_im, int nshift, hipStream_t s);
 hipError_t stft_init();
+hipError_t launch_istft(const void* spec, int N, int T, const float* itw, short* out_i16, float* out_f32, hipStream_t s);
+hipError_t istft_init();
+void istft_build_twiddles(float* tw);
+int istft_twiddle_count();
 void stft_build_twiddles(float* tw);
 int stft_twiddle_count();
 }  // namespace mn
@@ -636,7 +640,7 @@ const char* misonet_strerror(int code) {
   }
 }
 const char* misonet_last_error(void) { return g_err; }
-int misonet_version(void) { return 410; }   // 410: misonet_pipeline_create accepts miso3 == NULL (separation-only pipeline)
+int misonet_version(void) { return 420; }   // 410: misonet_pipeline_create accepts miso3 == NULL (separation-only pipeline); 420: misonet_istft
 
 int misonet_net_create(const misonet_cfg* cfg, misonet_net** out) {
   if (!cfg || !out) return fail(MISONET_EINVAL, "null argument");
@@ -1048,6 +1052,33 @@ static int get_twiddles(const float** out) {
     g_twid[d] = p;
   }
   *out = g_twid[d];
+  return MISONET_OK;
+}
+
+static float* g_itwid[MAX_DEV] = {};
+static int get_itwiddles(const float** out) {
+  const int d = cur_dev();
+  if (!g_itwid[d]) {
+    std::vector<float> tw((size_t)istft_twiddle_count());
+    istft_build_twiddles(tw.data());
+    float* p = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&p), tw.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(p, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(istft_init());
+    g_itwid[d] = p;
+  }
+  *out = g_itwid[d];
+  return MISONET_OK;
+}
+
+int misonet_istft(const void* spec_dev, int N, int T, void* out_i16_dev, float* out_f32_dev, misonet_stream stream) {
+  if (!spec_dev || (!out_i16_dev && !out_f32_dev)) return fail(MISONET_EINVAL, "null argument");
+  if (N <= 0 || T < 2) return fail(MISONET_EINVAL, "N must be positive and T >= 2 (got %d, %d)", N, T);
+  const float* tw;
+  int r = get_itwiddles(&tw);
+  if (r) return r;
+  HIPCHK(launch_istft(spec_dev, N, T, tw, reinterpret_cast<short*>(out_i16_dev), out_f32_dev,
+                      reinterpret_cast<hipStream_t>(stream)));
   return MISONET_OK;
 }
 

@@ -336,10 +336,19 @@ class Enhancer:
                 sl = slots[i % depth]
                 src_w = staged(sl, "wav", wav_h)
                 src_c = staged(sl, "clean", clean_h) if clean_h is not None else None
+                fresh = False
                 if sl.get("wav_d") is None or sl["wav_d"].shape != src_w.shape:
                     sl["wav_d"] = torch.empty(src_w.shape, dtype=torch.float32, device=dev)
+                    fresh = True
                 if src_c is not None and (sl.get("clean_d") is None or sl["clean_d"].shape != src_c.shape):
                     sl["clean_d"] = torch.empty(src_c.shape, dtype=torch.float32, device=dev)
+                    fresh = True
+                if fresh:
+                    # a new slot buffer comes out of the CURRENT stream's allocator pool: its block may be one that work
+                    # already queued on the current stream still writes (e.g. the previous batch's spectrogram, freed on the
+                    # host the moment its iSTFT was enqueued).  The copy-in stream must not touch it before that work is
+                    # done.  (Found when the iSTFT became a HIP kernel: torch.istft synchronises the host, which had hidden it.)
+                    s_in.wait_stream(cur)
                 with torch.cuda.stream(s_in):
                     if "ev_free" in sl:
                         s_in.wait_event(sl["ev_free"])        # the pass that read this slot's device buffers is done

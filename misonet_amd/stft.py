@@ -7,7 +7,9 @@
   * synthesis : tester.py:949-952, 979-990 -- istft(spec * scale) * 32767 -> int16 (truncation toward zero)
 
 torch.stft/istft with center=True, zero padding and a periodic hann window compute the same transforms (checked
-against SciPy in tests/test_stft.py).  PyTorch is used here as the north_star allows ("tensor containers and iSTFT").
+against SciPy in tests/test_stft.py).  On the device both directions are hand-written HIP (csrc/stft.hip: ``stft_hip``, and
+since round 4 the iSTFT + int16 of :func:`istft` / :func:`istft_int16`); torch's versions remain for CPU tensors (tests, host
+tools) -- the north_star allows PyTorch for "tensor containers and iSTFT".
 """
 from __future__ import annotations
 
@@ -17,6 +19,7 @@ import numpy as np
 import torch
 
 NPERSEG, HOP = 256, 64
+N_FREQ = NPERSEG // 2 + 1
 MAX_INT16 = 32767
 
 
@@ -53,10 +56,28 @@ def stft(wav: torch.Tensor) -> torch.Tensor:
     return z.transpose(1, 2).reshape(*lead, z.shape[2], z.shape[1]).to(torch.complex64)
 
 
-def istft(spec: torch.Tensor, length: int = None) -> torch.Tensor:
-    """complex [..., T, F] -> float32 [..., (T-1)*64]: inverse of :func:`stft` (== scipy istft(spec * scale))."""
+def _istft_hip(spec: torch.Tensor, want_i16: bool) -> torch.Tensor:
+    """The hand-written HIP iSTFT (csrc/stft.hip ``istft_k``, C ABI ``misonet_istft``): device complex [..., T, 129] ->
+    float32 or int16 [..., 64 (T - 1)] (windowed inverse DFT on the fp32 matrix cores, overlap-add, envelope division and --
+    for int16 -- ``x 32767`` and the truncating cast in one launch)."""
+    from . import _lib
     lead = spec.shape[:-2]
     T, F = spec.shape[-2:]
+    z = spec.reshape(-1, T, F).to(torch.complex64).contiguous()
+    out = torch.empty((z.shape[0], (T - 1) * HOP), dtype=torch.int16 if want_i16 else torch.float32, device=z.device)
+    with torch.cuda.device(z.device):
+        _lib.check(_lib.lib().misonet_istft(z.data_ptr(), z.shape[0], T, out.data_ptr() if want_i16 else None,
+                                            None if want_i16 else out.data_ptr(), _lib.stream_ptr(z.device)))
+    return out.reshape(*lead, (T - 1) * HOP)
+
+
+def istft(spec: torch.Tensor, length: int = None) -> torch.Tensor:
+    """complex [..., T, F] -> float32 [..., (T-1)*64]: inverse of :func:`stft` (== scipy istft(spec * scale)).  Device tensors
+    of the network geometry run the HIP kernel; CPU tensors (tests, host tools) and other lengths go through torch."""
+    lead = spec.shape[:-2]
+    T, F = spec.shape[-2:]
+    if spec.is_cuda and F == N_FREQ and T >= 2 and (length is None or length == (T - 1) * HOP) and spec.numel() > 0:
+        return _istft_hip(spec, False)
     z = spec.reshape(-1, T, F).transpose(1, 2).to(torch.complex64)
     n = (T - 1) * HOP if length is None else length
     x = torch.istft(z, n_fft=NPERSEG, hop_length=HOP, win_length=NPERSEG, window=_window(z.device), center=True,
@@ -66,6 +87,8 @@ def istft(spec: torch.Tensor, length: int = None) -> torch.Tensor:
 
 def istft_int16(spec: torch.Tensor) -> torch.Tensor:
     """tester.py:950-952: time signal * 32767 -> int16 (C-style truncation, like ndarray.astype(np.int16))."""
+    if spec.is_cuda and spec.shape[-1] == N_FREQ and spec.shape[-2] >= 2 and spec.numel() > 0:
+        return _istft_hip(spec, True)
     return (istft(spec) * MAX_INT16).to(torch.int16)
 
 

@@ -63,6 +63,24 @@ def test_stream_wav_equals_batch_by_batch(nets, depth):
         assert np.array_equal(g, w)
 
 
+def test_stream_wav_fresh_slot_buffers_wait_for_queued_work(nets):
+    """Regression (round 4): a slot's device buffer is allocated from the current stream's pool while earlier batches are
+    still queued -- its block can be the previous batch's spectrogram, which that batch's pipeline has yet to write.  The
+    copy-in stream must wait for the queued work before its first copy into a fresh buffer; without that the SECOND batch ran
+    on bytes of the first one's spectrogram (hidden for three rounds by torch.istft's host synchronisation, exposed when the
+    iSTFT became a HIP kernel).  Short utterances, three different batches, repeated generators."""
+    import misonet_amd as mz
+    m1, m3 = nets
+    enh = mz.Enhancer(m1, m3, num_spks=2, ref_ch=0)
+    n = 20 * 64
+    items = [_wav_batches(n, (u,)) for u in (1, 2, 1)]
+    want = [enh.enhance_wav_int16(w.cuda(), c.cuda()).cpu().numpy() for w, c in items]
+    for _ in range(5):
+        got = list(enh.stream_wav(iter(items), depth=2, check_nan=False))
+        for k, (g, w) in enumerate(zip(got, want)):
+            assert np.array_equal(g, w), f"batch {k} of the stream differs from the synchronous result"
+
+
 def test_stream_wav_reports_nan_of_the_right_batch(nets):
     import misonet_amd as mz
     m1, m3 = nets
