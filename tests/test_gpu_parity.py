@@ -120,7 +120,7 @@ def test_miso1_shortest_inputs_vs_oracle(nets, sd1, T, request):
     316 at every norm until it saturates -- the float64 oracle turns the 5e-5 difference between this build's and its own
     encoder output into 2e-2 at the TCN output (and the float32 oracle's 8e-5 difference into 2e-5: the direction of the
     round-off decides), the float32 oracle moves by 9e-4 at T = 3 when only its thread count changes (all measured,
-    tools/tmp experiments of round 4).  A bound on the END result is therefore meaningless there; what is checked instead
+    tools/experiments/tcn_*.py, round 4).  A bound on the END result is therefore meaningless there; what is checked instead
     is every part on ITS OWN input, against the oracle in float64: the encoder (well-conditioned) end to end, the TCN on the
     encoder output this build produced, and that the result is finite and of the right size.  (This case made the TCN subtract
     its means before scaling and accumulate its statistics about a pivot -- tcn.hip -- which took the TCN's own error at

@@ -1,5 +1,6 @@
+"""Round-4 experiment (GPU): the HIP iSTFT against SciPy (float64) and torch, and its time against torch.istft."""
 import sys, time, numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, ".")
 from misonet_amd import stft as S
 import scipy.signal
 torch.manual_seed(0)

@@ -1,5 +1,7 @@
+"""Round-4 experiment (GPU): batches through Enhancer.stream_wav against the synchronous result of each batch (the race of a
+fresh slot buffer with queued work showed here as a second batch that depended on the FIRST batch's data)."""
 import sys, os, numpy as np, torch
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+sys.path.insert(0, "."); sys.path.insert(0, 'tests')
 import misonet_amd as mz
 from misonet_amd import weights as W, _lib, stft as S
 sd1 = W.make_state_dict(W.miso1_spec(), 0); sd3 = W.make_state_dict(W.miso3_spec(), 1)

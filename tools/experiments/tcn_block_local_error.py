@@ -1,6 +1,8 @@
+"""Round-4 experiment (GPU): error of every TCN block of the HIP path ON ITS OWN INPUT (weights of the later blocks zeroed, so
+that the tcn_out tap shows the state after k blocks) against the float64 oracle block.  usage: python tools/experiments/tcn_block_local_error.py T sample mode"""
 import sys, numpy as np, torch
 import torch.nn.functional as F
-sys.path.insert(0, '.')
+sys.path.insert(0, ".")
 import misonet_amd as mz
 from misonet_amd import weights as W
 from oracle import miso_oracle

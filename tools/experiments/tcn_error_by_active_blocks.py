@@ -1,5 +1,7 @@
+"""Round-4 experiment (GPU): error at the TCN output against float64 as a function of the number of active TCN blocks
+(the point-wise conv weights of the later blocks zeroed).  usage: python tools/experiments/tcn_error_by_active_blocks.py T sample mode"""
 import sys, numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, ".")
 import misonet_amd as mz
 from misonet_amd import weights as W
 from oracle import miso_oracle

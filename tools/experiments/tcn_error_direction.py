@@ -1,5 +1,7 @@
+"""Round-4 experiment (GPU): what the float64 TCN does to the difference between the build's encoder output and the oracle's,
+at T = 2 -- the amplification depends on the direction of the round-off (LAB, round 4)."""
 import sys, numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, ".")
 import misonet_amd as mz
 from misonet_amd import weights as W
 from oracle import miso_oracle
