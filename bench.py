@@ -253,7 +253,7 @@ def pmc_live(precision, B, T, timeout_s=150):
 
 def _traffic_entry(precision):
     """measured HBM bytes per conv launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/)"""
-    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r04z_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", name)))
             if precision in tj:
