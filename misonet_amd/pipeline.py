@@ -408,7 +408,7 @@ class Enhancer:
         return m1
 
     def beamform_utterance(self, obs_splits: List[torch.Tensor], clean_splits: List[torch.Tensor], gap: int,
-                           epsi: float = 1e-6) -> np.ndarray:
+                           epsi: float = 1e-6, max_batch: int = 16) -> np.ndarray:
         """Utterance-wise MVDR of the reference's Tester_Beamforming (tester.py:340-449, ``utterance_flag``) for ONE
         recording: its splits are separated as ONE batch (:meth:`separate`; the reference runs them one by one), all
         (speaker, mic) estimates and the observation go back to the time domain with one batched iSTFT, the splits are
@@ -421,7 +421,8 @@ class Enhancer:
             raise ValueError("obs_splits / clean_splits must be non-empty lists of equal length")
         obs = torch.stack([torch.as_tensor(o) for o in obs_splits]).to(self.device)          # [K,M,T,F]
         cl = torch.stack([torch.as_tensor(c) for c in clean_splits]).to(self.device)         # [K,S,T,F]
-        est = self.separate(obs, cl)                                                          # [K,S,M,T,F]
+        est = torch.cat([self.separate(obs[lo:lo + max_batch], cl[lo:lo + max_batch])          # [K,S,M,T,F], in groups of
+                         for lo in range(0, K, max_batch)])                                   # <= max_batch splits (workspace)
         e = S.istft(est)                                                                      # [K,S,M,chunk]
         o = S.istft(obs)                                                                      # [K,M,chunk]
         n = e.shape[-1]
