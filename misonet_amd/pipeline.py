@@ -286,7 +286,7 @@ class Enhancer:
     def enhance_wav_int16(self, wav: torch.Tensor, clean_wav: Optional[torch.Tensor] = None, check_nan=True) -> torch.Tensor:
         """The reference's unit of work on the device: wav in -> int16 wav out (tester.py:865-867 H2D ... 949-952 iSTFT,
         x 32767, int16).  wav float32 [B, n_samples, M] (device) -> int16 [B, S, n_samples] (device): HIP STFT front-end,
-        the fused pipeline, ONE batched ``torch.istft`` over the B * S enhanced spectrograms and the truncating cast --
+        the fused pipeline, ONE ``istft_k`` launch over the B * S enhanced spectrograms incl. the truncating cast --
         nothing leaves the device and nothing synchronises (with ``check_nan=False``)."""
         return S.istft_int16(self.enhance_wav(wav, clean_wav, check_nan=check_nan))
 
