@@ -87,6 +87,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build the HIP extension first (make -C misonet_amd/csrc). "
                               "misonet_amd has no CPU fallback.")
+        # torch first: it ships its own libamdhip64; loading this library BEFORE torch makes the process hold two HIP runtimes
+        # (ours resolved against /opt/rocm), and the second one to initialise sees "no ROCm-capable device" (found by running
+        # __graft_entry__.build() and smoke() in one process)
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if the .so does not export a declared symbol

@@ -219,3 +219,15 @@ def test_tensor_registry_norm_type_variants(nt, kind, extra):
     assert W.norm_kind(nt) == kind and W.norm_kind("IN") == 0 and W.norm_kind("whatever") == 3
     lib.misonet_net_destroy(h)
     assert _make(tcn_norm=4)[1] == L.EINVAL and _make(tcn_norm=-1)[1] == L.EINVAL
+
+
+def test_library_load_pulls_torch_in_first():
+    """Loading libmisonet_hip.so before torch leaves the process with two HIP runtimes (torch ships its own libamdhip64) and the
+    second one to initialise reports "no ROCm-capable device" -- seen when __graft_entry__.build() and smoke() ran in one
+    process.  _lib.lib() therefore imports torch first; checked in a fresh interpreter."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from misonet_amd import _lib; assert 'torch' not in sys.modules; "
+            "_lib.lib(); assert 'torch' in sys.modules; print('ok')" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-500:]
