@@ -150,3 +150,30 @@ def test_tester_beamforming_class_drop_in(sd1, sd3, tmp_path, mode):
         tst._enh.enhance(obs_d["0"].cuda())
     with pytest.raises(TypeError):
         Tester_Beamforming("SMS_WSJ", [], [], [], object(), 6, 0, 2, 4.0, str(tmp_path), 0, True, False, True, **args)
+
+
+@pytest.mark.parametrize("N,T", [(1, 2), (2, 5), (3, 64), (2, 200), (2, 501)])
+def test_hip_istft_vs_scipy(N, T):
+    """misonet_istft (csrc/stft.hip istft_k) against the reference's own synthesis, scipy.signal.istft(hann, 256, 192) of
+    ``spec * scale`` in float64 (tester.py:949-952, 979-990): float32 output to 2e-6 of full scale, int16 within 1 LSB (the
+    truncating cast flips where the float64 value sits within round-off of an integer), shortest input T = 2 included."""
+    import scipy.signal
+    from misonet_amd import stft as S
+    from test_gpu_parity import _need_gpu
+    _need_gpu()
+    r = np.random.default_rng(N * 1000 + T)
+    z = (r.standard_normal((N, T, 129)) + 1j * r.standard_normal((N, T, 129))).astype(np.complex64) * 30
+    want = np.stack([scipy.signal.istft(z[i].T.astype(np.complex128) / 128.0, fs=16000, window="hann", nperseg=256,
+                                        noverlap=192)[1][: (T - 1) * 64] for i in range(N)])
+    zd = torch.from_numpy(z).cuda()
+    y = S.istft(zd)
+    assert y.is_cuda and y.dtype == torch.float32 and tuple(y.shape) == (N, (T - 1) * 64)
+    e = np.abs(y.cpu().numpy() - want).max() / np.abs(want).max()
+    assert e <= 2e-6, e
+    q = S.istft_int16(zd / 300).cpu().numpy().astype(np.int32)
+    ref = (want / 300 * 32767).astype(np.int16).astype(np.int32)
+    assert q.shape == ref.shape and np.abs(q - ref).max() <= 1 and np.mean(q != ref) < 1e-3
+    # leading dimensions are kept, and the CPU path (torch.istft) agrees
+    y4 = S.istft(zd.reshape(1, N, T, 129))
+    assert tuple(y4.shape) == (1, N, (T - 1) * 64) and torch.equal(y4[0], y)
+    assert np.abs(S.istft(torch.from_numpy(z)).numpy() - want).max() / np.abs(want).max() <= 2e-6
