@@ -625,6 +625,29 @@ def main():
                 del gr
             except Exception as e:                                      # a graph is an optimisation, never a requirement
                 b1["hip_graph_error"] = str(e)[:200]
+            # a RECORDING at the reference harness' operating point (B = 1 loader): 10 s = three 4 s splits
+            # (dataloader/data.py:558-595).  The reference runs them one pass per split (tester.py:860); Enhancer.inference
+            # runs the splits of a loader item as one batch (bit-identical by batch invariance).
+            try:
+                o3 = torch.empty((3, N_SPK, T, 129), dtype=torch.complex64, device=dev)
+                def rec_batched():
+                    enh.enhance(mix[:3], clean[:3], check_nan=False, out=o3)
+                def rec_serial():
+                    for k in range(3):
+                        enh.enhance(mix[k:k + 1], clean[k:k + 1], check_nan=False, out=o1)
+                res = {}
+                for name, fn in (("split_by_split", rec_serial), ("splits_as_one_batch", rec_batched)):
+                    for _ in range(2):
+                        fn()
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(8):
+                        fn()
+                    torch.cuda.synchronize()
+                    res[name] = round((time.perf_counter() - t1) / 8 * 1e3, 3)
+                b1["recording_3_splits_ms"] = res
+            except Exception as e:
+                b1["recording_3_splits_error"] = str(e)[:200]
             enh.enhance(mix, clean, check_nan=False, out=out)            # restore the batch workspace / result
             torch.cuda.synchronize()
         wavp, wav_pcm = None, None
