@@ -39,14 +39,14 @@ def test_bench_mode_floors():
     """Per-mode floor on the measured roofline fraction of the conv kernels (the bench's own instrumented pass): round 3
     shipped an f32 mode that had silently lost 36 % (88 -> 56 utt/s, frac 0.68 -> 0.43) to register spills.  Boxes differ
     by a few per cent in sustained clocks (round 4: bf16x6 0.429 ... 0.450 on seven boxes, f32 0.675 ... 0.684); the floors sit
-    just under the slowest box seen -- a spilled kernel loses 30 %, not 3 %."""
+    5 % under the slowest box seen (a false alarm on a slow box costs more than a missed 5 %) -- a spilled kernel loses 30 %."""
     r = subprocess.run([sys.executable, "bench.py", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--alt", "f32",
                         "--no-pmc"],
                        cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
-    assert d["dtype"] == "bf16x6" and d["roofline"]["frac"] >= 0.415, d["roofline"]
-    assert d["value"] >= 135.0, d["value"]
+    assert d["dtype"] == "bf16x6" and d["roofline"]["frac"] >= 0.405, d["roofline"]
+    assert d["value"] >= 133.0, d["value"]
     f32 = [a for a in d["alt_precision"] if a["dtype"] == "f32"]
     assert f32 and f32[0]["roofline"]["frac"] >= 0.62, f32
     assert f32[0]["value"] >= 80.0, f32[0]["value"]
