@@ -31,6 +31,7 @@ struct ConvArgs {
   const float* w;           // packed [ncg][nchunk][9][CK][COP]
   const float* bias;        // [ncg*COP]
   const unsigned short* w16; // bf16x3 path: packed [ncg][nchunk16][hi|lo][9][2][COP][8] bf16, or nullptr
+  const float* ww;          // f32w path (conv_wino.hip): Winograd-domain weights U = G g G^T, [cg32][chunk of 8][pos / 4][ci][32 co][pos % 4], or nullptr
   long long in_bstride;     // floats per sample of the input buffer
   long long out_bstride;
   int in_sstride, out_sstride;   // channels per sample in the stats arrays (= channels of the whole buffer)
@@ -100,6 +101,10 @@ int conv_cop(int Cout);                      // 32 (Cout <= 32) or 64
 int conv_rows(int sf, int tr2);              // NR for the mode
 hipError_t launch_conv(const ConvArgs& a, int n_samples, hipStream_t s);
 hipError_t conv_init();                      // dynamic-LDS attributes
+// Winograd F(2x2, 3x3) on the fp32 matrix cores for the stride-1 same-padded layers (conv_wino.hip; precision mode "f32w")
+bool conv_wino_ok(const ConvArgs& a);
+hipError_t launch_conv_wino(const ConvArgs& a, int n_samples, hipStream_t s);
+hipError_t conv_wino_init();
 hipError_t launch_conv_bf16(const ConvArgs& a, int n_samples, hipStream_t s);   // conv_bf16.hip (needs a.w16)
 hipError_t conv_bf16_init();
 hipError_t launch_conv_bf16_dma(const ConvArgs& a, int n_samples, hipStream_t s);   // conv_bf16_dma.hip (oct input)

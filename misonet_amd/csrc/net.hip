@@ -110,6 +110,7 @@ struct ConvL {
   long long wf_off = 0;             // offset (floats) of the float32 weights in bf16-image order (conv_wprep_k source)
   long long wf6_off = 0;            // offset (floats) of the float32 weights [cg][chunk of 8][tap][32][8] (conv_wprep6_k source)
   long long w6s_off = -1;           // first layer only: offset (floats) of the SHARED 3-part bf16 image [chunk][864 units]
+  long long ww_off = -1;            // stride-1 same-padded layers: offset (floats) of the Winograd-domain weights (conv_wino.hip)
   float wscale = 1.f;               // f16x3: power of two that brings max |W| of the layer to [32, 64)
 };
 
@@ -153,8 +154,11 @@ struct misonet_net {
   bool committed = false;
   bool keep_taps = false;        // true: no buffer shares memory with another (every tap stays readable after a forward)
   int precision = 3;             // 0: exact f32 MFMA, 1: bf16x3 planar, 2: bf16x3 DMA dataflow, 3: bf16x6 DMA dataflow (the
-                                 // default: fp32-faithful, what bench.py reports), 4: f16x3 DMA dataflow
+                                 // default: fp32-faithful, what bench.py reports), 4: f16x3 DMA dataflow, 5: f32 MFMA with the
+                                 // dense-block convs in Winograd F(2x2, 3x3) form ("f32w": planar float32 layout like mode 0)
 };
+// the planar-float32 modes: every activation buffer is float32 [c][f][Tp], instance norm applied while staging
+static inline bool planar_f32(const misonet_net* n) { return n->precision == 0 || n->precision == 5; }
 
 static int find_tensor(const misonet_net* n, const std::string& name) {
   for (size_t i = 0; i < n->tensors.size(); ++i)
@@ -330,7 +334,7 @@ static long long align_up(long long x, long long a) { return (x + a - 1) / a * a
 // and the TCN stay planar float32, and so do the F <= 3 bottleneck buffers except in bf16x6.  Returns the ConvArgs::in_oct /
 // out_oct code.
 static inline int buf_oct(const misonet_net* n, int b) {
-  if (n->precision < 2) return 0;
+  if (n->precision < 2 || n->precision == 5) return 0;
   const bool o = (b >= B_E0 && b <= B_E4) || (b >= B_D2 && b <= B_D6) || (b >= B_X2 && b <= B_X6);
   // bf16x6 also keeps the F <= 3 bottleneck buffers D0 / D1 in its layout (the TCN reads / writes it at its two ends), so
   // that encoder 6 and decoders 0-1 run on the persistent kernel instead of the one-row-per-wave f32 kernel
@@ -456,7 +460,8 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
   a.out_stats = stats_ptr(L, ws, c.out_buf);
   a.w = n->w_dev + c.w_off;
   a.bias = n->w_dev + c.b_off;
-  a.w16 = n->precision >= 1 ? reinterpret_cast<const unsigned short*>(n->w_dev + c.w16_off) : nullptr;
+  a.w16 = !planar_f32(n) ? reinterpret_cast<const unsigned short*>(n->w_dev + c.w16_off) : nullptr;
+  a.ww = (n->precision == 5 && c.ww_off >= 0) ? n->w_dev + c.ww_off : nullptr;
   a.in_bstride = bstride(n, L, c.in_buf);
   a.out_bstride = bstride(n, L, c.out_buf);
   a.in_sstride = n->bufs[c.in_buf].C;
@@ -532,6 +537,7 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
   {
     ProfScope ps(s, PK_CONV);
     if (a.w16) HIPCHK(launch_conv_bf16(a, nb, s));
+    else if (a.ww && conv_wino_ok(a)) HIPCHK(launch_conv_wino(a, nb, s));
     else HIPCHK(launch_conv(a, nb, s));
   }
   return MISONET_OK;
@@ -807,6 +813,32 @@ static void pack_conv_w6s(const misonet_net* n, const ConvL& c, std::vector<floa
           }
 }
 
+// f32w path: Winograd-domain weights U = G g G^T of a stride-1 same-padded conv (conv_wino.hip), G = [1 0 0; .5 .5 .5; .5 -.5 .5;
+// 0 0 1]; position pos = xi * 4 + nu with xi along frequency (kf) and nu along time (kt).  Image order: [cg of 32 co][chunk of
+// 8 ci][pos / 4][ci][co][pos % 4], zero padded past Cout.  Computed in double, rounded once.
+static void pack_conv_wino(const misonet_net* n, const ConvL& c, std::vector<float>& arena) {
+  if (c.ww_off < 0) return;
+  const std::vector<float>& W = n->tensors[c.wt].host;
+  static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+  const int nchunk = c.Cin / 8, ncg = (c.Cout + 31) / 32;
+  float* img = arena.data() + c.ww_off;
+  for (int cg = 0; cg < ncg; ++cg)
+    for (int kc = 0; kc < nchunk; ++kc)
+      for (int cil = 0; cil < 8; ++cil)
+        for (int col = 0; col < 32; ++col) {
+          const int ci = kc * 8 + cil, co = cg * 32 + col;
+          for (int pos = 0; pos < 16; ++pos) {
+            const int xi = pos >> 2, nu = pos & 3;
+            double u = 0.0;
+            if (co < c.Cout)
+              for (int kt = 0; kt < 3; ++kt)
+                for (int kf = 0; kf < 3; ++kf)
+                  u += G[xi][kf] * G[nu][kt] * (double)W[(((long long)co * c.Cin + ci) * 3 + kt) * 3 + kf];
+            img[(((((long long)cg * nchunk + kc) * 4 + (pos >> 2)) * 8 + cil) * 32 + col) * 4 + (pos & 3)] = (float)u;
+          }
+        }
+}
+
 int misonet_net_commit(misonet_net* n) {
   if (!n) return fail(MISONET_EINVAL, "null argument");
   for (const Tensor& t : n->tensors)
@@ -824,6 +856,9 @@ int misonet_net_commit(misonet_net* n) {
       // the first layer (planar network input, consumed un-normalised, <= 16 in / <= 32 out channels): shared 3-part image
       if (c.in_buf == B_IN && !c.transposed && c.sf == 1 && c.Cin <= 16 && c.Cout <= 32 && c.ident_c >= c.Cin)
         c.w6s_off = take((long long)((c.Cin + 7) / 8) * 864 * 4);          // 864 units x 16 bytes = x 4 floats
+      // the DenseBlock convs (stride 1, same padding, Cin a multiple of 8): Winograd-domain image for the f32w mode
+      if (!c.transposed && c.sf == 1 && c.padf == 1 && c.Cin % 8 == 0 && c.Cin <= 256)
+        c.ww_off = take((long long)((c.Cout + 31) / 32) * (c.Cin / 8) * 16 * 8 * 32);
     }
   };
   place(n->enc);
@@ -839,8 +874,8 @@ int misonet_net_commit(misonet_net* n) {
       tb.h[h].o_nsh = take(128);
     }
   std::vector<float> arena((size_t)off, 0.f);
-  for (ConvL& c : n->enc) { pack_conv(n, c, arena); pack_conv_bf16(n, c, arena); pack_conv_wf6(n, c, arena); pack_conv_w6s(n, c, arena); }
-  for (ConvL& c : n->dec) { pack_conv(n, c, arena); pack_conv_bf16(n, c, arena); pack_conv_wf6(n, c, arena); }
+  for (ConvL& c : n->enc) { pack_conv(n, c, arena); pack_conv_bf16(n, c, arena); pack_conv_wf6(n, c, arena); pack_conv_w6s(n, c, arena); pack_conv_wino(n, c, arena); }
+  for (ConvL& c : n->dec) { pack_conv(n, c, arena); pack_conv_bf16(n, c, arena); pack_conv_wf6(n, c, arena); pack_conv_wino(n, c, arena); }
   for (const TcnBlock& tb : n->tcn)
     for (int h = 0; h < 2; ++h) {
       const TcnHalf& H = tb.h[h];
@@ -868,6 +903,7 @@ int misonet_net_commit(misonet_net* n) {
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&n->w_dev), arena.size() * sizeof(float)));
   HIPCHK(hipMemcpy(n->w_dev, arena.data(), arena.size() * sizeof(float), hipMemcpyHostToDevice));
   HIPCHK(conv_init());
+  HIPCHK(conv_wino_init());
   HIPCHK(conv_bf16_init());
   HIPCHK(conv_bf16_dma_init());
   HIPCHK(conv_bf16x6_init());
@@ -877,8 +913,9 @@ int misonet_net_commit(misonet_net* n) {
 
 int misonet_net_set_precision(misonet_net* n, int mode) {
   if (!n) return fail(MISONET_EINVAL, "null argument");
-  if (mode < 0 || mode > 4)
-    return fail(MISONET_EINVAL, "precision mode must be 0 (f32), 1 (bf16x3, planar), 2 (bf16x3, DMA dataflow), 3 (bf16x6) or 4 (f16x3)");
+  if (mode < 0 || mode > 5)
+    return fail(MISONET_EINVAL, "precision mode must be 0 (f32), 1 (bf16x3, planar), 2 (bf16x3, DMA dataflow), 3 (bf16x6), 4 (f16x3) or "
+                                "5 (f32w: f32 with Winograd dense-block convs)");
   n->precision = mode;
   return MISONET_OK;
 }

@@ -95,12 +95,14 @@ class _Trunk:
         self.training = False
         return self
 
-    PRECISIONS = {"f32": 0, "bf16x3p": 1, "bf16x3": 2, "bf16x6": 3, "f16x3": 4}
+    PRECISIONS = {"f32": 0, "bf16x3p": 1, "bf16x3": 2, "bf16x6": 3, "f16x3": 4, "f32w": 5}
 
     def set_precision(self, mode: str):
         """Arithmetic of the 3x3 convolutions: "bf16x6" (the default; fp32-faithful: both operands split EXACTLY into
         three bf16 pieces, the six leading partial products on the bf16 matrix cores with f32 accumulation -- same
-        accuracy class as "f32" at 2.67x its matrix rate, conv_bf16x6.hip), "f32" (exact float32 matrix cores), "f16x3"
+        accuracy class as "f32" at 2.67x its matrix rate, conv_bf16x6.hip), "f32" (exact float32 matrix cores), "f32w" (float32
+        matrix cores with the DenseBlock convs -- 94 % of the MACs -- in Winograd F(2x2, 3x3) form: 2.25x fewer matrix
+        instructions, float32 products and sums throughout, conv_wino.hip), "f16x3"
         (operands rounded to two fp16 pieces = 22 bits, three terms, f32 accumulation: the "3xTF32" scheme; measured at the
         f32 mode's error level, at the cost of "bf16x3"; activations must stay inside fp16's range), "bf16x3" (three-term bf16
         split on the bf16 matrix cores, f32 accumulation, ~1e-5 relative per layer; activations travel pre-split in the
