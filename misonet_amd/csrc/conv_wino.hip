@@ -18,18 +18,26 @@
 //   rows = 8 output rows x 64 frames x 32 output channels.
 //
 // PERSISTENT: one workgroup per CU walks a contiguous range of its XCD's (sample, tile) list; the K-chunks (8 input
-// channels) of all its tiles form ONE stream through THREE LDS stages: while chunk g runs on the matrix pipe, chunk g + 1
-// (in registers since the previous chunk) is normalised and written to its stage -- instance norm applied on the way into
-// the LDS, zero padding applied after it, the reference's order -- and the global loads of chunk g + 2 are issued, also
-// across a tile boundary, so a new tile starts with its operands in registers.  One workgroup barrier per chunk, after
-// three of its four K-steps.
-// The instruction stream is laid out by hand: a K-step is 16 SLOTS of one MFMA (64 matrix cycles) + a piece of side work
-// (operand fetch of the next step, its input transform, one staging item), fenced by sched_barriers; the matrix pipe never
-// waits for an LDS round trip or a global load.
+// channels) of all its tiles form ONE stream, also across tile boundaries.  While chunk g runs on the matrix pipe from its
+// stage, chunk g + 1 is normalised from the RAW RING into its stage -- instance norm applied on the way, zero padding after
+// it, the reference's order -- the U image of chunk g + 2 and the raw input of chunk g + 3 travel global -> LDS by DMA
+// (`buffer_load ... lds`: no registers hold data in flight; with the input only ONE chunk ahead, in registers, 22 % of the
+// kernel was s_waitcnt on HBM latency).  A wave stages exactly the raw words its own lanes' DMA wrote, so the raw ring needs
+// no barrier, only the wave's own vmcnt.  Three stages, one workgroup barrier per chunk, inside the fourth K-step.
+// The instruction stream is laid out by hand.  Measured on gfx950 (tools/micro/mfma_f32_valu.hip): VALU work does NOT hide
+// behind v_mfma_f32_32x32x2_f32 -- the f32 MFMA runs at the f32 vector rate and a VALU instruction between two of them costs
+// its full ~4.5 cycles plus ~12 for the first one (64 -> 105 cycles per MFMA with 8 v_add behind each), while LDS, VMEM and
+// SALU instructions are free.  So a K-step is 16 MFMAs with only LDS reads / writes and global loads between them, followed by
+// ONE clustered VALU group: the input transform of the next step as 16 packed adds (op_sel / neg modifiers; position nu = 2
+// comes out negated, the weight image carries the same sign) and the instance norm of two staging items as packed FMAs.
+// Everything else that would be VALU is gone: LDS addresses are per-stage base registers + immediates (the chunk loop is
+// unrolled over the three stages), the chunk offset of a global load is an SGPR, rows outside the image read a (0, 0) norm
+// entry instead of being masked, the weights go global -> LDS by DMA, frame masks exist only in the two ragged column tiles.
 // Epilogue: inverse transform per lane (the 16 positions of a (channel, tile) are 16 accumulator registers of ONE lane),
 // + bias, ELU, centring, 8-byte stores along T, exact statistics (det_stats.hpp) as in conv_epilogue.hpp.
 #include "kernels.hpp"
 #include "conv_epilogue.hpp"
+#include <stdio.h>
 #include <stdlib.h>
 #include <utility>
 
@@ -39,19 +47,18 @@ typedef float wf16 __attribute__((ext_vector_type(16)));
 typedef float wf4 __attribute__((ext_vector_type(4)));
 typedef float wf2 __attribute__((ext_vector_type(2)));
 typedef unsigned int wu2 __attribute__((ext_vector_type(2)));
+#define MN_WLDS(p) ((__attribute__((address_space(3))) void*)(p))
 
 constexpr int WCK = 8;                         // input channels per chunk
 constexpr int WTT = 64;                        // output frames per workgroup (32 tiles)
 constexpr int WFT = 8;                         // output rows per workgroup (4 waves x 2)
 constexpr int WNR = 10;                        // staged input rows
-constexpr int WTW = 68;                        // floats per staged row: column c = frame t0 - 1 + c (66 used)
-constexpr int WIN_FLOATS = WCK * WNR * WTW;    // 5440
+constexpr int WTW = 66;                        // floats per staged row: column c = frame t0 - 1 + c
+constexpr int WIN_FLOATS = WCK * WNR * WTW;    // 5280
 constexpr int WW_FLOATS = 16 * WCK * 32;       // 4096: [pos / 4][ci][co][pos % 4]
 constexpr int WSTAGE_FLOATS = WIN_FLOATS + WW_FLOATS;
 constexpr int WNSTAGE = 3;
 constexpr int WNRM_MAX = 256;                  // input channels (s_nrm entries per parity)
-// stages | s_nrm[2][WNRM_MAX] float2 | s_red [4][32][2] | s_dummy [256]
-constexpr size_t WINO_LDS = (size_t)(WNSTAGE * WSTAGE_FLOATS) * 4 + 2 * WNRM_MAX * 8 + 4 * 64 * 4 + 256 * 4;
 
 // ---- the 256 accumulator registers are FIXED physical AGPRs a0..a255 (position p = a[16 p : 16 p + 15]), touched only by
 // inline asm.  With the MFMA builtin (or asm with "+a" operands) hipcc 7.2's allocator treats accumulators and operands as
@@ -104,15 +111,50 @@ template <int N, class F>
 __device__ __forceinline__ void wfor(F&& f) {
   wfor_impl(f, std::make_integer_sequence<int, N>{});
 }
+// packed f32 forms (semantics checked on the GPU by tools/micro/pk_opsel.hip)
+__device__ __forceinline__ wf2 pk_add(wf2 a, wf2 b) { wf2 d; asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ wf2 pk_sub(wf2 a, wf2 b) { wf2 d; asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+// (a0 - b0, a1 + b0)
+__device__ __forceinline__ wf2 pk_t01(wf2 a, wf2 b) { wf2 d; asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+// (a1 - b0, a1 - b1)
+__device__ __forceinline__ wf2 pk_t23(wf2 a, wf2 b) { wf2 d; asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+// (x0 * n0 + n1, x1 * n0 + n1)
+__device__ __forceinline__ wf2 pk_nrm(wf2 x, wf2 nr) { wf2 d; asm volatile("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(x), "v"(nr)); return d; }
+__device__ __forceinline__ unsigned launder(unsigned x) { asm volatile("" : "+v"(x)); return x; }
+// s_waitcnt vmcnt(n) with a RUN-TIME n: the wave's outstanding-VMEM count is readable (IB_STS.VM_CNT [3:0] + VM_CNT_HI [23:22];
+// checked on gfx950 by tools/micro/ibsts_vmcnt.hip).  SALU only, so it costs nothing beside the matrix pipe; the spin is bounded
+// (then the plain full wait), a wrong reading can never hang the GPU.
+__device__ __forceinline__ void wait_vm_le(int n) {
+  int spins = 0;
+  for (;;) {
+    const int lo = __builtin_amdgcn_s_getreg(7 | (0 << 6) | (3 << 11));
+    const int hi = __builtin_amdgcn_s_getreg(7 | (22 << 6) | (1 << 11));
+    if ((lo | (hi << 4)) <= n) return;
+    if (++spins > (1 << 20)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+  }
+}
+
+// LDS map: 3 stages {normalised input [8][10][WTW] | U image 16 KB} | raw ring: 2 slots {80 items x 64 frames as the DMA leaves
+// them | 256 halo words} | s_nrm[2][WNRM_MAX] float2 | s_zero[WNRM_MAX] float2 | s_red [4][32][2] | 64 dummy words | bias [64]
+constexpr int WRAW_FLOATS = WCK * WNR * WTT + 256;
+constexpr unsigned WRAW_B = (unsigned)(WNSTAGE * WSTAGE_FLOATS) * 4u;
+constexpr unsigned WNRM_B = WRAW_B + 2u * WRAW_FLOATS * 4u;
+constexpr unsigned WZERO_B = WNRM_B + 2u * WNRM_MAX * 8u;
+constexpr unsigned WRED_B = WZERO_B + WNRM_MAX * 8u;
+constexpr unsigned WDUMMY_B = WRED_B + 4u * 64u * 4u;
+constexpr unsigned WBIAS_B = WDUMMY_B + 64u * 4u;       // the layer's bias (<= 64 channels): the epilogue must not queue VMEM loads behind the DMA
+constexpr size_t WINO_LDS = WBIAS_B + 64 * 4;
+static_assert(WINO_LDS <= 160 * 1024, "one workgroup per CU: at most 160 KB of LDS");
 
 // DBG (timing experiments only, -DMISONET_EXPERIMENTS + MISONET_WINO_DBG): 1 = no staging side work in the chunk loop (wrong
-// results), 2 = no epilogue arithmetic / stores.
+// results), 2 = no epilogue arithmetic / stores, 4 = no input transform, 8 / 16 / 32 = no weight DMA / input DMA / staging
+// arithmetic + LDS traffic (the three parts of 1), 64 / 128 / 256 = no epilogue stores / statistics / ELU.
 template <int DBG>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
   extern __shared__ __align__(16) float smem[];
-  float2* s_nrm = reinterpret_cast<float2*>(smem + WNSTAGE * WSTAGE_FLOATS);
-  float* s_red = reinterpret_cast<float*>(s_nrm + 2 * WNRM_MAX);   // [4 waves][32][2]
-  float* s_dummy = s_red + 4 * 64;
+  char* const smem_c = reinterpret_cast<char*>(smem);
+  wf2* s_nrm = reinterpret_cast<wf2*>(smem_c + WNRM_B);
+  wf2* s_zero = reinterpret_cast<wf2*>(smem_c + WZERO_B);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -138,37 +180,72 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
     q1 = q0 + per < Q ? q0 + per : Q;
   }
   if (q0 >= q1) return;
+  for (int i = tid; i < WNRM_MAX; i += 256) s_zero[i] = wf2{0.f, 0.f};
+  float* s_bias = reinterpret_cast<float*>(smem_c + WBIAS_B);
+  if (tid < 64) s_bias[tid] = tid < a.ncg * 32 ? a.bias[tid] : 0.f;
 
   const unsigned row_e = (unsigned)Tp;
   const unsigned plane_b = (unsigned)F * row_e * 4u;
 
-  // ---- staging roles: thread (sq, scr) owns frames t0 + 4 sq .. + 3 of the (channel, row) items scr + 16 i, i = 0..4 ----
+  // ---- staging roles: thread (sq, scr) owns frames t0 + 4 sq .. + 3 (stage columns 1 + 4 sq .. 4 + 4 sq) of the (channel,
+  // row) items scr + 16 i, i = 0..4; threads 0..159 own the halo columns 0 / 65 (frames t0 - 1 / t0 + 64) of item tid >> 1 ----
   const int sq = tid & 15, scr = tid >> 4;
-  int sch[5];                                  // channel of item i; its LDS offset is loff0 + i * 16 * WTW (item p = row p of [80][WTW])
+  int sch[5];                                  // channel of item i; its stage row is scr + 16 i of [80][WTW]
 #pragma unroll
   for (int i = 0; i < 5; ++i) sch[i] = (scr + 16 * i) / WNR;
-  const int loff0 = scr * WTW + 1 + 4 * sq;
-  // halo columns: frame t0 - 1 (column 0) and t0 + 64 (column 65) of the 80 (channel, row) items
-  const int hp = tid >> 1, hside = tid & 1;
-  const bool hrole = hp < WCK * WNR;
-  const int hch = hrole ? hp / WNR : 0, hrow = hrole ? hp - hch * WNR : 0;
-  const int hloff = (hch * WNR + hrow) * WTW + (hside ? WTT + 1 : 0);
-  // operand fetch of K-step S (channels 2 S + half of the chunk)
-  const int d_off = (half * WNR + 2 * wave) * WTW + 2 * l31;     // + S * 2 * WNR * WTW
-  const int u_off = half * 32 + l31;                             // wf4 units; + S * 64, + q * 256
+  const bool hrole = tid < 2 * WCK * WNR;
+  const int hit = hrole ? tid >> 1 : 0, hside = tid & 1;
+  const int hch = hit / WNR, hrow = hit - hch * WNR;
+  // per-stage LDS addresses (absolute; laundered through an empty asm: the compiler must keep them in registers instead of
+  // re-deriving them from one base with VALU adds; every access is then base register + immediate.  The patch rows of a
+  // K-step are read with ds_read2_b64, whose offsets reach 2 KB, so every (stage, step) has its own base)
+  const unsigned lds0 = (unsigned)(unsigned long long)MN_WLDS(smem);
+  unsigned dofs[3][4];                         // patch fetch of step S: + (i * WTW (+ 2)) * 4
+  unsigned uofs[3];                            // U fetch: + (S * 64 + q * 256) * 16
+  unsigned cofs[3];                            // staging write of item i: + i * 16 * WTW * 4 (+ 0, 4, 8, 12)
+  unsigned hofs[3];                            // halo word write
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      dofs[s][k] = launder(lds0 + (unsigned)(s * WSTAGE_FLOATS + k * (2 * WNR * WTW) + (half * WNR + 2 * wave) * WTW + 2 * l31) * 4u);
+    uofs[s] = launder(lds0 + (unsigned)(s * WSTAGE_FLOATS + WIN_FLOATS) * 4u + (unsigned)(half * 32 + l31) * 16u);
+    cofs[s] = launder(lds0 + (unsigned)(s * WSTAGE_FLOATS + scr * WTW + 1 + 4 * sq) * 4u);
+    hofs[s] = launder(lds0 + (hrole ? (unsigned)(s * WSTAGE_FLOATS + hit * WTW + (hside ? WTT + 1 : 0)) * 4u : WDUMMY_B + (unsigned)(tid & 63) * 4u));
+  }
+#define W_LP(TYPE, ADDR) (reinterpret_cast<__attribute__((address_space(3))) TYPE*>(ADDR))
+  // raw ring: what THIS thread's DMA lanes wrote (slot 0; slot 1 is WRAW_FLOATS * 4 further): item i at + i * 4096
+  const unsigned rofs0 = lds0 + WRAW_B + (unsigned)(scr * WTT + 4 * sq) * 4u;
+  const unsigned rhofs0 = lds0 + WRAW_B + (unsigned)(WCK * WNR * WTT + tid) * 4u;
+  // DMA destinations are wave-uniform LDS addresses (the hardware adds lane * size)
+  const unsigned rdma0 = WRAW_B + (unsigned)wave * 1024u;                              // + slot * WRAW_FLOATS * 4 + i * 4096
+  const unsigned rhdma0 = WRAW_B + (unsigned)(WCK * WNR * WTT) * 4u + (unsigned)wave * 256u;
+  const unsigned wdma0 = (unsigned)(WIN_FLOATS * 4) + (unsigned)wave * 1024u;          // + stage * WSTAGE_FLOATS * 4 + j * 4096
+  const __amdgpu_buffer_rsrc_t rs_w = make_rsrc_e(reinterpret_cast<unsigned long long>(a.ww),
+                                                   (unsigned)(a.ncg * nchunk) * (unsigned)(WW_FLOATS * 4));
+  unsigned wvo[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wvo[j] = (unsigned)(tid + 256 * j) * 16u;
 
-  // ---- load-side state: the tile and chunk of the NEXT chunk to issue ----
+  // ---- load-side state L: the tile and chunk of the NEXT raw-input DMA (three chunks ahead of the matrix pipe).  What the
+  // later steps need of a chunk's tile is latched when the chunk is issued and handed down L -> D -> C.  D: the chunk whose
+  // U image is DMA'd in this iteration (g + 2); C: the chunk staged in this iteration (g + 1) ----
   unsigned ql = q0;
   int kl = 0;
-  int Ln = -1, Lpar = 1;                       // sample and s_nrm parity of the load tile
-  unsigned Lgoff[5], Lhoff = 0, Lrokm = 0;     // Lrokm: bit i = row of item i inside the image, bit 5 = halo element exists
-  bool Ltm0 = false, Ltm1 = false, Ltm2 = false, Ltm3 = false;     // frame tg + j < T
+  int Ln = -1, Lpar = 1, Lcg = 0;              // sample, s_nrm parity and channel group of the load tile
+  int lslot = 0;                               // raw slot of the chunk L points at
+  unsigned Lgoff[5], Lhoff = 0;
+  unsigned Lnr[6];                             // LDS address of the norm entry of item i / the halo item at chunk 0: in s_nrm, or s_zero when the row (halo: the element) is outside the image
+  bool Lfull = false;                          // every frame t0 .. t0 + 63 of the tile exists (no frame masks)
+  unsigned Lmask = 0;                          // bits 0-3: frame t0 + 4 sq + j exists
   __amdgpu_buffer_rsrc_t rs_l;
-  const wf4* w_l = nullptr;
-  // commit-side copies (the chunk committed in iteration g + 1 was issued in iteration g)
-  unsigned Crokm = 0;
-  bool Ctm0 = false, Ctm1 = false, Ctm2 = false, Ctm3 = false;
-  int Cnb = 0;
+  unsigned Cnr[6], Dnr[6];
+  bool Cfull = false, Dfull = false;
+  unsigned Cmask = 0, Dmask = 0;
+  unsigned Dwso = 0;                           // byte offset of D's chunk in the weight image
+  int cslot = 0;                               // raw slot of C's chunk
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { Lnr[i] = lds0 + WZERO_B; Cnr[i] = lds0 + WZERO_B; Dnr[i] = lds0 + WZERO_B; }
 
 #define W_DECODE(Q, TT_, FT_, N_, CG_)                                                                \
   {                                                                                                   \
@@ -201,177 +278,238 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
           mean = (float)m;                                                                            \
           rstd = (float)(1.0 / sqrt(var + (double)IN_EPS));                                           \
         }                                                                                             \
-        s_nrm[Lpar * WNRM_MAX + c] = make_float2(rstd, -mean * rstd);                                 \
+        s_nrm[Lpar * WNRM_MAX + c] = wf2{rstd, -mean * rstd};                                         \
       }                                                                                               \
       const float* in_n_ = a.in + (long long)n_ * a.in_bstride + (long long)a.in_c0 * F * Tp;         \
       rs_l = make_rsrc_e(reinterpret_cast<unsigned long long>(in_n_), (unsigned)Cin * plane_b);       \
     }                                                                                                 \
-    w_l = reinterpret_cast<const wf4*>(a.ww) + (long long)cg_ * nchunk * (WW_FLOATS / 4);             \
+    Lcg = cg_;                                                                                        \
     const int tg_ = t0_ + 4 * sq;                                                                     \
-    const unsigned tge_ = (unsigned)(tg_ + 4 <= Tp ? tg_ : Tp - 4);                                   \
-    Ltm0 = tg_ + 0 < T; Ltm1 = tg_ + 1 < T; Ltm2 = tg_ + 2 < T; Ltm3 = tg_ + 3 < T;                   \
-    Lrokm = 0;                                                                                        \
+    const int tge_ = tg_ + 4 <= Tp ? tg_ : Tp - 4;                                                    \
+    Lfull = t0_ + WTT <= T;                                                                           \
+    Lmask = (tg_ < T ? 1u : 0u) | (tg_ + 1 < T ? 2u : 0u) | (tg_ + 2 < T ? 4u : 0u) | (tg_ + 3 < T ? 8u : 0u); \
     _Pragma("unroll") for (int i = 0; i < 5; ++i) {                                                   \
       int fin = fin0_ + (scr + 16 * i) - sch[i] * WNR;                                                \
-      if (fin >= 0 && fin < F) Lrokm |= 1u << i;                                                      \
+      Lnr[i] = lds0 + ((fin >= 0 && fin < F) ? WNRM_B + (unsigned)(Lpar * WNRM_MAX + sch[i]) * 8u : WZERO_B); \
       fin = fin < 0 ? 0 : (fin >= F ? F - 1 : fin);                                                   \
-      Lgoff[i] = (unsigned)sch[i] * plane_b + ((unsigned)fin * row_e + tge_) * 4u;                    \
+      Lgoff[i] = (unsigned)sch[i] * plane_b + (unsigned)((fin * (int)row_e + tge_) * 4);              \
     }                                                                                                 \
     {                                                                                                 \
       const int htg_ = hside ? t0_ + WTT : t0_ - 1;                                                   \
       int fin = fin0_ + hrow;                                                                         \
-      if (hrole && fin >= 0 && fin < F && htg_ >= 0 && htg_ < T) Lrokm |= 1u << 5;                    \
+      const bool hok_ = hrole && fin >= 0 && fin < F && htg_ >= 0 && htg_ < T;                        \
+      Lnr[5] = lds0 + (hok_ ? WNRM_B + (unsigned)(Lpar * WNRM_MAX + hch) * 8u : WZERO_B);             \
       fin = fin < 0 ? 0 : (fin >= F ? F - 1 : fin);                                                   \
-      const int th_ = htg_ < 0 ? 0 : (htg_ >= Tp ? Tp - 1 : htg_);                                    \
-      Lhoff = (unsigned)hch * plane_b + ((unsigned)fin * row_e + (unsigned)th_) * 4u;                 \
+      const int th_ = (htg_ < 0 || htg_ >= T) ? 0 : htg_;   /* an element that does not exist: a word that does, times 0 (the padding may hold NaN) */ \
+      Lhoff = (unsigned)hch * plane_b + (unsigned)((fin * (int)row_e + th_) * 4);                     \
     }                                                                                                 \
   }
 
-  // what the commit of the chunk issued LAST needs (taken before the load position advances)
+  // hand the per-chunk state down (after the chunk L points at has been issued, before L advances)
 #define W_LATCH                                                                                       \
-  { Crokm = Lrokm; Ctm0 = Ltm0; Ctm1 = Ltm1; Ctm2 = Ltm2; Ctm3 = Ltm3; Cnb = Lpar * WNRM_MAX + kl * WCK; }
+  {                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 6; ++i) { Cnr[i] = Dnr[i]; Dnr[i] = Lnr[i] + (unsigned)(kl * WCK * 8); } \
+    Cfull = Dfull; Dfull = Lfull; Cmask = Dmask; Dmask = Lmask;                                       \
+    Dwso = (unsigned)(Lcg * nchunk + kl) * (unsigned)(WW_FLOATS * 4);                                 \
+  }
 #define W_ADVANCE                                                                                     \
   {                                                                                                   \
+    lslot ^= 1;                                                                                       \
     if (++kl == nchunk) {                                                                             \
       if (ql + 1 < q1) { kl = 0; ++ql; W_LOAD_SETUP(ql) }                                             \
       else kl = nchunk - 1;                    /* end of the stream: the last chunk again (never consumed) */ \
     }                                                                                                 \
   }
 
-  wf4 pin[5];
-  float ph = 0.f;
-  wf4 pw[4];
-  float2 nra, nrb;
-  wf4 cv;
+  wf4 rwa, rwb;                                // raw words of the two items being staged
+  float rh = 0.f;
+  wf2 nra, nrb;
+  wf2 cva[2], cvb[2];                          // two normalised items waiting for their LDS writes
+  float chv = 0.f;
+  unsigned rofs = rofs0, rhofs = rhofs0;       // raw-ring addresses of this thread in C's slot
 
 #define W_CB ((unsigned)kl * (unsigned)WCK * plane_b)
-#define W_ISSUE_I(I) pin[I] = __builtin_bit_cast(wf4, __builtin_amdgcn_raw_buffer_load_b128(rs_l, W_CB + Lgoff[I], 0, 0));
-#define W_ISSUE_H ph = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_l, W_CB + Lhoff, 0, 0));
-#define W_ISSUE_W(J) pw[J] = w_l[(unsigned)kl * (unsigned)(WW_FLOATS / 4) + tid + 256 * (J)];
-#define W_NR(DST, CH) DST = s_nrm[Cnb + (CH)];
-  // item I of the chunk in registers: normalise, zero what lies outside the image
-#define W_CC(I, NR)                                                                                   \
+#define W_ISSUE_I(I)                                                                                  \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_l, MN_WLDS(smem_c + rdma0 + lslot * (WRAW_FLOATS * 4) + (I) * 4096), 16, Lgoff[I], W_CB, 0, 0);
+#define W_ISSUE_H                                                                                     \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_l, MN_WLDS(smem_c + rhdma0 + lslot * (WRAW_FLOATS * 4)), 4, Lhoff, W_CB, 0, 0);
+#define W_ISSUE_W(J, ST, WSO)                                                                         \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, MN_WLDS(smem_c + (ST) * (WSTAGE_FLOATS * 4) + wdma0 + (J) * 4096), 16, wvo[J], WSO, 0, 0);
+#define W_WSO_L ((unsigned)(Lcg * nchunk + kl) * (unsigned)(WW_FLOATS * 4))
+#define W_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");
+#define W_NR(DST, I) DST = *W_LP(const wf2, Cnr[I]);
+#define W_RR(DST, I) DST = *W_LP(const wf4, rofs + (I) * 4096);
+#define W_RRH rh = *W_LP(const float, rhofs);
+  // item I: instance norm (a row outside the image reads scale = shift = 0); frames that do not exist occur only in the last
+  // column tile of an utterance
+#define W_CC(CV, RW, NR)                                                                              \
   {                                                                                                   \
-    const bool rok_ = (Crokm >> (I)) & 1u;                                                            \
-    const float sc_ = rok_ ? NR.x : 0.f, sh_ = rok_ ? NR.y : 0.f;                                     \
-    cv.x = Ctm0 ? fmaf(pin[I].x, sc_, sh_) : 0.f;                                                     \
-    cv.y = Ctm1 ? fmaf(pin[I].y, sc_, sh_) : 0.f;                                                     \
-    cv.z = Ctm2 ? fmaf(pin[I].z, sc_, sh_) : 0.f;                                                     \
-    cv.w = Ctm3 ? fmaf(pin[I].w, sc_, sh_) : 0.f;                                                     \
+    CV[0] = pk_nrm(wf2{RW.x, RW.y}, NR);                                                              \
+    CV[1] = pk_nrm(wf2{RW.z, RW.w}, NR);                                                              \
+    if (RAG) {                                                                                        \
+      CV[0].x = (Cmask & 1u) ? CV[0].x : 0.f; CV[0].y = (Cmask & 2u) ? CV[0].y : 0.f;                 \
+      CV[1].x = (Cmask & 4u) ? CV[1].x : 0.f; CV[1].y = (Cmask & 8u) ? CV[1].y : 0.f;                 \
+    }                                                                                                 \
   }
-#define W_CW(I, ST)                                                                                   \
+#define W_CCH(NR) chv = fmaf(rh, NR.x, NR.y);
+  // The stage writes are inline asm: for a C++ store to LDS the compiler waits for EVERY LDS-DMA in flight (s_waitcnt vmcnt(0):
+  // it cannot tell the raw ring and the U images from the staged rows), which would take the DMA's two-chunk run-ahead away.
+  // Nothing reads these words before the chunk barrier, in front of which the wave waits for lgkmcnt(0) by hand.
+#define W_DSW(ADDR, VAL, OFF) asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(ADDR), "v"(VAL), "n"(OFF) : "memory");
+#define W_CW(CV, I, ST)                                                                               \
   {                                                                                                   \
-    float* si_ = smem + (ST) * WSTAGE_FLOATS + loff0 + (I) * (16 * WTW);                              \
-    si_[0] = cv.x;                                                                                    \
-    *reinterpret_cast<wf2*>(si_ + 1) = wf2{cv.y, cv.z};                                               \
-    si_[3] = cv.w;                                                                                    \
+    W_DSW(cofs[ST], CV[0].x, (I) * (16 * WTW * 4))                                                    \
+    W_DSW(cofs[ST], CV[0].y, (I) * (16 * WTW * 4) + 4)                                                \
+    W_DSW(cofs[ST], CV[1].x, (I) * (16 * WTW * 4) + 8)                                                \
+    W_DSW(cofs[ST], CV[1].y, (I) * (16 * WTW * 4) + 12)                                               \
   }
-#define W_CH(ST, NR)                                                                                  \
-  {                                                                                                   \
-    const bool hok_ = (Crokm >> 5) & 1u;                                                              \
-    float* hp_ = hrole ? smem + (ST) * WSTAGE_FLOATS + hloff : s_dummy + tid;                         \
-    *hp_ = hok_ ? fmaf(ph, NR.x, NR.y) : 0.f;                                                         \
-  }
-#define W_CWW(J, ST) reinterpret_cast<wf4*>(smem + (ST) * WSTAGE_FLOATS + WIN_FLOATS)[tid + 256 * (J)] = pw[J];
+#define W_CWH(ST) W_DSW(hofs[ST], chv, 0)
+  // workgroup barrier without the compiler's fence (which is s_waitcnt vmcnt(0) while LDS-DMA is in flight): every LDS access
+  // of this wave has completed (lgkmcnt(0)); the DMA the OTHER waves must see is covered by the explicit vmcnt in front of it
+#define W_BARRIER { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
 
-  wf2 dd[4][2];
-  float tt[4][4];
+  wf2 dd[4][2];                                // raw patch of the next step: row i, columns (0, 1) / (2, 3)
   wf4 u[4];                                    // U operands: quad q = positions 4 q .. 4 q + 3; refilled quad by quad
-  float v[16];                                 // V operands of the running K-step; rewritten in its last two slots
-  float v15n;                                  // ... except v[15] (operand of the step's last MFMA): one slot later
+  wf2 vp[4][2];                                // V operands of the running K-step: position 4 x + nu = vp[x][nu >> 1][nu & 1] (nu = 2 negated)
 #define W_FD(I0, ST, S)                                                                               \
   {                                                                                                   \
-    const float* si_ = smem + (ST) * WSTAGE_FLOATS + d_off + (S) * (2 * WNR * WTW);                   \
-    dd[I0][0] = *reinterpret_cast<const wf2*>(si_ + (I0) * WTW);                                      \
-    dd[I0][1] = *reinterpret_cast<const wf2*>(si_ + (I0) * WTW + 2);                                  \
-    dd[I0 + 1][0] = *reinterpret_cast<const wf2*>(si_ + ((I0) + 1) * WTW);                            \
-    dd[I0 + 1][1] = *reinterpret_cast<const wf2*>(si_ + ((I0) + 1) * WTW + 2);                        \
+    const unsigned si_ = dofs[ST][S];                                                                 \
+    dd[I0][0] = *W_LP(const wf2, si_ + (I0) * (WTW * 4));                                             \
+    dd[I0][1] = *W_LP(const wf2, si_ + (I0) * (WTW * 4) + 8);                                         \
+    dd[I0 + 1][0] = *W_LP(const wf2, si_ + ((I0) + 1) * (WTW * 4));                                   \
+    dd[I0 + 1][1] = *W_LP(const wf2, si_ + ((I0) + 1) * (WTW * 4) + 8);                               \
   }
-#define W_FU(Q, ST, S)                                                                                \
-  u[Q] = (reinterpret_cast<const wf4*>(smem + (ST) * WSTAGE_FLOATS + WIN_FLOATS) + u_off + (S) * 64)[(Q) * 256];
-#define W_TROW(I)                                                                                     \
-  {                                                                                                   \
-    const float d0 = dd[I][0].x, d1 = dd[I][0].y, d2 = dd[I][1].x, d3 = dd[I][1].y;                   \
-    tt[I][0] = d0 - d2; tt[I][1] = d1 + d2; tt[I][2] = d2 - d1; tt[I][3] = d1 - d3;                   \
-  }
-#define W_TCOL01                                                                                      \
-  _Pragma("unroll") for (int j = 0; j < 4; ++j) { v[j] = tt[0][j] - tt[2][j]; v[4 + j] = tt[1][j] + tt[2][j]; }
-#define W_TCOL23                                                                                      \
-  {                                                                                                   \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) v[8 + j] = tt[2][j] - tt[1][j];                     \
-    _Pragma("unroll") for (int j = 0; j < 3; ++j) v[12 + j] = tt[1][j] - tt[3][j];                    \
-    v15n = tt[1][3] - tt[3][3];                                                                       \
+#define W_FU(Q, ST, S) u[Q] = *W_LP(const wf4, uofs[ST] + ((S) * 64 + (Q) * 256) * 16);
+  // V = B^T d B as 16 packed adds: rows first (pairs of columns), then the two column pairs of every row
+#define W_TRANSFORM                                                                                   \
+  if (!(DBG & 4)) {                                                                                   \
+    const wf2 c0a = pk_sub(dd[0][0], dd[2][0]), c0b = pk_sub(dd[0][1], dd[2][1]);                     \
+    const wf2 c1a = pk_add(dd[1][0], dd[2][0]), c1b = pk_add(dd[1][1], dd[2][1]);                     \
+    const wf2 c2a = pk_sub(dd[2][0], dd[1][0]), c2b = pk_sub(dd[2][1], dd[1][1]);                     \
+    const wf2 c3a = pk_sub(dd[1][0], dd[3][0]), c3b = pk_sub(dd[1][1], dd[3][1]);                     \
+    vp[0][0] = pk_t01(c0a, c0b); vp[0][1] = pk_t23(c0a, c0b);                                         \
+    vp[1][0] = pk_t01(c1a, c1b); vp[1][1] = pk_t23(c1a, c1b);                                         \
+    vp[2][0] = pk_t01(c2a, c2b); vp[2][1] = pk_t23(c2a, c2b);                                         \
+    vp[3][0] = pk_t01(c3a, c3b); vp[3][1] = pk_t23(c3a, c3b);                                         \
   }
 
 #define W_SB __builtin_amdgcn_sched_barrier(0);
-#define W_MF(P) wino_mfma<P>(u[(P) >> 2][(P) & 3], v[P]);
-  // one K-step (CST, CS): 16 slots = MFMA + side work.  The U quads are refilled as they are consumed (quad 3 of THIS step
-  // in slot 0, quads 0-2 of the next step (FST, FS) behind the slots that used them); the patch of the next step is fetched
-  // in slots 0-1 and transformed in slots 10-15 into v[] (positions 0-7 after MFMA 14, 8-15 after MFMA 15).
-#define W_STEP(CST, CS, FST, FS, X2, X3, X5, X6, X7, X9)                                              \
-  W_MF(0) v[15] = v15n; W_FD(0, FST, FS) W_FU(3, CST, CS) W_SB                                        \
-  W_MF(1) W_FD(2, FST, FS) W_SB                                                                       \
+#ifdef MISONET_EXPERIMENTS
+  // timeline of ONE wave (MISONET_WINO_TIMELINE=<Cin>): s_memtime stamps of the iterations around the first tile epilogues
+  unsigned long long* const tl_buf = (blockIdx.x == 8 && wave == 1) ? a.dbg_buf : nullptr;
+  int tl_n = 0;
+#define W_STAMP(ID) if (tl_buf && tl_n < 250) { if (lane == 0) { tl_buf[2 * tl_n] = (ID); tl_buf[2 * tl_n + 1] = __builtin_readcyclecounter(); } ++tl_n; }
+#else
+#define W_STAMP(ID)
+#endif
+#define W_MF(P) wino_mfma<P>(u[(P) >> 2][(P) & 3], vp[(P) >> 2][((P) & 3) >> 1][(P) & 1]);
+#define W_NONE
+#define W_X(...) if (!(DBG & (1 | 32))) { __VA_ARGS__ }      /* staging arithmetic, norm / raw reads, LDS writes */
+#define W_XL(...) if (!(DBG & (1 | 16))) { __VA_ARGS__ }     /* raw input DMA */
+#define W_XW(...) if (!(DBG & (1 | 8))) { __VA_ARGS__ }      /* weight DMA */
+  // One K-step (CST, CS): 16 MFMAs with only LDS / DMA work between them, then ONE VALU group.  U quads are refilled as they
+  // are consumed (quad 3 of THIS step in slot 0, quads 0-2 of the next step (FST, FS) behind the slots that used them); the
+  // patch of the next step is fetched in slots 5-6 and transformed in the VALU group.  X1-X3: LDS writes of the previous
+  // group's items; X7, X9-X11, X13, X14: norm entries and raw words for this group's items, or DMA pieces; XB: barrier (step
+  // 3 only, after slot 3, in front of every access to the next chunk's stage); XG: this step's staging arithmetic.
+#define W_STEP(CST, CS, FST, FS, X1, X2, X3, XB, X7, X9, X10, X11, X13, X14, XG)                      \
+  W_MF(0) W_FU(3, CST, CS) W_SB                                                                       \
+  W_MF(1) X1 W_SB                                                                                     \
   W_MF(2) X2 W_SB                                                                                     \
   W_MF(3) X3 W_SB                                                                                     \
+  XB                                                                                                  \
   W_MF(4) W_FU(0, FST, FS) W_SB                                                                       \
-  W_MF(5) X5 W_SB                                                                                     \
-  W_MF(6) X6 W_SB                                                                                     \
+  W_MF(5) W_FD(0, FST, FS) W_SB                                                                       \
+  W_MF(6) W_FD(2, FST, FS) W_SB                                                                       \
   W_MF(7) X7 W_SB                                                                                     \
   W_MF(8) W_FU(1, FST, FS) W_SB                                                                       \
   W_MF(9) X9 W_SB                                                                                     \
-  W_MF(10) W_T(W_TROW(0)) W_SB                                                                        \
-  W_MF(11) W_T(W_TROW(1)) W_SB                                                                        \
-  W_MF(12) W_T(W_TROW(2)) W_FU(2, FST, FS) W_SB                                                       \
-  W_MF(13) W_T(W_TROW(3)) W_SB                                                                        \
-  W_MF(14) W_T(W_TCOL01) W_SB                                                                         \
-  W_MF(15) W_T(W_TCOL23) W_SB
-#define W_NONE
-#define W_X(...) if (!(DBG & 1)) { __VA_ARGS__ }
-#define W_T(...) if (!(DBG & 4)) { __VA_ARGS__ } else { v[(DBG >> 4) & 15] += dd[0][0].x + dd[1][1].y + dd[2][0].x + dd[3][1].y; }
+  W_MF(10) X10 W_SB                                                                                   \
+  W_MF(11) X11 W_SB                                                                                   \
+  W_MF(12) W_FU(2, FST, FS) W_SB                                                                      \
+  W_MF(13) X13 W_SB                                                                                   \
+  W_MF(14) X14 W_SB                                                                                   \
+  W_MF(15) W_SB                                                                                       \
+  W_TRANSFORM XG W_SB
 
-  // ---- prologue: chunk 0 committed, chunk 1 in registers, operands of (chunk 0, step 0) transformed ----
+  // Chunk g on the matrix pipe from stage ST.  Chunk g + 1: raw ring -> stage STN (the wave's own DMA of two iterations ago:
+  // behind it in the wave's VMEM queue are the 10 pieces of the last iteration, hence vmcnt(10)).  After the barrier: U image
+  // of chunk g + 2 -> stage STNN, raw input of chunk g + 3 -> the raw slot this iteration has emptied.  In front of the
+  // barrier the U image of chunk g + 1 must have landed: behind it are the 6 raw pieces of the same iteration, vmcnt(6).
+  // vmcnt counts in issue order, stores included, and a tile epilogue queues exactly 16 stores (+ the statistics atomics of
+  // wave 0, which only make a wait more conservative) behind the DMA of its tile's last chunk: in the two iterations after an
+  // epilogue (post = 2, 1) the waits that look across them allow 16 more -- a run-time threshold (wait_vm_le).  Measured:
+  // waiting for the stores instead costs their HBM round trip per tile (the epilogue appeared twice as expensive), branching
+  // between two s_waitcnt immediates 13 % of the chunk time in instruction fetch.
+#define W_CHUNK_(ST, STN, STNN)                                                                       \
+  W_STEP(ST, 0, ST, 1, W_NONE, W_NONE, W_NONE, W_NONE,                                                \
+         W_X(W_STAMP(1) if (post) { W_VMCNT(26) } else { W_VMCNT(10) } W_STAMP(2) W_RR(rwa, 0)), W_X(W_RR(rwb, 1)), W_X(W_NR(nra, 0)), W_X(W_NR(nrb, 1)), W_NONE, W_NONE, \
+         W_X(W_CC(cva, rwa, nra) W_CC(cvb, rwb, nrb)))                                                \
+  W_STEP(ST, 1, ST, 2, W_X(W_CW(cva, 0, STN)), W_X(W_CW(cvb, 1, STN)), W_NONE, W_NONE,                \
+         W_X(W_RR(rwa, 2)), W_X(W_RR(rwb, 3)), W_X(W_NR(nra, 2)), W_X(W_NR(nrb, 3)), W_NONE, W_NONE,  \
+         W_X(W_CC(cva, rwa, nra) W_CC(cvb, rwb, nrb)))                                                \
+  W_STEP(ST, 2, ST, 3, W_X(W_CW(cva, 2, STN)), W_X(W_CW(cvb, 3, STN)), W_NONE, W_NONE,                \
+         W_X(W_RR(rwa, 4)), W_X(W_RRH), W_X(W_NR(nra, 4)), W_X(W_NR(nrb, 5)), W_NONE, W_NONE,         \
+         W_X(W_CC(cva, rwa, nra) W_CCH(nrb)))                                                         \
+  W_STEP(ST, 3, STN, 0, W_X(W_CW(cva, 4, STN)), W_X(W_CWH(STN)), W_NONE,                              \
+         W_STAMP(3) W_XW(if (post == 2) { W_VMCNT(22) } else { W_VMCNT(6) }) W_STAMP(4) W_BARRIER W_STAMP(5),                          \
+         W_XW(W_ISSUE_W(0, STNN, Dwso) W_ISSUE_W(1, STNN, Dwso)), W_XW(W_ISSUE_W(2, STNN, Dwso) W_ISSUE_W(3, STNN, Dwso)), \
+         W_XL(W_ISSUE_I(0) W_ISSUE_I(1)), W_XL(W_ISSUE_I(2) W_ISSUE_I(3)), W_XL(W_ISSUE_I(4)), W_XL(W_ISSUE_H), W_NONE)
+
+  // ---- prologue: raw chunks 0, 1, 2 and the U images of chunks 0, 1 on their way, chunk 0 staged, operands of (chunk 0,
+  // step 0) fetched and transformed ----
+  constexpr bool RAG = true;                         // (the prologue always applies the frame masks)
   W_LOAD_SETUP(ql)
-  __syncthreads();                                   // s_nrm visible
+  __syncthreads();                                   // s_nrm, s_zero visible
+  W_ISSUE_W(0, 0, W_WSO_L) W_ISSUE_W(1, 0, W_WSO_L) W_ISSUE_W(2, 0, W_WSO_L) W_ISSUE_W(3, 0, W_WSO_L)
   W_ISSUE_I(0) W_ISSUE_I(1) W_ISSUE_I(2) W_ISSUE_I(3) W_ISSUE_I(4) W_ISSUE_H
-  W_ISSUE_W(0) W_ISSUE_W(1) W_ISSUE_W(2) W_ISSUE_W(3)
   W_LATCH
   W_ADVANCE
-  W_NR(nra, sch[0]) W_CC(0, nra) W_CW(0, 0) W_ISSUE_I(0)
-  W_NR(nra, sch[1]) W_CC(1, nra) W_CW(1, 0) W_ISSUE_I(1)
-  W_NR(nra, sch[2]) W_CC(2, nra) W_CW(2, 0) W_ISSUE_I(2)
-  W_NR(nra, sch[3]) W_CC(3, nra) W_CW(3, 0) W_ISSUE_I(3)
-  W_NR(nra, sch[4]) W_CC(4, nra) W_CW(4, 0) W_ISSUE_I(4)
-  W_NR(nra, hch) W_CH(0, nra) W_ISSUE_H
-  W_CWW(0, 0) W_ISSUE_W(0) W_CWW(1, 0) W_ISSUE_W(1) W_CWW(2, 0) W_ISSUE_W(2) W_CWW(3, 0) W_ISSUE_W(3)
-  W_LATCH
+  W_ISSUE_W(0, 1, W_WSO_L) W_ISSUE_W(1, 1, W_WSO_L) W_ISSUE_W(2, 1, W_WSO_L) W_ISSUE_W(3, 1, W_WSO_L)
+  W_ISSUE_I(0) W_ISSUE_I(1) W_ISSUE_I(2) W_ISSUE_I(3) W_ISSUE_I(4) W_ISSUE_H
+  W_LATCH                                            // C = chunk 0, D = chunk 1
   W_ADVANCE
-  __syncthreads();
+  W_VMCNT(0)
+  W_RR(rwa, 0) W_NR(nra, 0) W_CC(cva, rwa, nra) W_CW(cva, 0, 0)
+  W_RR(rwa, 1) W_NR(nra, 1) W_CC(cva, rwa, nra) W_CW(cva, 1, 0)
+  W_RR(rwa, 2) W_NR(nra, 2) W_CC(cva, rwa, nra) W_CW(cva, 2, 0)
+  W_RR(rwa, 3) W_NR(nra, 3) W_CC(cva, rwa, nra) W_CW(cva, 3, 0)
+  W_RR(rwa, 4) W_NR(nra, 4) W_CC(cva, rwa, nra) W_CW(cva, 4, 0)
+  W_RRH W_NR(nrb, 5) W_CCH(nrb) W_CWH(0)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's reads of raw slot 0 are done: chunk 2 may land there
+  W_ISSUE_I(0) W_ISSUE_I(1) W_ISSUE_I(2) W_ISSUE_I(3) W_ISSUE_I(4) W_ISSUE_H
+  W_LATCH                                            // C = chunk 1, D = chunk 2
+  W_ADVANCE
+  cslot = 1;
+  rofs = rofs0 + WRAW_FLOATS * 4;
+  rhofs = rhofs0 + WRAW_FLOATS * 4;
+  W_BARRIER
   W_FD(0, 0, 0) W_FD(2, 0, 0) W_FU(0, 0, 0) W_FU(1, 0, 0) W_FU(2, 0, 0)
-  W_TROW(0) W_TROW(1) W_TROW(2) W_TROW(3) W_TCOL01 W_TCOL23
+  W_TRANSFORM
   wfor<256>([&](auto i) __attribute__((always_inline)) { agpr_zero<decltype(i)::value>(); });
   asm volatile("s_nop 4");
 
   unsigned qc = q0;                                  // tile of the chunk on the matrix pipe
   int kc = 0;
-  int st = 0;                                        // stage of chunk g
+  int ph3 = 0;                                       // stage of chunk g = g mod 3
+  int post = 0;                                      // iterations since a tile epilogue: 2, 1, then 0
   const unsigned G = (q1 - q0) * (unsigned)nchunk;
   for (unsigned g = 0; g < G; ++g) {
-    const int stn = st == WNSTAGE - 1 ? 0 : st + 1;
-    // steps 0-2: chunk g + 1 registers -> stage stn, the loads of chunk g + 2 issued item by item behind it
-    W_STEP(st, 0, st, 1, W_X(W_NR(nra, sch[0]) W_NR(nrb, sch[1])), W_X(W_CC(0, nra)), W_X(W_CW(0, stn) W_ISSUE_I(0)), W_X(W_CC(1, nrb)),
-           W_X(W_CW(1, stn) W_ISSUE_I(1)), W_X(W_NR(nra, sch[2]) W_NR(nrb, sch[3])))
-    W_STEP(st, 1, st, 2, W_X(W_CC(2, nra)), W_X(W_CW(2, stn) W_ISSUE_I(2)), W_X(W_CC(3, nrb)), W_X(W_CW(3, stn) W_ISSUE_I(3)),
-           W_X(W_NR(nra, sch[4]) W_NR(nrb, hch)), W_X(W_CC(4, nra)))
-    W_STEP(st, 2, st, 3, W_X(W_CW(4, stn) W_ISSUE_I(4)), W_X(W_CH(stn, nrb) W_ISSUE_H), W_X(W_CWW(0, stn) W_ISSUE_W(0)),
-           W_X(W_CWW(1, stn) W_ISSUE_W(1)), W_X(W_CWW(2, stn) W_ISSUE_W(2)), W_X(W_CWW(3, stn) W_ISSUE_W(3)))
-    if (!(DBG & 8)) __syncthreads();                 // chunk g + 1 complete in stage stn; the stage of chunk g - 1 is free
-    W_STEP(st, 3, stn, 0, W_NONE, W_NONE, W_NONE, W_NONE, W_NONE, W_NONE)
-    W_LATCH
-    W_ADVANCE
-    st = stn;
+    // six bodies: the stage rotation (3) x frame masks in the staging arithmetic or not (only the last column tile of an
+    // utterance stages frames that do not exist)
+#define W_CHUNKS                                                                                      \
+    if (ph3 == 0) { W_CHUNK_(0, 1, 2) } else if (ph3 == 1) { W_CHUNK_(1, 2, 0) } else { W_CHUNK_(2, 0, 1) }
+    if (Cfull) {
+      constexpr bool RAG = false;
+      W_CHUNKS
+    } else {
+      constexpr bool RAG = true;
+      W_CHUNKS
+    }
     if (++kc == nchunk) {
       // ---- tile epilogue: Y = A^T M A per (channel, tile), + bias, ELU, centring, stores, statistics ----
       asm volatile("s_nop 15\n\ts_nop 7");             // the last MFMA's result (16 passes) before any accumulator read
+      W_STAMP(10)
       if (!(DBG & 2)) {
       int tt_, ft_, n, cg;
       W_DECODE(qc, tt_, ft_, n, cg)
@@ -379,24 +517,30 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
       const int cbase = cg * 32;
       const int fa = f0 + 2 * wave;
       const int t = t0 + 2 * l31;
-      const bool full_t = (t0 + WTT <= T);
       const bool r0ok = fa < F, r1ok = fa + 1 < F;
       const bool c0ok = t < T, c1ok = t + 1 < T;
       const unsigned P4 = (unsigned)F * (unsigned)Tp * 4u;
       const float* ob_ = a.out + (long long)n * a.out_bstride + (long long)a.out_c0 * F * Tp;
       const __amdgpu_buffer_rsrc_t rs_out = make_rsrc_e(reinterpret_cast<unsigned long long>(ob_), (unsigned)a.Cout * P4);
       const unsigned vbase = (unsigned)(fa * Tp + t) * 4u + (unsigned)(4 * half) * P4;
-      const unsigned vo0 = (r0ok && c0ok) ? vbase : 0x80000000u;
-      const unsigned vo1 = (r1ok && c0ok) ? vbase + (unsigned)Tp * 4u : 0x80000000u;
+      // Stores are 16 bytes per lane (the store path is ISSUE-bound: 32 8-byte stores per lane cost 17 k cycles per tile, a
+      // fifth of the kernel): neighbouring lanes exchange pairs, the even lane stores frames t .. t + 3 of row fa, the odd lane
+      // frames t - 2 .. t + 1 of row fa + 1.  A group whose last frames are >= T writes words of the row's padding [T, Tp),
+      // which every consumer masks.
+      const bool ev = (l31 & 1) == 0;
+      const unsigned vo_x = ev ? ((r0ok && c0ok) ? vbase : 0x80000000u)
+                               : ((r1ok && t - 2 < T) ? vbase + (unsigned)Tp * 4u - 8u : 0x80000000u);
       const float m00 = (r0ok && c0ok) ? 1.f : 0.f, m01 = (r0ok && c1ok) ? 1.f : 0.f;
       const float m10 = (r1ok && c0ok) ? 1.f : 0.f, m11 = (r1ok && c1ok) ? 1.f : 0.f;
       const bool act = a.act != 0;
+      const unsigned bias_a = lds0 + WBIAS_B + (unsigned)(4 * half) * 4u;      // explicit LDS addresses: a generic-pointer access is a
+      const unsigned red_a = lds0 + WRED_B;                                    // FLAT op, and a flat op waits for vmcnt(0) = for every store
       float s1[16], s2[16];
       wfor<16>([&](auto rc) __attribute__((always_inline)) {
         constexpr int r = decltype(rc)::value;
         constexpr int kr = (r & 3) + 8 * (r >> 2);
         const unsigned coff = (unsigned)(cbase + kr) * P4;
-        const float b = a.bias[cbase + kr + 4 * half];
+        const float b = *W_LP(const float, bias_a + (unsigned)(cbase + kr) * 4u);
         const float cr = act ? elu_fast(b) : 0.f;
         float e0[4], e1[4];
         wfor<4>([&](auto xc) __attribute__((always_inline)) {
@@ -408,50 +552,58 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
         });
         float y00 = (e0[0] + e0[1]) + e0[2] + b, y10 = (e0[1] - e0[2]) - e0[3] + b;
         float y01 = (e1[0] + e1[1]) + e1[2] + b, y11 = (e1[1] - e1[2]) - e1[3] + b;
-        if (act) {
+        if (act && !(DBG & 256)) {
           y00 = elu_fast(y00) - cr; y01 = elu_fast(y01) - cr;
           y10 = elu_fast(y10) - cr; y11 = elu_fast(y11) - cr;
         }
-        if (full_t) {
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wu2, wf2{y00, y01}), rs_out, vo0 + coff, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wu2, wf2{y10, y11}), rs_out, vo1 + coff, 0, 0);
-        } else {
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y00), rs_out, vo0 + coff, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y10), rs_out, vo1 + coff, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y01), rs_out, c1ok ? vo0 + coff + 4u : 0x80000000u, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y11), rs_out, c1ok ? vo1 + coff + 4u : 0x80000000u, 0, 0);
+        if (!(DBG & 64)) {
+          // (quad_perm [1,0,3,2]: the neighbour's value; the compiler folds the move into v_cndmask_b32_dpp)
+          const float n00 = dpp_get<0xB1>(y00), n01 = dpp_get<0xB1>(y01), n10 = dpp_get<0xB1>(y10), n11 = dpp_get<0xB1>(y11);
+          const wf4 o = {ev ? y00 : n10, ev ? y01 : n11, ev ? n00 : y10, ev ? n01 : y11};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rs_out, vo_x + coff, 0, 0);
         }
         const float z00 = y00 * m00, z01 = y01 * m01, z10 = y10 * m10, z11 = y11 * m11;
         s1[r] = (z00 + z01) + (z10 + z11);
         s2[r] = fmaf(z00, z00, fmaf(z01, z01, fmaf(z10, z10, z11 * z11)));
       });
-      if (act) {
+      W_STAMP(11)
+      if (act && !(DBG & 128)) {
         const float x1 = reduce16_halfwave(s1, lane);
         const float x2 = reduce16_halfwave(s2, lane);
         if ((lane & 16) == 0) {
           const int q = lane & 15;
           const int co_l = (q & 3) + 8 * (q >> 2) + 4 * half;
-          s_red[(wave * 32 + co_l) * 2 + 0] = x1;
-          s_red[(wave * 32 + co_l) * 2 + 1] = x2;
+          W_DSW(red_a + (unsigned)((wave * 32 + co_l) * 2) * 4u, x1, 0)
+          W_DSW(red_a + (unsigned)((wave * 32 + co_l) * 2) * 4u, x2, 4)
         }
-        __syncthreads();
+        W_BARRIER
         if (tid < 64) {
           const int co_l = tid >> 1, which = tid & 1;
           const int co = cbase + co_l;
           if (co < a.Cout) {
             float tot = 0.f;
             for (int w = 0; w < 4; ++w)
-              if (f0 + 2 * w < F) tot += s_red[(w * 32 + co_l) * 2 + which];
+              if (f0 + 2 * w < F) tot += *W_LP(const float, red_a + (unsigned)((w * 32 + co_l) * 2 + which) * 4u);
             dstat_add(a.out_stats + (((long long)n * a.out_sstride + a.out_c0 + co) * 2 + which) * DS_NL, (double)tot);
           }
         }
       }
       }
+      W_STAMP(12)
       wfor<256>([&](auto i) __attribute__((always_inline)) { agpr_zero<decltype(i)::value>(); });
       asm volatile("s_nop 4");
+      W_STAMP(13)
       kc = 0;
       ++qc;
+      post = (DBG & (2 | 64)) ? 0 : 3;
     }
+    ph3 = ph3 == 2 ? 0 : ph3 + 1;
+    post = post > 0 ? post - 1 : 0;
+    W_LATCH
+    W_ADVANCE
+    cslot ^= 1;
+    rofs = cslot ? rofs0 + WRAW_FLOATS * 4 : rofs0;
+    rhofs = cslot ? rhofs0 + WRAW_FLOATS * 4 : rhofs0;
   }
 }
 
@@ -471,12 +623,9 @@ hipError_t conv_wino_init() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_f32<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)WINO_LDS);
 #ifdef MISONET_EXPERIMENTS
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_f32<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_f32<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_f32<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_f32<7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_f32<11>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_f32<15>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS);
+#define W_ATTR(D) if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_f32<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS);
+  W_ATTR(1) W_ATTR(2) W_ATTR(3) W_ATTR(4) W_ATTR(7) W_ATTR(10) W_ATTR(18) W_ATTR(34) W_ATTR(64) W_ATTR(128) W_ATTR(256) W_ATTR(448)
+#undef W_ATTR
 #endif
   return e;
 }
@@ -493,13 +642,30 @@ hipError_t launch_conv_wino(const ConvArgs& a_in, int n_samples, hipStream_t s) 
   const unsigned grid = (unsigned)(tiles < cus ? tiles : cus);
   const dim3 g(a.xcd ? (unsigned)cus : grid);
 #ifdef MISONET_EXPERIMENTS
+  {
+    static const int tl_cin = [] { const char* e = getenv("MISONET_WINO_TIMELINE"); return e ? atoi(e) : 0; }();
+    static unsigned long long* tl_dev = nullptr;
+    static int tl_done = 0;
+    if (tl_cin && a.Cin == tl_cin && a.Fin == 63 && n_samples == 96 && tl_done < 2) {
+      if (!tl_dev) (void)hipMalloc(reinterpret_cast<void**>(&tl_dev), 512 * 8);
+      (void)hipMemsetAsync(tl_dev, 0, 512 * 8, s);
+      a.dbg_buf = tl_dev;
+      hipLaunchKernelGGL(conv3x3_wino_f32<0>, g, dim3(256), WINO_LDS, s, a);
+      (void)hipStreamSynchronize(s);
+      unsigned long long h[512];
+      (void)hipMemcpy(h, tl_dev, sizeof(h), hipMemcpyDeviceToHost);
+      if (++tl_done == 2) {
+        fprintf(stderr, "[wino timeline] Cin=%d nchunk=%d: id, cycles since previous stamp\n", a.Cin, a.Cin / 8);
+        for (int i = 0; i < 250 && h[2 * i]; ++i)
+          fprintf(stderr, "  %2llu %8lld\n", h[2 * i], i ? (long long)(h[2 * i + 1] - h[2 * i - 1]) : 0ll);
+      }
+      return hipGetLastError();
+    }
+  }
   switch (wino_dbg_env()) {
-    case 1: hipLaunchKernelGGL(conv3x3_wino_f32<1>, g, dim3(256), WINO_LDS, s, a); return hipGetLastError();
-    case 2: hipLaunchKernelGGL(conv3x3_wino_f32<2>, g, dim3(256), WINO_LDS, s, a); return hipGetLastError();
-    case 3: hipLaunchKernelGGL(conv3x3_wino_f32<3>, g, dim3(256), WINO_LDS, s, a); return hipGetLastError();
-    case 7: hipLaunchKernelGGL(conv3x3_wino_f32<7>, g, dim3(256), WINO_LDS, s, a); return hipGetLastError();
-    case 11: hipLaunchKernelGGL(conv3x3_wino_f32<11>, g, dim3(256), WINO_LDS, s, a); return hipGetLastError();
-    case 15: hipLaunchKernelGGL(conv3x3_wino_f32<15>, g, dim3(256), WINO_LDS, s, a); return hipGetLastError();
+#define W_CASE(D) case D: hipLaunchKernelGGL(conv3x3_wino_f32<D>, g, dim3(256), WINO_LDS, s, a); return hipGetLastError();
+    W_CASE(1) W_CASE(2) W_CASE(3) W_CASE(4) W_CASE(7) W_CASE(10) W_CASE(18) W_CASE(34) W_CASE(64) W_CASE(128) W_CASE(256) W_CASE(448)
+#undef W_CASE
     default: break;
   }
 #endif
