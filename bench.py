@@ -82,6 +82,18 @@ def conv_flops_per_forward(in_ch, out_ch, T, en=(24, 32, 32, 32, 32, 64, 128), d
     return 2.0 * mac
 
 
+def dense_flops_per_forward(in_ch, out_ch, T, en=(24, 32, 32, 32, 32, 64, 128), de=(128, 64, 32, 32, 32, 32, 24)):
+    """the share of conv_flops_per_forward in the 50 stride-1 same-padded DenseBlock convs (model.py:437-482): the layers the
+    f32w mode runs in Winograd F(2x2, 3x3) form, 16 instead of 36 products per 2 x 2 outputs"""
+    Fe = [127, 63, 31, 15, 7, 3, 1]
+
+    def dense(c0, g1, g2, F):
+        return sum((c0 + i * g1) * (g1 if i < 4 else g2) for i in range(5)) * 9 * F * T
+    mac = sum(dense(en[b], en[b], en[b], Fe[b]) for b in range(5))
+    mac += sum(dense(2 * de[i], de[i], 2 * de[i], Fe[6 - i]) for i in range(2, 7))
+    return 2.0 * mac
+
+
 def conv_bytes_per_forward(in_ch, out_ch, T, en=(24, 32, 32, 32, 32, 64, 128), de=(128, 64, 32, 32, 32, 32, 24),
                            inner_elem_bytes=4.0):
     """Algorithmic HBM bytes of the conv layers of one forward-sample with layer-level fusion only (every conv reads its
@@ -254,7 +266,7 @@ def pmc_live(precision, B, T, timeout_s=150):
 
 def _traffic_entry(precision):
     """measured HBM bytes per conv launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/)"""
-    for name in ("r04z_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r05_traffic.json", "r04z_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", name)))
             if precision in tj:
@@ -312,8 +324,22 @@ def roofline_objects(precision, B, T, steps, dt_conv_ms, n_launch, live=None):
     # 2.5 PF bf16 / fp16 MFMA) -- i.e. the rate the mode would reach with the matrix pipe 100 % busy on useful work
     raw_peak = PEAK_BF16_MFMA_TF if terms else PEAK_F32_MFMA_TF
     mfma_peak = round(raw_peak / terms, 1) if terms else raw_peak
+    wino = None
+    if precision == "f32w":
+        # the DenseBlock layers issue 16 / 36 of their algorithmic products (Winograd F(2x2, 3x3)), the other layers all of them:
+        # peak = the algorithmic rate at which the f32 matrix pipe would be 100 % busy with exactly those products
+        dn = B * (N_MIC * dense_flops_per_forward(2 * N_MIC, 2 * N_SPK, T) + N_SPK * dense_flops_per_forward(2 * (N_MIC + 2), 2, T))
+        issued = dn * 16.0 / 36.0 + (flops_step - dn)
+        mfma_peak = round(raw_peak * flops_step / issued, 1)
+        wino = {"dense_block_share_of_flops": round(dn / flops_step, 4), "issued_over_algorithmic_products": round(issued / flops_step, 4),
+                "issued_tflops": round(ach_tf * issued / flops_step, 1),
+                "frac_of_direct_f32_peak": round(ach_tf / raw_peak, 4)}
     r_mfma = dict(common, bound="mfma", achieved=round(ach_tf, 3), peak=mfma_peak, unit="TFLOP/s",
                   frac=round(ach_tf / mfma_peak, 4))
+    if wino:
+        r_mfma["peak_basis"] = (f"{raw_peak} TF/s f32 MFMA peak x algorithmic / issued products (Winograd F(2x2,3x3) on the "
+                                "DenseBlock convs: 16 of 36)")
+        r_mfma.update(wino)
     if terms:
         r_mfma["peak_basis"] = f"{raw_peak:.0f} TF/s dense 16-bit MFMA peak / {terms} MFMA products per algorithmic product"
         r_mfma["mfma_products_per_product"] = terms
@@ -387,8 +413,9 @@ def wav_leg(enh, W, rank, B, n, steps, warmup, dev, headline_value):
                             "host_resident_serial": round(v_ser / headline_value, 4)},
             "pcie_bytes_per_utterance": {"h2d": n * (N_MIC + N_SPK) * 4, "d2h": N_SPK * n * 2},
             "host_equals_device_result": same,
-            "what": "float32 wav [B, 64000, 6] (+ clean [B, 64000, 2]) -> HIP STFT -> MISO1x6/align/MVDRx2/MISO3x2 -> one "
-                    "batched torch.istft -> x 32767 -> int16 [B, 2, 64000]; the headline starts and ends at spectrograms"}, pcm_d
+            "what": "float32 wav [B, 64000, 6] (+ clean [B, 64000, 2]) -> HIP STFT (stft_pack_k) -> MISO1x6/align/MVDRx2/"
+                    "MISO3x2 -> ONE istft_k launch (inverse DFT, overlap-add, x 32767, truncating cast) -> int16 [B, 2, 64000]; "
+                    "the headline starts and ends at spectrograms"}, pcm_d
 
 
 def workload_name(world, B):
@@ -439,7 +466,7 @@ def main():
     ap.add_argument("--precision", choices=sorted(MODES), default=HEADLINE_PRECISION,
                     help="arithmetic of the 3x3 convs (default: the fp32-faithful headline mode)")
     ap.add_argument("--no-alt", action="store_true", help="skip the runs of the other precision modes (N = 1 only)")
-    ap.add_argument("--alt", default="f32,bf16x6,f16x3,bf16x3",
+    ap.add_argument("--alt", default="f32,f32w,bf16x6,f16x3,bf16x3",
                     help="comma-separated precision modes timed beside the headline (alt_precision on the line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--wav", action="store_true",
@@ -594,10 +621,32 @@ def main():
                 if not args.no_profile:
                     k = max(1, min(args.steps, 3))
                     _, ms2, cnt2 = run_steps(enh, mix, clean, out, k, 0, None, L, _lib, True)
-                    a["roofline"] = roofline_objects(other, B, T, k, ms2[0], cnt2[0])[0]
+                    # the two modes whose arithmetic is literally float32 get their own LIVE counters
+                    live2 = pmc_live(other, B, T) if (other in ("f32", "f32w") and not args.no_pmc) else None
+                    a["roofline"] = roofline_objects(other, B, T, k, ms2[0], cnt2[0], live2)[0]
+                    a["roofline"]["time_share"] = {"conv_ms_per_step": round(ms2[0] / k, 2), "tcn_ms_per_step": round(ms2[1] / k, 2),
+                                                   "mvdr_ms_per_step": round(ms2[2] / k, 2), "other_ms_per_step": round(ms2[3] / k, 2)}
                 alts.append(a)
             m1.set_precision(args.precision)
             m3.set_precision(args.precision)
+            # The literal-float32 figures INSIDE the roofline object (the driver keeps that object whole): "exact_f32" = every
+            # conv an fmaf chain on v_mfma_f32_32x32x2_f32 (the reference's own arithmetic, model.py:77-80, 401-416);
+            # "winograd_f32" = the same matrix cores with the DenseBlock convs in Winograd F(2x2, 3x3) form.
+            if roof is not None:
+                for key, mode in (("exact_f32", "f32"), ("winograd_f32", "f32w")):
+                    src = [a for a in alts if a["dtype"] == mode and "roofline" in a]
+                    if mode == args.precision:
+                        src = [{"value": round(value, 3), "steps": args.steps, "roofline": roof}]
+                    if src:
+                        r2 = src[0]["roofline"]
+                        roof[key] = {"dtype": mode, "value": src[0]["value"], "unit": "utt/s",
+                                     "ms_per_step": round(B / src[0]["value"] * 1e3, 2),
+                                     **{kk: r2.get(kk) for kk in ("kernel", "achieved", "peak", "frac", "avg_launch_ms", "traffic",
+                                                                  "traffic_over_layout_bytes", "mfma_busy_frac_pmc",
+                                                                  "clock_ghz_observed_pmc", "pmc_fields_measured_live",
+                                                                  "pmc_source_sha16", "time_share", "peak_basis",
+                                                                  "issued_tflops", "frac_of_direct_f32_peak")
+                                        if r2.get(kk) is not None}}
         # latency of ONE utterance (B = 1: the reference harness' own batch size, tester.py:846-975) in the headline mode
         b1 = None
         if world == 1 and not args.no_alt:
@@ -675,6 +724,11 @@ def main():
                        "batch_per_gpu": B, "global_batch": world * B, "frames": T, "freq_bins": 129,
                        "parallelism": f"utterance-shard x{world}"},
             "realtime_factor": round(value * (n / 16000.0), 2), "source_sha16": _source_sha16(),
+            # every MISONET_* variable of this process: {} in a clean run.  The product library reads none of them (the kernel
+            # experiment switches exist only in `make exp`'s libmisonet_hip_exp.so, selected through MISONET_LIB_PATH -- which
+            # would show here, as would the harness hooks MISONET_BENCH_* and MISONET_PRECISION)
+            "env_overrides": {k: v for k, v in sorted(os.environ.items()) if k.startswith("MISONET_")},
+            "library": os.path.basename(_lib.LIB_PATH),
             "rccl_ranks": rccl_ranks, "per_rank_utt_per_s": [round(v, 3) for v in per_rank],
             "per_rank_utterances": rank_ranges, "backend": (backend if world > 1 else None),
             "parity": (cpu or {}).pop("parity_of_headline", None) if cpu else None,

@@ -82,7 +82,10 @@ int misonet_net_commit(misonet_net* net);
  *   2 "bf16x3"  every product as w_hi*x_hi + w_hi*x_lo + w_lo*x_hi with 16-bit operands (2.4e-5 per forward, not
  *               fp32-faithful; loses |mean|/std of its accuracy when a layer's input has |mean| >> std), same dataflow
  *               with two parts -- the fastest mode;
- *   1 "bf16x3p" the arithmetic of mode 2 on planar float32 activations (normalise-on-load staging).
+ *   1 "bf16x3p" the arithmetic of mode 2 on planar float32 activations (normalise-on-load staging);
+ *   5 "f32w"    (ABI 430) mode 0 with the DenseBlock convs (model.py:437-482: 94 % of the MACs) in Winograd F(2x2, 3x3) form:
+ *               float32 products and sums on the same matrix cores, 2.25 x fewer of them (conv_wino.hip); measured 2.0e-6
+ *               per forward against the reference (mode 0: 2.6e-6), 1.47 x mode 0's speed.  Same planar float32 layout.
  * The choice is internal to the workspace (whose size depends on it: misonet_net_workspace_bytes must be asked again
  * after a change): inputs, outputs and taps are the same float32 / complex64 tensors in every mode. */
 int misonet_net_set_precision(misonet_net* net, int mode);
@@ -178,6 +181,8 @@ int misonet_pipeline_run_wav(misonet_pipeline* p, const float* wav_dev, const fl
  * (the one allocation outside *_commit). */
 int misonet_stft_frames(int n_samples);
 long long misonet_stft_workspace_bytes(int B, int M, int n_samples);
+/* STFT + iSTFT tables (0.3 MB) and kernel attributes of the CURRENT device; idempotent (ABI 430) */
+int misonet_frontend_init(void);
 int misonet_stft(const float* wav_dev, int B, int n_samples, int M, void* out_dev, void* ws_dev, long long ws_bytes,
                  misonet_stream stream);
 
@@ -186,7 +191,10 @@ int misonet_stft(const float* wav_dev, int B, int n_samples, int M, void* out_de
 /* spec_dev complex64 [N, T, 129] (the boundary layout of every output above, T >= 2) -> 64 (T - 1) samples per row:
  * out_i16_dev int16 [N, 64 (T - 1)] (truncating cast of y * 32767) and / or out_f32_dev float32 of the same shape (either
  * may be NULL).  The windowed inverse DFT runs on the fp32 matrix cores, overlap-add and the division by the window
- * envelope follow on chip.  Its table (267 KB) is allocated once per device, on first use there. */
+ * envelope follow on chip.  Like every other call it is asynchronous and allocation-free -- PROVIDED the front-end tables of
+ * the current device exist: misonet_net_commit, misonet_pipeline_create and misonet_frontend_init build them (hipMalloc +
+ * synchronous copy, once per device, thread-safe).  A process that calls misonet_stft / misonet_istft without any of
+ * these builds them inside its first call, which therefore synchronises and must not sit inside a stream capture. */
 int misonet_istft(const void* spec_dev, int N, int T, void* out_i16_dev, float* out_f32_dev, misonet_stream stream);
 
 /* ---- per-launch timing (bench.py roofline leg): while enabled, the library brackets every conv launch, the TCN

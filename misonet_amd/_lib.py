@@ -67,6 +67,7 @@ SIGNATURES = {
     "misonet_stft_frames": (C.c_int, [C.c_int]),
     "misonet_stft_workspace_bytes": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
     "misonet_stft": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
+    "misonet_frontend_init": (C.c_int, []),
     "misonet_istft": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "misonet_pipeline_check": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "misonet_profile_begin": (C.c_int, [C.c_int]),

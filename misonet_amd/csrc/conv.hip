@@ -343,7 +343,7 @@ int device_cus() {
 
 int conv_xcd_env() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("MISONET_XCD"); v = e ? atoi(e) : 1; }
+  if (v < 0) v = exp_env("MISONET_XCD", 1);
   return v;
 }
 

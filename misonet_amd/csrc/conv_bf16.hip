@@ -296,7 +296,7 @@ hipError_t launch_conv_bf16(const ConvArgs& a_in, int n_samples, hipStream_t s) 
   ConvArgs a = a_in;
   {
     static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("MISONET_WS_DEBUG"); dbg = e ? atoi(e) : 0; }
+    if (dbg < 0) dbg = exp_env("MISONET_WS_DEBUG", 0);
     a.dbg = dbg;
   }
   const dim3 grid = conv_grid(a, n_samples, TT, FT, conv_xcd_env());
@@ -306,7 +306,7 @@ hipError_t launch_conv_bf16(const ConvArgs& a_in, int n_samples, hipStream_t s) 
   static int tl_env = -1;
   static int tl_done = 0;
   static unsigned long long* tl_buf = nullptr;
-  if (tl_env < 0) { const char* e = getenv("MISONET_TIMELINE"); tl_env = e ? atoi(e) : 0; }
+  if (tl_env < 0) tl_env = exp_env("MISONET_TIMELINE", 0);
   const bool do_tl = tl_env && tl_done < 3 && mode == 0 && a.Cin == 96 && a.Fout == 63 && n_samples >= 8;
   if (do_tl) {
     if (!tl_buf && hipMalloc(reinterpret_cast<void**>(&tl_buf), 64 * 8) != hipSuccess) tl_buf = nullptr;

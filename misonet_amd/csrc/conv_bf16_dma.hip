@@ -855,14 +855,14 @@ hipError_t launch_conv_bf16_dma(const ConvArgs& a_in, int n_samples, hipStream_t
   if (a.NR != conv_rows(a.sf, a.tr2)) return hipErrorInvalidValue;
   {
     static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("MISONET_WS_DEBUG"); dbg = e ? atoi(e) : 0; }
+    if (dbg < 0) dbg = exp_env("MISONET_WS_DEBUG", 0);
     a.dbg = dbg;
   }
   const dim3 grid = conv_grid(a, n_samples, TT, FT, conv_xcd_env());
   size_t lds = dma_lds_bytes(a.NR);
   {
     static int pad = -1;                          // MISONET_DMA_ONE=1: pad the LDS request so only ONE workgroup fits a CU (experiments)
-    if (pad < 0) { const char* e = getenv("MISONET_DMA_ONE"); pad = e ? atoi(e) : 0; }
+    if (pad < 0) pad = exp_env("MISONET_DMA_ONE", 0);
     if (pad && lds < 100 * 1024) lds = 100 * 1024;
   }
   const int mode = a.tr2 ? 2 : (a.sf == 2 ? 1 : 0);
@@ -870,7 +870,7 @@ hipError_t launch_conv_bf16_dma(const ConvArgs& a_in, int n_samples, hipStream_t
   static int tl_env = -1;
   static int tl_done = 0;
   static unsigned long long* tl_buf = nullptr;
-  if (tl_env < 0) { const char* e = getenv("MISONET_TIMELINE"); tl_env = e ? atoi(e) : 0; }
+  if (tl_env < 0) tl_env = exp_env("MISONET_TIMELINE", 0);
   const bool do_tl = tl_env && tl_done < 3 && mode == 0 && a.Cin == 96 && a.Fout == 63 && n_samples >= 8;
   a.dbg_buf = nullptr;
   if (do_tl) {
@@ -878,7 +878,7 @@ hipError_t launch_conv_bf16_dma(const ConvArgs& a_in, int n_samples, hipStream_t
     if (tl_buf) { (void)hipMemsetAsync(tl_buf, 0, 64 * 8, s); a.dbg_buf = tl_buf; }
   }
   static int dma2_env = -1;
-  if (dma2_env < 0) { const char* e = getenv("MISONET_DMA2"); dma2_env = e ? atoi(e) : 1; }
+  if (dma2_env < 0) dma2_env = exp_env("MISONET_DMA2", 1);
   const int nchunk_l = (a.Cin + CKB - 1) / CKB;
   // stride-2 layers run the pipelined kernel on 2-row tiles (5 staged rows; 9 rows x two stages do not fit the LDS)
   const bool dma2_ok = mode != 1 || (nchunk_l >= 2 && a.act && a.out_oct);

@@ -849,7 +849,7 @@ hipError_t launch_conv_x6_first(const ConvArgs& a_in, const void* wimg, int n_sa
   ConvArgs a = a_in;
   if (a.in_oct || a.sf != 1 || a.tr2 || a.act || a.Cin > 16 || a.Cout > 32 || a.ident_c < a.Cin || !wimg) return hipErrorInvalidValue;
   if (a.out_oct && a.out_oct != 3) return hipErrorInvalidValue;
-  static const int dbg = [] { const char* e = getenv("MISONET_WS_DEBUG"); return e ? atoi(e) : 0; }();
+  static const int dbg = exp_env("MISONET_WS_DEBUG", 0);
   a.dbg = dbg;
   const dim3 grid((a.T + TT - 1) / TT, (a.Fout + 3) / 4, n_samples);
   const size_t lds = (size_t)(3 * 6 * X6_TW + X6_WU) * 16 + (size_t)(2 * 4 * 32) * sizeof(float);
@@ -1008,13 +1008,13 @@ hipError_t launch_conv_bf16x6(const ConvArgs& a_in, int n_samples, hipStream_t s
   if (a.out_oct && ((a.out_oct != 3 && a.out_oct != 4) || (a.Cout & 7) || (a.out_c0 & 7) || (a.out_sstride & 7))) return hipErrorInvalidValue;
   if (a.out_oct == 4 && (a.tr2 || a.sf != 1 || a.descale != 1.f)) return hipErrorInvalidValue;   // stride-1 layers only (see OUT16)
   // measurement hooks: read once per process (thread-safe function-local statics)
-  static const int dbg = [] { const char* e = getenv("MISONET_WS_DEBUG"); return e ? atoi(e) : 0; }();
+  static const int dbg = exp_env("MISONET_WS_DEBUG", 0);
   a.dbg = dbg;
   a.dbg_buf = nullptr;
-  static const int tl_env = [] { const char* e = getenv("MISONET_TIMELINE"); return e ? atoi(e) : 0; }();
+  static const int tl_env = exp_env("MISONET_TIMELINE", 0);
   // MISONET_TIMELINE_F / _MODE: which layer (defaults: F = 63, stride 1); the timeline itself is a single-threaded experiment
-  static const int tl_f = [] { const char* e = getenv("MISONET_TIMELINE_F"); return e ? atoi(e) : 63; }();
-  static const int tl_mode = [] { const char* e = getenv("MISONET_TIMELINE_MODE"); return e ? atoi(e) : 0; }();
+  static const int tl_f = exp_env("MISONET_TIMELINE_F", 63);
+  static const int tl_mode = exp_env("MISONET_TIMELINE_MODE", 0);
   static int tl_done = 0;
   static unsigned long long* tl_buf = nullptr;
   const bool do_tl = tl_env && tl_done < 2 && (a.tr2 ? 2 : (a.sf == 2 ? 1 : 0)) == tl_mode && a.Cin == tl_env && a.Fout == tl_f && n_samples >= 8;
@@ -1025,15 +1025,15 @@ hipError_t launch_conv_bf16x6(const ConvArgs& a_in, int n_samples, hipStream_t s
   const int mode = a.tr2 ? 2 : (a.sf == 2 ? 1 : 0);
   // tile geometry: 128 frames x 8 rows for the stride-1 layers with more than 4 rows (10 staged rows per 8 instead of
   // 6 per 4 and one weight image per 216 instead of 108 MFMAs: 25 % fewer staged bytes per MFMA), else x 4 rows
-  static const int ft8 = [] { const char* e = getenv("MISONET_X6_ROWS8"); return e ? atoi(e) : 3; }();   // bit 0: stride-1, bit 1: transposed
+  static const int ft8 = exp_env("MISONET_X6_ROWS8", 3);   // bit 0: stride-1, bit 1: transposed
   // rows-in-M tiles (MODE 3) for the raw 4-channel output layer (MISONET_X6_RM=0: the 32-channel tiles, for A/B runs)
-  static const int rm_env = [] { const char* e = getenv("MISONET_X6_RM"); return e ? atoi(e) : 1; }();
+  static const int rm_env = exp_env("MISONET_X6_RM", 1);
   const bool rows_in_m = rm_env && mode == 0 && a.padf == 2 && !a.act && !a.out_oct && a.Cout <= 4 && a.ncg == 1 && a.Fout > 4;
   int ftr = rows_in_m ? 8 : ((mode != 1 && a.Fout > 4 && (ft8 & (mode == 0 ? 1 : 2))) ? 8 : 4);
   // "flexible" layers: stride-1, oct3 in and out, 4 < F <= 31.  Their 8-row kernel forms the statistics per half tile (U2), so
   // 4-row tiles give the same bits: the launch takes 4-row tiles when 8-row tiles would leave CUs without work (one utterance:
   // 48 frame-tile columns x ceil(F / 8) row tiles).  MISONET_X6_FLEX=0: always 8-row tiles with one statistic unit (A/B runs).
-  static const int flex_env = [] { const char* e = getenv("MISONET_X6_FLEX"); return e ? atoi(e) : 1; }();
+  static const int flex_env = exp_env("MISONET_X6_FLEX", 1);
   const bool flex = flex_env && mode == 0 && ftr == 8 && !rows_in_m && a.out_oct == 3 && a.Fout <= 31 && (a.Cout & 31) == 0;
   if (flex) {
     const int g_cus_ = device_cus();
@@ -1059,20 +1059,20 @@ hipError_t launch_conv_bf16x6(const ConvArgs& a_in, int n_samples, hipStream_t s
   if (nslots < 1) nslots = 1;
   if (nslots > nk_max) nslots = (int)nk_max;
   {
-    static const int cap = [] { const char* e = getenv("MISONET_X6_SLOTS"); return e ? atoi(e) : 0; }();   // workgroups per XCD (experiments)
+    static const int cap = exp_env("MISONET_X6_SLOTS", 0);   // workgroups per XCD (experiments)
     if (cap > 0 && nslots > cap) nslots = cap;
   }
   const dim3 pgrid((unsigned)(8 * nslots), 1, 1);
   // <= 24 output channels in one group: the epilogue variant that skips the padded register quad (MISONET_X6_Q3=0: A/B runs)
-  static const int q3_env = [] { const char* e = getenv("MISONET_X6_Q3"); return e ? atoi(e) : 1; }();
+  static const int q3_env = exp_env("MISONET_X6_Q3", 1);
   const bool q3 = q3_env && a.ncg == 1 && a.Cout <= 24 && a.out_oct == 3;
   // the F = 1 bottleneck pair on their reduced 4-row tiles (MISONET_X6_BN=0: the full tiles, for A/B runs)
-  static const int bn_env = [] { const char* e = getenv("MISONET_X6_BN"); return e ? atoi(e) : 1; }();
+  static const int bn_env = exp_env("MISONET_X6_BN", 1);
   const int bn = (!bn_env || mode != 0 || ftr != 4 || a.out_oct != 3 || a.nty != 1) ? 0
                  : ((a.Fin == 3 && a.Fout == 1 && a.padf == 0) ? 1 : ((a.Fin == 1 && a.Fout == 3 && a.padf == 2) ? 2 : 0));
   // Cout % 32 == 16 (the 48-channel conv of the last decoder's dense block): its 16-channel group as two rows in M
   // (MISONET_X6_G16=0: the padded 32-channel tiles, for A/B runs)
-  static const int g16_env = [] { const char* e = getenv("MISONET_X6_G16"); return e ? atoi(e) : 1; }();
+  static const int g16_env = exp_env("MISONET_X6_G16", 1);
   const bool g16 = g16_env && mode == 0 && ftr == 8 && a.out_oct == 3 && a.ncg >= 2 && (a.Cout & 31) == 16;
   if (g16) hipLaunchKernelGGL((conv3x3_bf16x6<0, 8, false, 4, true>), pgrid, dim3(512), x6_lds_bytes(10, 8), s, a, nslots);
   else if (flex && ftr == 8) hipLaunchKernelGGL((conv3x3_bf16x6<0, 8, false, 4, false, true>), pgrid, dim3(512), x6_lds_bytes(10, 8, 2), s, a, nslots);

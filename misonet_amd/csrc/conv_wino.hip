@@ -135,15 +135,15 @@ __device__ __forceinline__ void wait_vm_le(int n) {
 }
 
 // LDS map: 3 stages {normalised input [8][10][WTW] | U image 16 KB} | raw ring: 2 slots {80 items x 64 frames as the DMA leaves
-// them | 256 halo words} | s_nrm[2][WNRM_MAX] float2 | s_zero[WNRM_MAX] float2 | s_red [4][32][2] | 64 dummy words | bias [64]
+// them | 256 halo words} | s_nrm[2][WNRM_MAX] float2 | s_zero[WNRM_MAX] float2 | s_red [4][32][2] | 64 dummy words | bias [128]
 constexpr int WRAW_FLOATS = WCK * WNR * WTT + 256;
 constexpr unsigned WRAW_B = (unsigned)(WNSTAGE * WSTAGE_FLOATS) * 4u;
 constexpr unsigned WNRM_B = WRAW_B + 2u * WRAW_FLOATS * 4u;
 constexpr unsigned WZERO_B = WNRM_B + 2u * WNRM_MAX * 8u;
 constexpr unsigned WRED_B = WZERO_B + WNRM_MAX * 8u;
 constexpr unsigned WDUMMY_B = WRED_B + 4u * 64u * 4u;
-constexpr unsigned WBIAS_B = WDUMMY_B + 64u * 4u;       // the layer's bias (<= 64 channels): the epilogue must not queue VMEM loads behind the DMA
-constexpr size_t WINO_LDS = WBIAS_B + 64 * 4;
+constexpr unsigned WBIAS_B = WDUMMY_B + 64u * 4u;       // the layer's bias (<= 128 channels): the epilogue must not queue VMEM loads behind the DMA
+constexpr size_t WINO_LDS = WBIAS_B + 128 * 4;
 static_assert(WINO_LDS <= 160 * 1024, "one workgroup per CU: at most 160 KB of LDS");
 
 // DBG (timing experiments only, -DMISONET_EXPERIMENTS + MISONET_WINO_DBG): 1 = no staging side work in the chunk loop (wrong
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
   if (q0 >= q1) return;
   for (int i = tid; i < WNRM_MAX; i += 256) s_zero[i] = wf2{0.f, 0.f};
   float* s_bias = reinterpret_cast<float*>(smem_c + WBIAS_B);
-  if (tid < 64) s_bias[tid] = tid < a.ncg * 32 ? a.bias[tid] : 0.f;
+  if (tid < 128) s_bias[tid] = tid < a.ncg * 32 ? a.bias[tid] : 0.f;
 
   const unsigned row_e = (unsigned)Tp;
   const unsigned plane_b = (unsigned)F * row_e * 4u;
@@ -200,19 +200,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
   // re-deriving them from one base with VALU adds; every access is then base register + immediate.  The patch rows of a
   // K-step are read with ds_read2_b64, whose offsets reach 2 KB, so every (stage, step) has its own base)
   const unsigned lds0 = (unsigned)(unsigned long long)MN_WLDS(smem);
-  unsigned dofs[3][4];                         // patch fetch of step S: + (i * WTW (+ 2)) * 4
-  unsigned uofs[3];                            // U fetch: + (S * 64 + q * 256) * 16
-  unsigned cofs[3];                            // staging write of item i: + i * 16 * WTW * 4 (+ 0, 4, 8, 12)
-  unsigned hofs[3];                            // halo word write
-#pragma unroll
-  for (int s = 0; s < 3; ++s) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      dofs[s][k] = launder(lds0 + (unsigned)(s * WSTAGE_FLOATS + k * (2 * WNR * WTW) + (half * WNR + 2 * wave) * WTW + 2 * l31) * 4u);
-    uofs[s] = launder(lds0 + (unsigned)(s * WSTAGE_FLOATS + WIN_FLOATS) * 4u + (unsigned)(half * 32 + l31) * 16u);
-    cofs[s] = launder(lds0 + (unsigned)(s * WSTAGE_FLOATS + scr * WTW + 1 + 4 * sq) * 4u);
-    hofs[s] = launder(lds0 + (hrole ? (unsigned)(s * WSTAGE_FLOATS + hit * WTW + (hside ? WTT + 1 : 0)) * 4u : WDUMMY_B + (unsigned)(tid & 63) * 4u));
-  }
+  // Rolling stage addresses: the chunk on the matrix pipe reads stage c (patch rows of its K-steps 1-3: d1-d3, U: uc) and, in
+  // its last step, the first operands of stage n (d0n, un); the chunk being staged is written to stage n (cn, hn).  After a
+  // chunk every register moves one stage on with ONE v_add of an SGPR (+ stride, or - 2 strides at the wrap), so the chunk
+  // body names no stage and exists once per (frame masks, epilogue distance) instead of three times.
+  constexpr unsigned STAGE_B = (unsigned)WSTAGE_FLOATS * 4u, STEP_B = (unsigned)(2 * WNR * WTW) * 4u;
+  const unsigned dbase = lds0 + (unsigned)((half * WNR + 2 * wave) * WTW + 2 * l31) * 4u;
+  unsigned d1 = launder(dbase + STEP_B), d2 = launder(dbase + 2 * STEP_B), d3 = launder(dbase + 3 * STEP_B);
+  unsigned d0n = launder(dbase + STAGE_B);
+  unsigned uc = launder(lds0 + (unsigned)WIN_FLOATS * 4u + (unsigned)(half * 32 + l31) * 16u);
+  unsigned un = launder(uc + STAGE_B);
+  unsigned cn = launder(lds0 + STAGE_B + (unsigned)(scr * WTW + 1 + 4 * sq) * 4u);
+  unsigned hn = launder(lds0 + (hrole ? STAGE_B + (unsigned)(hit * WTW + (hside ? WTT + 1 : 0)) * 4u : WDUMMY_B + (unsigned)(tid & 63) * 4u));
 #define W_LP(TYPE, ADDR) (reinterpret_cast<__attribute__((address_space(3))) TYPE*>(ADDR))
   // raw ring: what THIS thread's DMA lanes wrote (slot 0; slot 1 is WRAW_FLOATS * 4 further): item i at + i * 4096
   const unsigned rofs0 = lds0 + WRAW_B + (unsigned)(scr * WTT + 4 * sq) * 4u;
@@ -356,14 +355,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
   // it cannot tell the raw ring and the U images from the staged rows), which would take the DMA's two-chunk run-ahead away.
   // Nothing reads these words before the chunk barrier, in front of which the wave waits for lgkmcnt(0) by hand.
 #define W_DSW(ADDR, VAL, OFF) asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(ADDR), "v"(VAL), "n"(OFF) : "memory");
-#define W_CW(CV, I, ST)                                                                               \
+#define W_CW(CV, I)                                                                                   \
   {                                                                                                   \
-    W_DSW(cofs[ST], CV[0].x, (I) * (16 * WTW * 4))                                                    \
-    W_DSW(cofs[ST], CV[0].y, (I) * (16 * WTW * 4) + 4)                                                \
-    W_DSW(cofs[ST], CV[1].x, (I) * (16 * WTW * 4) + 8)                                                \
-    W_DSW(cofs[ST], CV[1].y, (I) * (16 * WTW * 4) + 12)                                               \
+    W_DSW(cn, CV[0].x, (I) * (16 * WTW * 4))                                                          \
+    W_DSW(cn, CV[0].y, (I) * (16 * WTW * 4) + 4)                                                      \
+    W_DSW(cn, CV[1].x, (I) * (16 * WTW * 4) + 8)                                                      \
+    W_DSW(cn, CV[1].y, (I) * (16 * WTW * 4) + 12)                                                     \
   }
-#define W_CWH(ST) W_DSW(hofs[ST], chv, 0)
+#define W_CWH W_DSW(hn, chv, 0)
   // workgroup barrier without the compiler's fence (which is s_waitcnt vmcnt(0) while LDS-DMA is in flight): every LDS access
   // of this wave has completed (lgkmcnt(0)); the DMA the OTHER waves must see is covered by the explicit vmcnt in front of it
 #define W_BARRIER { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
@@ -371,15 +370,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
   wf2 dd[4][2];                                // raw patch of the next step: row i, columns (0, 1) / (2, 3)
   wf4 u[4];                                    // U operands: quad q = positions 4 q .. 4 q + 3; refilled quad by quad
   wf2 vp[4][2];                                // V operands of the running K-step: position 4 x + nu = vp[x][nu >> 1][nu & 1] (nu = 2 negated)
-#define W_FD(I0, ST, S)                                                                               \
+#define W_FD(I0, DREG)                                                                                \
   {                                                                                                   \
-    const unsigned si_ = dofs[ST][S];                                                                 \
+    const unsigned si_ = DREG;                                                                        \
     dd[I0][0] = *W_LP(const wf2, si_ + (I0) * (WTW * 4));                                             \
     dd[I0][1] = *W_LP(const wf2, si_ + (I0) * (WTW * 4) + 8);                                         \
     dd[I0 + 1][0] = *W_LP(const wf2, si_ + ((I0) + 1) * (WTW * 4));                                   \
     dd[I0 + 1][1] = *W_LP(const wf2, si_ + ((I0) + 1) * (WTW * 4) + 8);                               \
   }
-#define W_FU(Q, ST, S) u[Q] = *W_LP(const wf4, uofs[ST] + ((S) * 64 + (Q) * 256) * 16);
+#define W_FU(Q, UREG, S) u[Q] = *W_LP(const wf4, UREG + ((S) * 64 + (Q) * 256) * 16);
   // V = B^T d B as 16 packed adds: rows first (pairs of columns), then the two column pairs of every row
 #define W_TRANSFORM                                                                                   \
   if (!(DBG & 4)) {                                                                                   \
@@ -412,21 +411,21 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
   // patch of the next step is fetched in slots 5-6 and transformed in the VALU group.  X1-X3: LDS writes of the previous
   // group's items; X7, X9-X11, X13, X14: norm entries and raw words for this group's items, or DMA pieces; XB: barrier (step
   // 3 only, after slot 3, in front of every access to the next chunk's stage); XG: this step's staging arithmetic.
-#define W_STEP(CST, CS, FST, FS, X1, X2, X3, XB, X7, X9, X10, X11, X13, X14, XG)                      \
-  W_MF(0) W_FU(3, CST, CS) W_SB                                                                       \
+#define W_STEP(CS, FD_, FU_, FS, X1, X2, X3, XB, X7, X9, X10, X11, X13, X14, XG)                      \
+  W_MF(0) W_FU(3, uc, CS) W_SB                                                                        \
   W_MF(1) X1 W_SB                                                                                     \
   W_MF(2) X2 W_SB                                                                                     \
   W_MF(3) X3 W_SB                                                                                     \
   XB                                                                                                  \
-  W_MF(4) W_FU(0, FST, FS) W_SB                                                                       \
-  W_MF(5) W_FD(0, FST, FS) W_SB                                                                       \
-  W_MF(6) W_FD(2, FST, FS) W_SB                                                                       \
+  W_MF(4) W_FU(0, FU_, FS) W_SB                                                                       \
+  W_MF(5) W_FD(0, FD_) W_SB                                                                           \
+  W_MF(6) W_FD(2, FD_) W_SB                                                                           \
   W_MF(7) X7 W_SB                                                                                     \
-  W_MF(8) W_FU(1, FST, FS) W_SB                                                                       \
+  W_MF(8) W_FU(1, FU_, FS) W_SB                                                                       \
   W_MF(9) X9 W_SB                                                                                     \
   W_MF(10) X10 W_SB                                                                                   \
   W_MF(11) X11 W_SB                                                                                   \
-  W_MF(12) W_FU(2, FST, FS) W_SB                                                                      \
+  W_MF(12) W_FU(2, FU_, FS) W_SB                                                                      \
   W_MF(13) X13 W_SB                                                                                   \
   W_MF(14) X14 W_SB                                                                                   \
   W_MF(15) W_SB                                                                                       \
@@ -441,19 +440,19 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
   // epilogue (post = 2, 1) the waits that look across them allow 16 more -- a run-time threshold (wait_vm_le).  Measured:
   // waiting for the stores instead costs their HBM round trip per tile (the epilogue appeared twice as expensive), branching
   // between two s_waitcnt immediates 13 % of the chunk time in instruction fetch.
-#define W_CHUNK_(ST, STN, STNN)                                                                       \
-  W_STEP(ST, 0, ST, 1, W_NONE, W_NONE, W_NONE, W_NONE,                                                \
-         W_X(W_STAMP(1) if (post) { W_VMCNT(26) } else { W_VMCNT(10) } W_STAMP(2) W_RR(rwa, 0)), W_X(W_RR(rwb, 1)), W_X(W_NR(nra, 0)), W_X(W_NR(nrb, 1)), W_NONE, W_NONE, \
+#define W_CHUNK_                                                                                      \
+  W_STEP(0, d1, uc, 1, W_NONE, W_NONE, W_NONE, W_NONE,                                                \
+         W_X(W_STAMP(1) if (POST) { W_VMCNT(26) } else { W_VMCNT(10) } W_STAMP(2) W_RR(rwa, 0)), W_X(W_RR(rwb, 1)), W_X(W_NR(nra, 0)), W_X(W_NR(nrb, 1)), W_NONE, W_NONE, \
          W_X(W_CC(cva, rwa, nra) W_CC(cvb, rwb, nrb)))                                                \
-  W_STEP(ST, 1, ST, 2, W_X(W_CW(cva, 0, STN)), W_X(W_CW(cvb, 1, STN)), W_NONE, W_NONE,                \
+  W_STEP(1, d2, uc, 2, W_X(W_CW(cva, 0)), W_X(W_CW(cvb, 1)), W_NONE, W_NONE,                          \
          W_X(W_RR(rwa, 2)), W_X(W_RR(rwb, 3)), W_X(W_NR(nra, 2)), W_X(W_NR(nrb, 3)), W_NONE, W_NONE,  \
          W_X(W_CC(cva, rwa, nra) W_CC(cvb, rwb, nrb)))                                                \
-  W_STEP(ST, 2, ST, 3, W_X(W_CW(cva, 2, STN)), W_X(W_CW(cvb, 3, STN)), W_NONE, W_NONE,                \
+  W_STEP(2, d3, uc, 3, W_X(W_CW(cva, 2)), W_X(W_CW(cvb, 3)), W_NONE, W_NONE,                          \
          W_X(W_RR(rwa, 4)), W_X(W_RRH), W_X(W_NR(nra, 4)), W_X(W_NR(nrb, 5)), W_NONE, W_NONE,         \
          W_X(W_CC(cva, rwa, nra) W_CCH(nrb)))                                                         \
-  W_STEP(ST, 3, STN, 0, W_X(W_CW(cva, 4, STN)), W_X(W_CWH(STN)), W_NONE,                              \
-         W_STAMP(3) W_XW(if (post == 2) { W_VMCNT(22) } else { W_VMCNT(6) }) W_STAMP(4) W_BARRIER W_STAMP(5),                          \
-         W_XW(W_ISSUE_W(0, STNN, Dwso) W_ISSUE_W(1, STNN, Dwso)), W_XW(W_ISSUE_W(2, STNN, Dwso) W_ISSUE_W(3, STNN, Dwso)), \
+  W_STEP(3, d0n, un, 0, W_X(W_CW(cva, 4)), W_X(W_CWH), W_NONE,                                        \
+         W_STAMP(3) W_XW(if (POST == 2) { W_VMCNT(22) } else { W_VMCNT(6) }) W_STAMP(4) W_BARRIER W_STAMP(5), \
+         W_XW(W_ISSUE_W(0, stnn, Dwso) W_ISSUE_W(1, stnn, Dwso)), W_XW(W_ISSUE_W(2, stnn, Dwso) W_ISSUE_W(3, stnn, Dwso)), \
          W_XL(W_ISSUE_I(0) W_ISSUE_I(1)), W_XL(W_ISSUE_I(2) W_ISSUE_I(3)), W_XL(W_ISSUE_I(4)), W_XL(W_ISSUE_H), W_NONE)
 
   // ---- prologue: raw chunks 0, 1, 2 and the U images of chunks 0, 1 on their way, chunk 0 staged, operands of (chunk 0,
@@ -470,12 +469,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
   W_LATCH                                            // C = chunk 0, D = chunk 1
   W_ADVANCE
   W_VMCNT(0)
-  W_RR(rwa, 0) W_NR(nra, 0) W_CC(cva, rwa, nra) W_CW(cva, 0, 0)
-  W_RR(rwa, 1) W_NR(nra, 1) W_CC(cva, rwa, nra) W_CW(cva, 1, 0)
-  W_RR(rwa, 2) W_NR(nra, 2) W_CC(cva, rwa, nra) W_CW(cva, 2, 0)
-  W_RR(rwa, 3) W_NR(nra, 3) W_CC(cva, rwa, nra) W_CW(cva, 3, 0)
-  W_RR(rwa, 4) W_NR(nra, 4) W_CC(cva, rwa, nra) W_CW(cva, 4, 0)
-  W_RRH W_NR(nrb, 5) W_CCH(nrb) W_CWH(0)
+  cn -= STAGE_B;                                     // (chunk 0 is staged to stage 0; the loop stages chunk g + 1 to the stage after g's)
+  if (hrole) hn -= STAGE_B;
+  W_RR(rwa, 0) W_NR(nra, 0) W_CC(cva, rwa, nra) W_CW(cva, 0)
+  W_RR(rwa, 1) W_NR(nra, 1) W_CC(cva, rwa, nra) W_CW(cva, 1)
+  W_RR(rwa, 2) W_NR(nra, 2) W_CC(cva, rwa, nra) W_CW(cva, 2)
+  W_RR(rwa, 3) W_NR(nra, 3) W_CC(cva, rwa, nra) W_CW(cva, 3)
+  W_RR(rwa, 4) W_NR(nra, 4) W_CC(cva, rwa, nra) W_CW(cva, 4)
+  W_RRH W_NR(nrb, 5) W_CCH(nrb) W_CWH
+  cn += STAGE_B;
+  if (hrole) hn += STAGE_B;
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's reads of raw slot 0 are done: chunk 2 may land there
   W_ISSUE_I(0) W_ISSUE_I(1) W_ISSUE_I(2) W_ISSUE_I(3) W_ISSUE_I(4) W_ISSUE_H
   W_LATCH                                            // C = chunk 1, D = chunk 2
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
   rofs = rofs0 + WRAW_FLOATS * 4;
   rhofs = rhofs0 + WRAW_FLOATS * 4;
   W_BARRIER
-  W_FD(0, 0, 0) W_FD(2, 0, 0) W_FU(0, 0, 0) W_FU(1, 0, 0) W_FU(2, 0, 0)
+  W_FD(0, dbase) W_FD(2, dbase) W_FU(0, uc, 0) W_FU(1, uc, 0) W_FU(2, uc, 0)
   W_TRANSFORM
   wfor<256>([&](auto i) __attribute__((always_inline)) { agpr_zero<decltype(i)::value>(); });
   asm volatile("s_nop 4");
@@ -495,16 +498,22 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
   int post = 0;                                      // iterations since a tile epilogue: 2, 1, then 0
   const unsigned G = (q1 - q0) * (unsigned)nchunk;
   for (unsigned g = 0; g < G; ++g) {
-    // six bodies: the stage rotation (3) x frame masks in the staging arithmetic or not (only the last column tile of an
-    // utterance stages frames that do not exist)
-#define W_CHUNKS                                                                                      \
-    if (ph3 == 0) { W_CHUNK_(0, 1, 2) } else if (ph3 == 1) { W_CHUNK_(1, 2, 0) } else { W_CHUNK_(2, 0, 1) }
+    // six bodies: frame masks in the staging arithmetic or not (only the last column tile of an utterance stages frames that
+    // do not exist) x the distance to the last tile epilogue (the immediates of two waits)
+    const int stnn = ph3 == 0 ? 2 : ph3 - 1;         // stage of chunk g + 2
     if (Cfull) {
       constexpr bool RAG = false;
-      W_CHUNKS
+      if (post == 0) { constexpr int POST = 0; W_CHUNK_ } else if (post == 1) { constexpr int POST = 1; W_CHUNK_ } else { constexpr int POST = 2; W_CHUNK_ }
     } else {
       constexpr bool RAG = true;
-      W_CHUNKS
+      if (post == 0) { constexpr int POST = 0; W_CHUNK_ } else if (post == 1) { constexpr int POST = 1; W_CHUNK_ } else { constexpr int POST = 2; W_CHUNK_ }
+    }
+    {                                                // every stage address moves one stage on (the one after ph3 + 1 for d0n, un, cn, hn)
+      const unsigned dl_n = (ph3 == 1) ? 0u - 2u * STAGE_B : STAGE_B;      // stage n = ph3 + 1 -> ph3 + 2
+      d1 = d0n + STEP_B; d2 = d0n + 2 * STEP_B; d3 = d0n + 3 * STEP_B;
+      uc = un;
+      d0n += dl_n; un += dl_n; cn += dl_n;
+      hn += hrole ? dl_n : 0u;
     }
     if (++kc == nchunk) {
       // ---- tile epilogue: Y = A^T M A per (channel, tile), + bias, ELU, centring, stores, statistics ----
@@ -560,7 +569,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
           // (quad_perm [1,0,3,2]: the neighbour's value; the compiler folds the move into v_cndmask_b32_dpp)
           const float n00 = dpp_get<0xB1>(y00), n01 = dpp_get<0xB1>(y01), n10 = dpp_get<0xB1>(y10), n11 = dpp_get<0xB1>(y11);
           const wf4 o = {ev ? y00 : n10, ev ? y01 : n11, ev ? n00 : y10, ev ? n01 : y11};
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rs_out, vo_x + coff, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rs_out, (DBG & 512) ? 0x80000000u : vo_x + coff, 0, 2);   // non-temporal: read back by the NEXT launch, long after it left the L2
         }
         const float z00 = y00 * m00, z01 = y01 * m01, z10 = y10 * m10, z11 = y11 * m11;
         s1[r] = (z00 + z01) + (z10 + z11);
@@ -607,14 +616,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
   }
 }
 
+// (Cin >= 24: every sample then contributes >= 3 consecutive chunks to a workgroup's stream, which is what the two-parity
+// s_nrm table and the look-back of the DMA waits assume; the network's DenseBlock layers have 24 ... 192 input channels)
 bool conv_wino_ok(const ConvArgs& a) {
-  return a.sf == 1 && a.padf == 1 && !a.tr2 && a.Fin == a.Fout && (a.Cin % WCK) == 0 && a.Cin <= WNRM_MAX && !a.in_oct &&
+  return a.Cin >= 3 * WCK && a.Cout <= 128 && a.sf == 1 && a.padf == 1 && !a.tr2 && a.Fin == a.Fout && (a.Cin % WCK) == 0 && a.Cin <= WNRM_MAX && !a.in_oct &&
          !a.out_oct && a.ww != nullptr;
 }
 
 #ifdef MISONET_EXPERIMENTS
 static int wino_dbg_env() {
-  static const int v = [] { const char* e = getenv("MISONET_WINO_DBG"); return e ? atoi(e) : 0; }();
+  static const int v = exp_env("MISONET_WINO_DBG", 0);
   return v;
 }
 #endif
@@ -624,7 +635,7 @@ hipError_t conv_wino_init() {
                                      (int)WINO_LDS);
 #ifdef MISONET_EXPERIMENTS
 #define W_ATTR(D) if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_f32<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS);
-  W_ATTR(1) W_ATTR(2) W_ATTR(3) W_ATTR(4) W_ATTR(7) W_ATTR(10) W_ATTR(18) W_ATTR(34) W_ATTR(64) W_ATTR(128) W_ATTR(256) W_ATTR(448)
+  W_ATTR(1) W_ATTR(2) W_ATTR(3) W_ATTR(4) W_ATTR(7) W_ATTR(10) W_ATTR(18) W_ATTR(34) W_ATTR(64) W_ATTR(128) W_ATTR(256) W_ATTR(448) W_ATTR(512)
 #undef W_ATTR
 #endif
   return e;
@@ -643,7 +654,7 @@ hipError_t launch_conv_wino(const ConvArgs& a_in, int n_samples, hipStream_t s) 
   const dim3 g(a.xcd ? (unsigned)cus : grid);
 #ifdef MISONET_EXPERIMENTS
   {
-    static const int tl_cin = [] { const char* e = getenv("MISONET_WINO_TIMELINE"); return e ? atoi(e) : 0; }();
+    static const int tl_cin = exp_env("MISONET_WINO_TIMELINE", 0);
     static unsigned long long* tl_dev = nullptr;
     static int tl_done = 0;
     if (tl_cin && a.Cin == tl_cin && a.Fin == 63 && n_samples == 96 && tl_done < 2) {
@@ -664,7 +675,7 @@ hipError_t launch_conv_wino(const ConvArgs& a_in, int n_samples, hipStream_t s) 
   }
   switch (wino_dbg_env()) {
 #define W_CASE(D) case D: hipLaunchKernelGGL(conv3x3_wino_f32<D>, g, dim3(256), WINO_LDS, s, a); return hipGetLastError();
-    W_CASE(1) W_CASE(2) W_CASE(3) W_CASE(4) W_CASE(7) W_CASE(10) W_CASE(18) W_CASE(34) W_CASE(64) W_CASE(128) W_CASE(256) W_CASE(448)
+    W_CASE(1) W_CASE(2) W_CASE(3) W_CASE(4) W_CASE(7) W_CASE(10) W_CASE(18) W_CASE(34) W_CASE(64) W_CASE(128) W_CASE(256) W_CASE(448) W_CASE(512)
 #undef W_CASE
     default: break;
   }

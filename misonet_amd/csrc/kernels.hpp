@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "det_stats.hpp"
 
 namespace mn {
@@ -18,6 +19,15 @@ constexpr int TW = 136;     // staged frames per input row: [t0-4, t0+132) -> 34
 constexpr int FT = 4;       // output rows (frequency bins) per workgroup = waves per workgroup
 constexpr float IN_EPS = 1e-5f;    // nn.InstanceNorm{1,2}d default eps (reference model.py:413,579)
 constexpr float GLN_EPS = 1e-8f;   // reference model.py:6
+
+// Experiment switches (kernel variants for A/B runs, timelines, parts switched off): they exist only in the experiment build
+// (`make exp` -> libmisonet_hip_exp.so, -DMISONET_EXPERIMENTS; tools/gpu_*.sh select it through MISONET_LIB_PATH).  In the
+// product library every switch is its default, a compile-time constant: no environment variable changes what it runs.
+#ifdef MISONET_EXPERIMENTS
+inline int exp_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#else
+constexpr int exp_env(const char*, int dflt) { return dflt; }
+#endif
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 inline int frames_pitch(int T) { return round_up(T, 32); }

@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <atomic>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -84,6 +85,8 @@ struct ProfScope {
     if (hipEventRecord(e1, s) == hipSuccess) pr->recs.push_back({kind, e0, e1});
   }
 };
+
+static int frontend_init();   // STFT / iSTFT tables of the current device (below, with the front-end entry points)
 
 // ---------------------------------------------------------------------------------------------------------------
 struct Tensor {
@@ -489,7 +492,7 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
   if (a.in_oct == 4) { a.wscale = c.wscale; a.descale = 1.f / c.wscale; }
   if (a.w16 || a.in_oct) { a.cop = 32; a.ncg = (c.Cout + 31) / 32; }
   // MISONET_SYNC_DEBUG=1: name every conv launch and wait for it (fault hunting)
-  static const int sync_dbg = [] { const char* e = getenv("MISONET_SYNC_DEBUG"); return e ? atoi(e) : 0; }();
+  static const int sync_dbg = exp_env("MISONET_SYNC_DEBUG", 0);
   struct SyncDbg {
     hipStream_t s; const ConvArgs& a; int on;
     ~SyncDbg() {
@@ -502,7 +505,7 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
   } sync_guard{s, a, sync_dbg};
   // bf16x6 / f16x3 networks: the planar-input first layer in the bf16x6 arithmetic (MISONET_X6_FIRST=0: the exact-f32 kernel
   // of rounds 1-3, for A/B runs)
-  static const int x6first_env = [] { const char* e = getenv("MISONET_X6_FIRST"); return e ? atoi(e) : 1; }();
+  static const int x6first_env = exp_env("MISONET_X6_FIRST", 1);
   if (x6first_env && n->precision >= 3 && !a.in_oct && a.out_oct == 3 && c.w6s_off >= 0 && !a.act) {
     ProfScope ps(s, PK_CONV);
     HIPCHK(launch_conv_x6_first(a, n->w_dev + c.w6s_off, nb, s));
@@ -561,7 +564,7 @@ static int forward_planar(misonet_net* n, const Layout& L, void* ws, hipStream_t
   HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(reinterpret_cast<char*>(ws) + 8), (int)layout_stamp(n, L), 1, s));
   // Optional sample sub-batching of the conv stacks (MISONET_SUBBATCH = samples per pass at F = 127; deeper levels take
   // proportionally more): keeps a level's producer->consumer traffic inside the 256 MiB Infinity Cache.
-  static const int sub_env = [] { const char* e = getenv("MISONET_SUBBATCH"); return e ? atoi(e) : 0; }();
+  static const int sub_env = exp_env("MISONET_SUBBATCH", 0);
   auto run_stack = [&](const std::vector<ConvL>& v) -> int {
     if (sub_env <= 0) {
       for (const ConvL& c : v) { int r = run_conv(n, L, ws, c, s); if (r) return r; }
@@ -604,7 +607,7 @@ static int forward_planar(misonet_net* n, const Layout& L, void* ws, hipStream_t
     float* cur = xa;
     float* nxt = xb;
     // bf16x6 mode: the point-wise convs in the same arithmetic as the 3x3 convs (MISONET_TCN_X6=0: fp32 MFMA, A/B runs)
-    static const int tcn_x6_env = [] { const char* e = getenv("MISONET_TCN_X6"); return e ? atoi(e) : 1; }();
+    static const int tcn_x6_env = exp_env("MISONET_TCN_X6", 1);
     const int tcn_x6 = (n->precision == 3 && tcn_x6_env) ? 1 : 0;
     for (int k = 0; k < 14; ++k) {
       const TcnBlock& tb = n->tcn[k];
@@ -646,7 +649,7 @@ const char* misonet_strerror(int code) {
   }
 }
 const char* misonet_last_error(void) { return g_err; }
-int misonet_version(void) { return 420; }   // 410: misonet_pipeline_create accepts miso3 == NULL (separation-only pipeline); 420: misonet_istft
+int misonet_version(void) { return 430; }   // 410: misonet_pipeline_create accepts miso3 == NULL (separation-only pipeline); 420: misonet_istft; 430: misonet_frontend_init, precision mode 5 (f32w)
 
 int misonet_net_create(const misonet_cfg* cfg, misonet_net** out) {
   if (!cfg || !out) return fail(MISONET_EINVAL, "null argument");
@@ -908,6 +911,7 @@ int misonet_net_commit(misonet_net* n) {
   HIPCHK(conv_bf16_init());
   HIPCHK(conv_bf16_dma_init());
   HIPCHK(conv_bf16x6_init());
+  { int rf = frontend_init(); if (rf) return rf; }     // STFT / iSTFT tables: never allocated inside an asynchronous call
   n->committed = true;
   return MISONET_OK;
 }
@@ -1078,8 +1082,14 @@ int misonet_pit_select(const void* anchor, const void* cand, int B, int S, int T
 // twiddle table + the > 64 KB dynamic-LDS attribute of stft_pack_k, per device (the table lives in the memory of the
 // device that was current when it was first needed)
 static float* g_twid[MAX_DEV] = {};
-static int get_twiddles(const float** out) {
+static float* g_itwid[MAX_DEV] = {};
+static std::mutex g_front_mu;
+// Builds both tables on the CURRENT device (hipMalloc + synchronous copy + kernel attributes).  misonet_net_commit and
+// misonet_pipeline_create call it, so every path that runs a network has them before its first asynchronous call -- a HIP
+// graph may capture misonet_pipeline_run_wav / misonet_istft as the first call of a process.  Idempotent, thread-safe.
+static int frontend_init() {
   const int d = cur_dev();
+  std::lock_guard<std::mutex> lk(g_front_mu);
   if (!g_twid[d]) {
     std::vector<float> tw((size_t)stft_twiddle_count());
     stft_build_twiddles(tw.data());
@@ -1089,13 +1099,6 @@ static int get_twiddles(const float** out) {
     HIPCHK(stft_init());
     g_twid[d] = p;
   }
-  *out = g_twid[d];
-  return MISONET_OK;
-}
-
-static float* g_itwid[MAX_DEV] = {};
-static int get_itwiddles(const float** out) {
-  const int d = cur_dev();
   if (!g_itwid[d]) {
     std::vector<float> tw((size_t)istft_twiddle_count());
     istft_build_twiddles(tw.data());
@@ -1105,6 +1108,21 @@ static int get_itwiddles(const float** out) {
     HIPCHK(istft_init());
     g_itwid[d] = p;
   }
+  return MISONET_OK;
+}
+int misonet_frontend_init(void) { return frontend_init(); }
+
+// the table of the current device; a stand-alone misonet_stft / misonet_istft without any committed network on this device
+// builds it on first use (that one call allocates and synchronises: not inside a stream capture; include/misonet.h)
+static int get_twiddles(const float** out) {
+  const int d = cur_dev();
+  if (!g_twid[d]) { int r = frontend_init(); if (r) return r; }
+  *out = g_twid[d];
+  return MISONET_OK;
+}
+static int get_itwiddles(const float** out) {
+  const int d = cur_dev();
+  if (!g_itwid[d]) { int r = frontend_init(); if (r) return r; }
   *out = g_itwid[d];
   return MISONET_OK;
 }
@@ -1197,6 +1215,7 @@ int misonet_pipeline_create(misonet_net* n1, misonet_net* n3, int num_mic, int n
     return fail(MISONET_EINVAL, "MISO_1 geometry does not match num_mic/num_spk");
   if (n3 && (n3->cfg.in_ch != 2 * (num_mic + 2) || n3->cfg.out_ch != 2))
     return fail(MISONET_EINVAL, "MISO_3 geometry must be in_ch = 2*(num_mic+2), out_ch = 2");
+  { int rf = frontend_init(); if (rf) return rf; }
   misonet_pipeline* p = new misonet_pipeline{n1, n3, num_mic, num_spk, ref_ch, epsi};
   *out = p;
   return MISONET_OK;

@@ -14,6 +14,7 @@ path; ``gather_outputs`` is the optional all_gather of the results (RCCL on GPUs
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import Callable, Dict, List, Optional, Tuple
 
 import numpy as np
@@ -71,9 +72,18 @@ class CapturedPass:
     Enhancer is used with in between (its own cache may drop and re-allocate workspaces freely).  ``replay()`` re-runs the
     pass; new inputs are copied INTO ``mix`` / ``clean`` first (``load``).  Unpacks as ``(graph, out)``."""
 
-    def __init__(self, graph, out, ws, mix, clean, key):
+    def __init__(self, graph, out, ws, mix, clean, key, owner=None):
         self.graph, self.out, self.mix, self.clean = graph, out, mix, clean
         self._ws, self.key = ws, key
+        self._owner = weakref.ref(owner) if owner is not None else None
+
+    def check(self):
+        """Synchronise and raise FloatingPointError if the last replay produced a NaN (the pass's flag word lives in the
+        workspace this object owns, not in the Enhancer's eager workspace)."""
+        enh = self._owner() if self._owner is not None else None
+        if enh is None:
+            raise RuntimeError("the Enhancer this pass was captured from is gone")
+        enh.check(self.key[0], self.key[1], captured=self)
 
     def load(self, mix, clean=None):
         self.mix.copy_(mix)
@@ -113,6 +123,7 @@ class Enhancer:
         _lib.check(_lib.lib().misonet_pipeline_create(model_sep._net, model._net if model is not None else None, self.num_ch,
                                                       self.num_spks, self.ref_ch, float(epsi), C.byref(self._pipe)))
         self._ws: Dict[tuple, torch.Tensor] = {}
+        self._captured = weakref.WeakSet()     # live CapturedPass objects: check(B, T) must not silently look elsewhere
 
     def __del__(self):
         try:
@@ -211,7 +222,9 @@ class Enhancer:
         device tensors (a converted copy would be what the graph reads, not the caller's tensor), and the returned object
         keeps the workspace, the inputs and the result alive -- the Enhancer's own workspace cache may be re-used for other
         shapes / modes meanwhile.  NaN checking is the caller's (``misonet_pipeline_check`` synchronises, so it is not part
-        of the graph): call :meth:`check` when needed."""
+        of the graph): call ``captured.check()`` (or ``enh.check(B, T, captured=captured)``) after a replay -- the flag word
+        lives in the workspace the CapturedPass owns; ``enh.check(B, T)`` without it refuses to answer while a captured pass
+        of that shape is alive (it would read the eager workspace, which a replay never touches)."""
         self._ready()
         for name, x in (("mix", mix), ("clean", clean)):
             if x is None:
@@ -234,11 +247,21 @@ class Enhancer:
         # from now on this workspace belongs to the graph: the cache hands out a fresh one for the same key, so an eager
         # pass between two replays cannot clobber activations a replay is about to read
         del self._ws[key]
-        return CapturedPass(g, out, ws, mix, clean, key)
+        cp = CapturedPass(g, out, ws, mix, clean, key, owner=self)
+        self._captured.add(cp)
+        return cp
 
     def check(self, B: int, T: int, captured: Optional[CapturedPass] = None):
         """Synchronise and raise FloatingPointError if the last pass on the (B, T) workspace produced a NaN
         (``captured``: the workspace of that captured pass instead of the eager one)."""
+        if captured is None:
+            key = self._ws_key(B, T)
+            live = [c for c in self._captured if c.key == key]
+            if live and key not in self._ws:
+                # ADVICE r4: after capture_graph the (B, T) workspace belongs to the graph; a fresh eager workspace always reads
+                # clean, so `g.replay(); enh.check(B, T)` would silently check nothing
+                raise RuntimeError(f"check({B}, {T}): a captured pass owns the workspace of this shape and no eager pass has run "
+                                   "since; call captured.check() / check(B, T, captured=...) for the replay's NaN flag")
         ws = captured._ws if captured is not None else self.workspace(B, T)
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().misonet_pipeline_check(self._pipe, ws.data_ptr(), _lib.stream_ptr(self.device)))
@@ -250,6 +273,8 @@ class Enhancer:
         None.  The STFT front-end runs as a HIP kernel straight into the network's layout; returns what
         :meth:`enhance` returns (T = n_samples // 64 + 1 frames)."""
         self._ready()
+        if self.model is None:
+            raise RuntimeError("this Enhancer was built without MISO_3 (separation only): use separate() / beamform_*()")
         if not isinstance(wav, torch.Tensor) or wav.dim() != 3 or wav.is_complex():
             raise ValueError("wav must be a real 3-D tensor [B, n_samples, M]")
         if wav.device != self.device:
@@ -267,6 +292,8 @@ class Enhancer:
                 raise ValueError("clean_wav must be [B, n_samples, num_spks]")
         L = _lib.lib()
         T = L.misonet_stft_frames(Ls)
+        if T < 2:                              # n_samples < 64: one frame -- the reference's instance norms raise (model.py:89, 413)
+            raise ValueError(f"Expected more than 1 spatial element when training, got T = {T} frame(s) ({Ls} samples)")
         ws = self.workspace(B, T)
         out = torch.empty((B, self.num_spks, T, 129), dtype=torch.complex64, device=self.device)
         bf = torch.empty_like(out) if want_bf else None
@@ -285,7 +312,8 @@ class Enhancer:
 
     def enhance_wav_int16(self, wav: torch.Tensor, clean_wav: Optional[torch.Tensor] = None, check_nan=True) -> torch.Tensor:
         """The reference's unit of work on the device: wav in -> int16 wav out (tester.py:865-867 H2D ... 949-952 iSTFT,
-        x 32767, int16).  wav float32 [B, n_samples, M] (device) -> int16 [B, S, n_samples] (device): HIP STFT front-end,
+        x 32767, int16).  wav float32 [B, n_samples, M] (device) -> int16 [B, S, 64 * (n_samples // 64)] (device; = n_samples
+        when that is a multiple of the hop, as the reference's 4 s chunks are): HIP STFT front-end,
         the fused pipeline, ONE ``istft_k`` launch over the B * S enhanced spectrograms incl. the truncating cast --
         nothing leaves the device and nothing synchronises (with ``check_nan=False``)."""
         return S.istft_int16(self.enhance_wav(wav, clean_wav, check_nan=check_nan))
@@ -299,13 +327,19 @@ class Enhancer:
         batch i - 1's int16 result (copy-out stream) run beside the pipeline of batch i (current stream); ``depth`` device
         input / pinned output slots.  The host only blocks on the result of the OLDEST batch in flight, so the GPU always
         has the next batch queued.  A NaN in batch i raises FloatingPointError when that batch is handed out (the
-        pipeline's flag word travels with the result instead of a synchronising check)."""
+        pipeline's flag word travels with the result instead of a synchronising check).
+
+        Contracts: the compute stream is whatever stream is CURRENT when the generator resumes for a batch
+        (re-read every iteration; the events that protect the slot buffers are recorded on and waited by that stream).  A
+        PINNED input is the direct source of an asynchronous H2D copy: leave it untouched until the result of ITS batch has
+        been yielded (un-pinned inputs are copied into the generator's own staging buffer before ``next()`` returns).  A
+        CUDA-resident input is read on the copy-in stream after the work queued on the stream that was current when it
+        was handed over."""
         import collections
         self._ready()
         dev = self.device
         depth = max(1, int(depth))
         with torch.cuda.device(dev):
-            cur = torch.cuda.current_stream(dev)
             s_in, s_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
             slots = [dict() for _ in range(depth)]
             pending = collections.deque()
@@ -334,6 +368,7 @@ class Enhancer:
                 while len(pending) >= depth:                  # slot i % depth still belongs to batch i - depth
                     yield finish(pending.popleft())
                 sl = slots[i % depth]
+                cur = torch.cuda.current_stream(dev)          # the consumer may have changed streams between two next() calls
                 src_w = staged(sl, "wav", wav_h)
                 src_c = staged(sl, "clean", clean_h) if clean_h is not None else None
                 fresh = False
@@ -343,6 +378,8 @@ class Enhancer:
                 if src_c is not None and (sl.get("clean_d") is None or sl["clean_d"].shape != src_c.shape):
                     sl["clean_d"] = torch.empty(src_c.shape, dtype=torch.float32, device=dev)
                     fresh = True
+                if src_w.is_cuda or (src_c is not None and src_c.is_cuda):
+                    s_in.wait_stream(cur)                     # a device-resident input: after its producer on the current stream
                 if fresh:
                     # a new slot buffer comes out of the CURRENT stream's allocator pool: its block may be one that work
                     # already queued on the current stream still writes (e.g. the previous batch's spectrogram, freed on the
@@ -408,19 +445,20 @@ class Enhancer:
         return m1
 
     def beamform_utterance(self, obs_splits: List[torch.Tensor], clean_splits: List[torch.Tensor], gap: int,
-                           epsi: float = 1e-6, max_batch: int = 16) -> np.ndarray:
+                           epsi: float = 1e-6, max_batch: int = 16, to_host: bool = True):
         """Utterance-wise MVDR of the reference's Tester_Beamforming (tester.py:340-449, ``utterance_flag``) for ONE
         recording: its splits are separated as ONE batch (:meth:`separate`; the reference runs them one by one), all
         (speaker, mic) estimates and the observation go back to the time domain with one batched iSTFT, the splits are
         stitched (last one trimmed by ``gap``), the whole recording is re-analysed by the HIP STFT front-end and ONE MVDR per
         speaker is solved over all its frames (spatial covariances accumulated over the full utterance instead of per 4 s
-        chunk).  obs_splits: list of complex [M,T,F]; clean_splits: list of complex [S,T,F].  Returns int16 [S, n]."""
+        chunk).  obs_splits: list of complex [M,T,F]; clean_splits: list of complex [S,T,F].  Returns int16 [S, n] (an ndarray;
+        ``to_host=False``: the device tensor, nothing synchronises)."""
         from .beamform import Apply_Beamforming
         K = len(obs_splits)
         if K < 1 or len(clean_splits) != K:
             raise ValueError("obs_splits / clean_splits must be non-empty lists of equal length")
-        obs = torch.stack([torch.as_tensor(o) for o in obs_splits]).to(self.device)          # [K,M,T,F]
-        cl = torch.stack([torch.as_tensor(c) for c in clean_splits]).to(self.device)         # [K,S,T,F]
+        obs = torch.stack([torch.as_tensor(o) for o in obs_splits]).to(self.device, non_blocking=True)   # [K,M,T,F]
+        cl = torch.stack([torch.as_tensor(c) for c in clean_splits]).to(self.device, non_blocking=True)  # [K,S,T,F]
         est = torch.cat([self.separate(obs[lo:lo + max_batch], cl[lo:lo + max_batch])          # [K,S,M,T,F], in groups of
                          for lo in range(0, K, max_batch)])                                   # <= max_batch splits (workspace)
         e = S.istft(est)                                                                      # [K,S,M,chunk]
@@ -437,7 +475,8 @@ class Enhancer:
         mix_bf = spec[0].permute(2, 0, 1)[None]                               # [1,F,M,Tt]
         bf = torch.stack([Apply_Beamforming(spec[1 + s].permute(2, 0, 1)[None], mix_bf, epsi)[0]
                           for s in range(self.num_spks)])                     # [S,Tt,F]
-        return S.istft_int16(bf).cpu().numpy()
+        pcm = S.istft_int16(bf)
+        return pcm.cpu().numpy() if to_host else pcm
 
     def beamform_chunks(self, mix: torch.Tensor, clean: Optional[torch.Tensor] = None, epsi: float = 1e-6) -> torch.Tensor:
         """Chunk-wise MVDR (BASELINE configs[2]: MISO1 -> MVDR; the ``utterance_flag = False`` branch of the reference's
@@ -449,6 +488,67 @@ class Enhancer:
         mix_bf = self._check_c64(mix, "mix").permute(0, 3, 1, 2)                              # [B,F,M,T]
         return torch.stack([Apply_Beamforming(est[:, s].permute(0, 3, 1, 2), mix_bf, epsi)
                             for s in range(self.num_spks)], dim=1)                            # [B,S,T,F]
+
+    def enhance_recording(self, wav_observe, wav_clean=None, num_ch_utilize: Optional[int] = None, chunk_size: int = 64000,
+                          max_batch: int = 16, save_path: Optional[str] = None, fs: int = 16000) -> np.ndarray:
+        """Recording in -> enhanced int16 waves out: the reference's loader item AND its tester body as one device-side
+        object (``AudioDataset_Test.__getitem__``, dataloader/data.py:524-597, + ``Tester_Enhance.inference``,
+        tester.py:846-975), without host STFT dicts.
+
+        wav_observe: float32 [L, M_all] (ndarray or CPU tensor, time-major as ``read_wav`` returns it); wav_clean: the
+        clean sources, a sequence of S arrays [L, M_all] (``<name>_0.wav``, ``<name>_1.wav``, data.py:527-528) or None.
+        Steps, each as the reference does it: microphone sub-sampling ``[0:M:M // num_ch_utilize]`` (data.py:544; default:
+        the network's microphone count), 4 s chunks with the last one zero-padded by ``gap`` (data.py:536-595;
+        ``L == chunk_size``, which the reference leaves unhandled, is one chunk), the clean sources at ``ref_ch`` of the
+        sub-sampled array (tester.py:889-890), per chunk STFT -> MISO1 x M -> alignments -> MVDR x S -> MISO3 x S -> iSTFT ->
+        x 32767 -> int16 (HIP kernels end to end, the chunks of the recording as batches of <= ``max_batch`` through
+        :meth:`stream_wav`: H2D of the next batch and D2H of the previous one beside the compute), chunks stitched with the
+        padded tail dropped (tester.py:960-969).  Returns int16 [S, L]; ``save_path`` = "<dir>/<wav_name>" also writes
+        ``<save_path>_{s}.wav`` as 24-bit PCM (tester.py:972-974)."""
+        self._ready()
+        if self.model is None:
+            raise RuntimeError("this Enhancer was built without MISO_3 (separation only): use separate() / beamform_*()")
+        obs = np.asarray(wav_observe, dtype=np.float32)
+        if obs.ndim != 2 or obs.shape[0] <= obs.shape[1]:
+            raise ValueError("wav_observe must be [n_samples, n_mics] with n_samples > n_mics (data.py:510)")
+        L, M_all = obs.shape
+        n_use = self.num_ch if num_ch_utilize is None else int(num_ch_utilize)
+        if n_use < 1 or n_use > M_all:
+            raise ValueError(f"num_ch_utilize must be in [1, {M_all}]")
+        mics = list(range(0, M_all, M_all // n_use))                       # data.py:544: [0:M:M // num_ch_utilize]
+        if len(mics) != self.num_ch:
+            raise ValueError(f"[0:{M_all}:{M_all // n_use}] selects {len(mics)} microphones, the networks take {self.num_ch}")
+        if int(chunk_size) < 2 * S.HOP or int(chunk_size) % S.HOP:
+            raise ValueError(f"chunk_size must be a multiple of the hop ({S.HOP}) and at least two hops")
+        obs = obs[:, mics]
+        cl = None
+        if wav_clean is not None:
+            if len(wav_clean) != self.num_spks:
+                raise ValueError(f"wav_clean must hold {self.num_spks} source recordings")
+            srcs = []
+            for c in wav_clean:
+                c = np.asarray(c, dtype=np.float32)
+                if c.shape != (L, M_all):
+                    raise ValueError("every clean source must have the shape of wav_observe")
+                srcs.append(c[:, mics][:, self.ref_ch])
+            cl = np.stack(srcs, axis=1)                                    # [L, S]
+        pieces, gap = S.split_chunks(obs, int(chunk_size))
+        cpieces = S.split_chunks(cl, int(chunk_size))[0] if cl is not None else None
+        K = len(pieces)
+
+        def batches():
+            for lo in range(0, K, max_batch):
+                w = torch.from_numpy(np.stack(pieces[lo:lo + max_batch]))
+                yield (w, torch.from_numpy(np.stack(cpieces[lo:lo + max_batch]))) if cpieces is not None else w
+
+        pcm = np.concatenate(list(self.stream_wav(batches())), axis=0)     # [K, S, chunk]
+        out = np.stack([S.stitch_int16([pcm[k, s] for k in range(K)], gap) for s in range(self.num_spks)])
+        if save_path is not None:
+            import os
+            os.makedirs(os.path.dirname(os.path.abspath(save_path)), exist_ok=True)
+            for s in range(self.num_spks):
+                S.write_wav_pcm24(f"{save_path}_{s}.wav", out[s], fs)
+        return out
 
     def inference(self, data_loader, saveDir, fs=16000, write=True, max_batch=32):
         """Drop-in for ``Tester_Enhance.inference(data_loader, saveDir)`` (tester.py:846-975): the loader yields

@@ -119,24 +119,61 @@ class Tester_Beamforming(object):
         os.makedirs(saveDir, exist_ok=True)
         results = {}
         dev = self._enh.device
-        for (obs_d, s0_d, s1_d, gap, wav_name) in data_loader:
-            K = len(obs_d)
-            obs = [torch.as_tensor(obs_d[str(k)]).to(dev) for k in range(K)]                        # K x [B,M,T,F]
-            clean = [torch.stack((torch.as_tensor(s0_d[str(k)])[:, self.ref_ch],
-                                  torch.as_tensor(s1_d[str(k)])[:, self.ref_ch]), dim=1).to(dev) for k in range(K)]
-            B = obs[0].shape[0]
-            gaps = [int(gap[b]) if hasattr(gap, "__len__") else int(gap) for b in range(B)]
-            names = [wav_name] * B if isinstance(wav_name, str) else list(wav_name)
-            if self.utterance_flag:
-                wavs = [self._enh.beamform_utterance([o[b] for o in obs], [c[b] for c in clean], gaps[b]) for b in range(B)]
-            else:
-                pcm = torch.stack([S.istft_int16(self._enh.beamform_chunks(obs[k], clean[k])) for k in range(K)])
-                pcm = pcm.cpu().numpy()                                                              # [K,B,S,n]
-                wavs = [np.stack([S.stitch_int16([pcm[k, b, s] for k in range(K)], gaps[b]) for s in range(self.num_spks)])
-                        for b in range(B)]
-            for b in range(B):
-                results[names[b]] = wavs[b]
+
+        def h2d(x):
+            """one asynchronous copy per tensor out of pinned memory instead of a synchronous ``.to(device)`` per split"""
+            x = torch.as_tensor(x)
+            if x.device == dev:
+                return x
+            if x.device.type == "cpu" and not x.is_pinned():
+                x = x.contiguous().pin_memory()
+            return x.to(dev, non_blocking=True)
+
+        def finalize(rec):
+            """the PREVIOUS loader item: wait for its one D2H only, stitch, write -- beside the current item's kernels"""
+            rec["ev"].synchronize()
+            for b, name in enumerate(rec["names"]):
+                if rec["utterance"]:
+                    wav = rec["host"][b].numpy().copy()                                              # [S, n]
+                else:
+                    pcm = rec["host"][0].numpy()                                                     # [K,B,S,n]
+                    wav = np.stack([S.stitch_int16([pcm[k, b, s] for k in range(pcm.shape[0])], rec["gaps"][b])
+                                    for s in range(self.num_spks)])
+                results[name] = wav
                 if write:
                     for s in range(self.num_spks):
-                        S.write_wav_pcm24(os.path.join(saveDir, f"{names[b]}_{s}.wav"), wavs[b][s], self.fs)
+                        S.write_wav_pcm24(os.path.join(saveDir, f"{name}_{s}.wav"), wav[s], self.fs)
+
+        with torch.cuda.device(dev):
+            s_out = torch.cuda.Stream(dev)
+            prev = None
+            for (obs_d, s0_d, s1_d, gap, wav_name) in data_loader:
+                K = len(obs_d)
+                obs = [h2d(obs_d[str(k)]) for k in range(K)]                                         # K x [B,M,T,F]
+                clean = [torch.stack((h2d(torch.as_tensor(s0_d[str(k)])[:, self.ref_ch]),
+                                      h2d(torch.as_tensor(s1_d[str(k)])[:, self.ref_ch])), dim=1) for k in range(K)]
+                B = obs[0].shape[0]
+                gaps = [int(gap[b]) if hasattr(gap, "__len__") else int(gap) for b in range(B)]
+                names = [wav_name] * B if isinstance(wav_name, str) else list(wav_name)
+                if self.utterance_flag:
+                    dev_out = [self._enh.beamform_utterance([o[b] for o in obs], [c[b] for c in clean], gaps[b], to_host=False)
+                               for b in range(B)]                                                    # B x int16 [S, n_b] (device)
+                else:
+                    dev_out = [torch.stack([S.istft_int16(self._enh.beamform_chunks(obs[k], clean[k])) for k in range(K)])]
+                ev_done = torch.cuda.Event()
+                ev_done.record(torch.cuda.current_stream(dev))
+                rec = {"names": names, "gaps": gaps, "utterance": self.utterance_flag,
+                       "host": [torch.empty(t.shape, dtype=torch.int16, pin_memory=True) for t in dev_out]}
+                with torch.cuda.stream(s_out):                   # the item's D2H beside the next item's compute
+                    s_out.wait_event(ev_done)
+                    for h, t in zip(rec["host"], dev_out):
+                        h.copy_(t, non_blocking=True)
+                        t.record_stream(s_out)
+                    rec["ev"] = torch.cuda.Event()
+                    rec["ev"].record(s_out)
+                if prev is not None:
+                    finalize(prev)
+                prev = rec
+            if prev is not None:
+                finalize(prev)
         return results

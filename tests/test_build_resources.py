@@ -22,6 +22,7 @@ HOT = [
     "mn::conv3x3_mfma<1, 2, 0, false>",                                            # f32: stride-2 transposed convs
     "mn::conv3x3_mfma<1, 0, 0, true>", "mn::conv3x3_mfma<1, 0, 3, true>",          # first layer (12 input channels)
     "mn::conv3x3_mfma<1, 0, 3, false>",                                            # (first layer on the f32 kernel: MISONET_X6_FIRST=0)
+    "mn::conv3x3_wino_f32<0>",                                                     # f32w: the DenseBlock convs (Winograd F(2x2, 3x3))
     "mn::conv3x3_x6_first<3>", "mn::conv3x3_x6_first<4>",                          # first layer in bf16x6 (round 4)
     "mn::conv3x3_bf16x6<0, 8, false, 4, false, false, 0>", "mn::conv3x3_bf16x6<0, 8, false, 3, false, false, 0>",    # 38 % + 28 % of the bf16x6 step
     "mn::conv3x3_bf16x6<0, 8, false, 4, false, true, 0>",                             # F <= 31 layers (two statistic units)
@@ -98,3 +99,31 @@ def test_headline_kernel_occupancy(table):
     assert table["mn::conv3x3_mfma<1, 0, 0, false>"]["occupancy"] >= 3
     # the first-layer kernel is latency-bound: three workgroups per CU (<= 168 VGPRs, 52 KB of LDS each)
     assert table["mn::conv3x3_x6_first<3>"]["vgprs"] <= 168 and table["mn::conv3x3_x6_first<3>"]["occupancy"] >= 3
+
+
+def test_wino_kernel_register_files(table):
+    """conv3x3_wino_f32 keeps its 256 accumulators in FIXED AGPRs behind inline asm (conv_wino.hip): one wave per SIMD, all 256
+    AGPRs declared, nothing spilled -- a spilled VGPR could be parked in an AGPR between two asm statements -- and, in the
+    ISA, no v_accvgpr_* instruction that the compiler generated itself (every one sits inside an asm block)."""
+    r = table["mn::conv3x3_wino_f32<0>"]
+    assert r["agprs"] == 256 and r["vgprs"] <= 256 and r["occupancy"] == 1, r
+    assert r["vgpr_spill"] == 0 and r["scratch"] == 0, r
+    csrc = os.path.join(ROOT, "misonet_amd", "csrc")
+    asm = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-S",
+                          "--cuda-device-only", "conv_wino.hip", "-o", "-"], cwd=csrc, check=True, capture_output=True,
+                         text=True).stdout.splitlines()
+    inside, own, total, dma = False, 0, 0, 0
+    for ln in asm:
+        t = ln.strip()
+        if t.startswith(";;#ASMSTART"):
+            inside = True
+        elif t.startswith(";;#ASMEND"):
+            inside = False
+        elif t.startswith("v_accvgpr"):
+            total += 1
+            own += inside
+        elif " lds" in t and t.startswith("buffer_load"):
+            dma += 1
+    assert total == own and total >= 512, (total, own)          # 256 reads in the epilogue + 2 x 256 zeroing writes
+    assert dma >= 6 * 10, dma                                   # six chunk bodies x (4 U-image + 6 raw-input pieces)
+    assert not any("flat_load" in ln or "flat_store" in ln or "scratch_" in ln for ln in asm)

@@ -33,6 +33,18 @@ def test_bench_single_process_line():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    # a clean run carries no MISONET_* variable and runs the product library
+    assert d["env_overrides"] == {} and d["library"] == "libmisonet_hip.so", (d["env_overrides"], d["library"])
+
+
+def test_bench_line_records_environment():
+    env = dict(os.environ, MISONET_BENCH_NOCHECK="1", MISONET_X6_SLOTS="8")
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-alt", "--no-profile"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert d["env_overrides"] == {"MISONET_BENCH_NOCHECK": "1", "MISONET_X6_SLOTS": "8"}
+    assert d["value"] > 100.0            # ... and the product library ignored the kernel switch (it would run 64 of 256 CUs)
 
 
 def test_bench_mode_floors():
@@ -40,16 +52,24 @@ def test_bench_mode_floors():
     shipped an f32 mode that had silently lost 36 % (88 -> 56 utt/s, frac 0.68 -> 0.43) to register spills.  Boxes differ
     by a few per cent in sustained clocks (round 4: bf16x6 0.429 ... 0.450 on seven boxes, f32 0.675 ... 0.684); the floors sit
     5 % under the slowest box seen (a false alarm on a slow box costs more than a missed 5 %) -- a spilled kernel loses 30 %."""
-    r = subprocess.run([sys.executable, "bench.py", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--alt", "f32",
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--alt", "f32,f32w",
                         "--no-pmc"],
                        cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
+    # the gate is the roofline FRACTION (what a spilled kernel loses); absolute utt/s floors only where a box's class is known
+    # (MISONET_TEST_ABS_FLOORS=1: the pool's MI355X boxes; ADVICE r4: a throttled or shared box must not fail the suite)
+    absf = bool(os.environ.get("MISONET_TEST_ABS_FLOORS"))
     assert d["dtype"] == "bf16x6" and d["roofline"]["frac"] >= 0.405, d["roofline"]
-    assert d["value"] >= 133.0, d["value"]
+    assert not absf or d["value"] >= 133.0, d["value"]
     f32 = [a for a in d["alt_precision"] if a["dtype"] == "f32"]
     assert f32 and f32[0]["roofline"]["frac"] >= 0.62, f32
-    assert f32[0]["value"] >= 80.0, f32[0]["value"]
+    assert not absf or f32[0]["value"] >= 80.0, f32[0]["value"]
+    # f32w: the same matrix cores with 16 / 36 of the products on the DenseBlock layers; round 5: 128-130 utt/s, 1.47 x f32
+    w = [a for a in d["alt_precision"] if a["dtype"] == "f32w"]
+    assert w and w[0]["roofline"]["frac"] >= 0.42 and w[0]["value"] >= 1.35 * f32[0]["value"], w
+    assert d["roofline"]["exact_f32"]["frac"] == f32[0]["roofline"]["frac"]
+    assert d["roofline"]["winograd_f32"]["value"] == w[0]["value"]
 
 
 def test_bench_live_pmc_fields():
@@ -95,6 +115,28 @@ def test_bench_two_ranks_on_one_device():
     assert gp["from_rank"] == 1 and gp["utterance"] == 4 and gp["ok"] and gp["rel_l2_magnitudes_vs_oracle"] < 1e-3
     # whole-job aggregate: 2 ranks x 4 utterances x 2 steps over the max-over-ranks time
     assert abs(d["value"] - 2 * 4 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-2
+
+
+def test_bench_eight_ranks_on_one_device():
+    """BASELINE configs[4]'s launch shape without its hardware: 8 real ranks, rendezvous on 127.0.0.1,
+    barrier, MAX-reduce of the elapsed time, the result gather verified from rank 7 -- all ranks on device 0 over gloo, 2
+    utterances each (the block split of dataloader/data.py:558-595's independent utterances: rank r owns [2 r, 2 r + 2))."""
+    env = dict(os.environ, MISONET_BENCH_ONE_DEVICE="1", MISONET_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "bench.py", "--gpus", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-alt",
+           "--batch", "2", "--verify-gather"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and d["scaling"] == "weak" and d["backend"] == "gloo"
+    assert d["per_rank_utterances"] == [[2 * r_, 2 * r_ + 2] for r_ in range(8)]
+    assert "configs[4]" in d["config"]["workload"] and d["config"]["global_batch"] == 16
+    assert len(d["per_rank_utt_per_s"]) == 8 and min(d["per_rank_utt_per_s"]) > 0
+    gp = d["gather_parity"]
+    assert d["gathered_shape"] == [16, 2, 1001, 129]
+    assert gp["from_rank"] == 7 and gp["utterance"] == 14 and gp["ok"] and gp["rel_l2_magnitudes_vs_oracle"] < 1e-3
+    assert abs(d["value"] - 8 * 2 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-2
 
 
 def test_bench_two_ranks_rccl():

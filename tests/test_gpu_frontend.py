@@ -177,3 +177,56 @@ def test_hip_istft_vs_scipy(N, T):
     y4 = S.istft(zd.reshape(1, N, T, 129))
     assert tuple(y4.shape) == (1, N, (T - 1) * 64) and torch.equal(y4[0], y)
     assert np.abs(S.istft(torch.from_numpy(z)).numpy() - want).max() / np.abs(want).max() <= 2e-6
+
+
+def test_enhance_recording_loader_side_drop_in(nets, sd1, sd3, tmp_path):
+    """recording in -> ``<wav>_{0,1}.wav`` out with no host STFT dicts (AudioDataset_Test.__getitem__,
+    dataloader/data.py:524-597, + Tester_Enhance.inference, tester.py:846-975, as ONE device-side call).
+
+    (a) golden G13 = the REAL reference harness on one 4 s recording at 8 kHz: the waves within 1 LSB;
+    (b) a 2.4-chunk recording of 12 microphones with ``num_ch_utilize = 6`` (every second microphone, data.py:544) against the
+        oracle run chunk by chunk on the sub-sampled, zero-padded pieces: <= 1 LSB, padded tail trimmed, files byte-exact."""
+    import misonet_amd as mz
+    from misonet_amd import stft as S
+    from misonet_amd.weights import synthetic_utterance
+    from oracle import pipeline_oracle
+    from conftest import golden
+    m1, m3 = nets
+    enh = mz.Enhancer(m1, m3, num_spks=2, ref_ch=0)
+    # ---- (a) ----
+    g = golden("g13_pipeline_8k_T501.npz")
+    T = int(g["frames"])
+    obs, s0, s1 = synthetic_utterance(int(g["utt"]), (T - 1) * 64)
+    wav = enh.enhance_recording(obs, (s0, s1), chunk_size=(T - 1) * 64, fs=8000)
+    assert wav.shape == (2, (T - 1) * 64) and wav.dtype == np.int16
+    for s in range(2):
+        d = np.abs(wav[s][::8].astype(np.int32) - g["wav_dec8"][s].astype(np.int32))
+        assert d.max() <= 1, d.max()
+    # ---- (b) ----
+    chunk = 47 * 64
+    L = 2 * chunk + 1200
+    r = np.random.default_rng(21)
+    src = [(0.05 * r.standard_normal((L, 12))).astype(np.float32) for _ in range(2)]
+    rec = src[0] + src[1]
+    got = enh.enhance_recording(rec, src, num_ch_utilize=6, chunk_size=chunk, max_batch=2, save_path=str(tmp_path / "rec7"),
+                                fs=16000)
+    assert got.shape == (2, L)
+    mics = list(range(0, 12, 2))
+    want = []
+    for k in range(3):
+        def piece(x):
+            p = x[k * chunk:(k + 1) * chunk][:, mics]
+            return np.pad(p, ((0, chunk - p.shape[0]), (0, 0)))
+        mix = pipeline_oracle.stft_chunk(piece(rec))
+        clean = np.stack([pipeline_oracle.stft_chunk(piece(src[0]))[0], pipeline_oracle.stft_chunk(piece(src[1]))[0]])
+        o = pipeline_oracle.enhance_utterance(mix, clean, sd1, sd3, ref_ch=0)["out"]
+        want.append(np.stack([pipeline_oracle.istft_int16(o[s]) for s in range(2)]))
+    want = np.concatenate(want, axis=1)[:, :L]
+    d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    print(f"[recording] 3 chunks, 12 -> 6 mics: max |diff| = {d.max()} LSB, {float((d > 0).mean()):.2e} of the samples differ")
+    assert d.max() <= 1
+    for s in range(2):
+        v, fs = S.read_wav_pcm24(str(tmp_path / f"rec7_{s}.wav"))
+        assert fs == 16000 and np.array_equal(v[:, 0], got[s].astype(np.int32) << 8)
+    with pytest.raises(ValueError):
+        enh.enhance_recording(rec, src, num_ch_utilize=4, chunk_size=chunk)      # [0:12:3] = 4 microphones, the networks take 6

@@ -1,7 +1,9 @@
 """GPU tests of the round-2 boundary work: PIT over S! permutations (S = 3 golden from the real reference), no limit on
 the number of frames in the TCN, device handling of the host-side mirror, Enhancer re-commit."""
 import numpy as np
+import os
 import pytest
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 import torch
 
 from conftest import golden, rel_l2
@@ -10,7 +12,7 @@ from test_gpu_parity import _assert_parity, _utt_inputs, _need_gpu
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x6"])
+@pytest.mark.parametrize("mode", ["f32", "f32w", "bf16x6"])
 def test_three_speaker_separation_vs_reference_golden(sd3, mode):
     """Enhancer.separate with num_spks = 3 against G10 (Tester_Enhance.MISO1_Inference of the real reference)."""
     _need_gpu()
@@ -111,7 +113,7 @@ def test_device_handling(sd1, sd3):
     assert y0.shape == (1, 2, 8, 129)
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x6", "f16x3", "bf16x3"])
+@pytest.mark.parametrize("mode", ["f32", "f32w", "bf16x6", "f16x3", "bf16x3"])
 def test_one_chunk_layers(mode):
     """8-channel dense-block growth: layers of ONE and TWO 8-channel K-chunks (the bf16x6 producers fold the set-up of the
     coming tile into fewer iterations there) and output groups of 8 channels."""
@@ -131,7 +133,7 @@ def test_one_chunk_layers(mode):
     _assert_parity(y, ref, f"[{mode}] 8-channel growth (en={en})")
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x6", "f16x3", "bf16x3"])
+@pytest.mark.parametrize("mode", ["f32", "f32w", "bf16x6", "f16x3", "bf16x3"])
 def test_non_default_geometry(mode):
     """A geometry other than config/NN_BSS.yml's: 4 microphones, 3 speakers, bottleneck channels
     (16,24,40,32,48,64,128) -- output groups of 16/24/40/48 channels, 2-chunk layers, a dense block that grows to 200
@@ -200,7 +202,69 @@ def test_hip_graph_capture_replays_identical_bits(sd1, sd3):
     torch.cuda.synchronize()
     assert torch.equal(out, eager_b)
     enh.check(1, 64, captured=cap)          # the graph owns its workspace (tests/test_gpu_wavpath.py: lifetime)
-    enh.check(1, 64)                        # a fresh eager workspace reads clean
+    cap.check()                             # ... the same through the captured pass itself
+    # `g.replay(); enh.check(B, T)` used to allocate a fresh eager workspace and report "clean" whatever the replay
+    # did; while a captured pass of that shape is alive and no eager pass has run, the ambiguous call refuses to answer
+    with pytest.raises(RuntimeError, match="captured"):
+        enh.check(1, 64)
+    # a NaN fed through the graph is seen by the captured pass's check, not lost
+    bad = torch.from_numpy(b[0][None]).clone()
+    bad[0, 0, 3, 5] = complex(float("nan"), 0.0)
+    mix.copy_(bad)
+    g.replay()
+    with pytest.raises(FloatingPointError):
+        cap.check()
+    # after an eager pass of that shape its own workspace exists again and check(B, T) means it
+    mix.copy_(torch.from_numpy(b[0][None]))
+    enh.enhance(mix, clean)
+    enh.check(1, 64)
+
+
+def test_wav_entry_guards_and_cold_graph_capture(sd1, sd3):
+    """enhance_wav has the guards of enhance (one frame raises the reference's ValueError, a separation-only
+    Enhancer raises instead of failing inside the library); and -- VERDICT r4 item 3 -- a HIP graph can capture
+    enhance_wav_int16 as the FIRST call of a fresh process: the STFT / iSTFT tables are built by misonet_net_commit /
+    misonet_pipeline_create, never inside an asynchronous call."""
+    _need_gpu()
+    import subprocess
+    import sys
+    import misonet_amd as mz
+    from misonet_amd import weights as W
+    m1 = mz.MISO_1(2, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN").cuda(0)
+    m1.load_state_dict(sd1)
+    m3 = mz.MISO_3(1, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN").cuda(0)
+    m3.load_state_dict(sd3)
+    enh = mz.Enhancer(m1.eval(), m3.eval(), num_spks=2, ref_ch=0)
+    with pytest.raises(ValueError, match="more than 1 spatial element"):
+        enh.enhance_wav(torch.zeros((1, 40, 6), device="cuda"))
+    sep = mz.Enhancer(m1, None, num_spks=2, ref_ch=0)
+    with pytest.raises(RuntimeError, match="without MISO_3"):
+        sep.enhance_wav(torch.zeros((1, 64 * 20, 6), device="cuda"))
+    code = """
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import misonet_amd as mz
+from misonet_amd import weights as W
+m1 = mz.MISO_1(2, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN").cuda(0); m1.load_state_dict(W.make_state_dict(W.miso1_spec(), 0))
+m3 = mz.MISO_3(1, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN").cuda(0); m3.load_state_dict(W.make_state_dict(W.miso3_spec(), 1))
+enh = mz.Enhancer(m1.eval(), m3.eval(), num_spks=2, ref_ch=0)
+obs, s0, s1 = W.synthetic_utterance(5, 64 * 47)
+wav = torch.from_numpy(obs[None]).cuda()
+ws = enh.workspace(1, 48)                       # allocation only: no kernel of the wav path has run in this process
+s = torch.cuda.Stream()
+s.wait_stream(torch.cuda.current_stream())
+g = torch.cuda.CUDAGraph()
+with torch.cuda.stream(s):
+    with torch.cuda.graph(g, stream=s):         # the FIRST wav-path call of the process, inside a capture
+        pcm = enh.enhance_wav_int16(wav, None, check_nan=False)
+g.replay(); torch.cuda.synchronize()
+a = pcm.cpu().numpy().copy()
+b = enh.enhance_wav_int16(wav, None).cpu().numpy()
+assert np.array_equal(a, b) and np.abs(a).max() > 0, (np.abs(a).max(), np.abs(a.astype(int) - b).max())
+print("COLD_CAPTURE_OK")
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "COLD_CAPTURE_OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
 
 
 @pytest.mark.parametrize("scale", [1e-4, 1e-2, 1e3])

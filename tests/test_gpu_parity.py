@@ -20,10 +20,11 @@ def _need_gpu():
         pytest.skip("no GPU")
 
 
-# Every test that takes ``nets`` (here and in test_gpu_frontend.py) runs twice: in the exact-f32 MFMA mode and in the
-# bench's headline arithmetic "bf16x6" (fp32-faithful split-bf16; also the library default) -- same goldens, same
-# tolerances, int16 waves still within 1 LSB.
-HEADLINE_MODES = ("f32", "bf16x6")
+# Every test that takes ``nets`` (here and in test_gpu_frontend.py) runs three times: in the exact-f32 MFMA mode, in "f32w" (the
+# same matrix cores with the DenseBlock convs in Winograd F(2x2, 3x3) form, conv_wino.hip) and in the bench's headline
+# arithmetic "bf16x6" (fp32-faithful split-bf16; also the library default) -- same goldens, same tolerances, int16 waves
+# still within 1 LSB.
+HEADLINE_MODES = ("f32", "f32w", "bf16x6")
 
 
 @pytest.fixture(scope="module", params=HEADLINE_MODES)
@@ -146,14 +147,20 @@ def test_miso1_shortest_inputs_vs_oracle(nets, sd1, T, request):
         with miso_oracle.precision(torch.float64):
             truth = miso_oracle.miso1_forward(torch.from_numpy(x[b:b + 1]).to(torch.complex128), sd1, t64).numpy()
             tcn_local = miso_oracle.tcn_forward(torch.from_numpy(enc6[b:b + 1]), sd1).numpy()
+        # yardstick for the TCN's conditioning ON THIS INPUT: the float32 oracle (stock torch CPU) against the float64 one.  Whether
+        # a channel's two or three frames nearly coincide somewhere in the 28 instance norms depends on the last bits of the
+        # encoder output, i.e. on the arithmetic mode that produced it (round 5: the f32w encoder output hit such a channel in
+        # sample 1 at T = 2 -- float32 evaluations of the TCN then differ by 0.1-0.3 from float64 whoever computes them)
+        tcn_f32 = miso_oracle.tcn_forward(torch.from_numpy(enc6[b:b + 1].astype(np.float32)), sd1).numpy()
+        e32 = rel_l2(tcn_f32, tcn_local)
         e5 = rel_l2(enc5[b:b + 1], t64["enc5"].numpy())
         e6 = rel_l2(enc6[b:b + 1], t64["enc6"].numpy()[..., 0])
         et = rel_l2(tcn[b:b + 1], tcn_local)
         eo = mag_parity(y[b:b + 1], truth)[0]
         print(f"[parity] miso1 T={T} sample {b}: encoder 5 {e5:.2e}, encoder 6 {e6:.2e} vs float64 truth; TCN on its own input "
-              f"{et:.2e}; end result {eo:.2e} (ill-conditioned, not bounded at 1e-3)")
+              f"{et:.2e} (float32 oracle on the same input: {e32:.2e}); end result {eo:.2e} (ill-conditioned, not bounded at 1e-3)")
         assert e5 <= 2e-5 and e6 <= 1e-3, (T, b, e5, e6)      # encoder 6 is one instance norm over T values per channel
-        assert et <= 5e-3, (T, b, et)
+        assert et <= max(5e-3, 10.0 * e32), (T, b, et, e32)
         assert eo <= 0.2, (T, b, eo)
 
 

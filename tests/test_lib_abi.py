@@ -33,6 +33,21 @@ def test_header_symbols_exported():
     assert lib.misonet_strerror(-4).decode() == "workspace too small"
 
 
+def test_product_library_has_no_experiment_switches():
+    """the kernel-variant / ablation / timeline switches (MISONET_X6_*, MISONET_DMA*, MISONET_SUBBATCH, ...)
+    exist only in the experiment build (`make exp`, -DMISONET_EXPERIMENTS).  The product library reads NO environment
+    variable: not one MISONET_* name (nor a getenv import) is in the binary, and its ABI version says 430."""
+    L = _lib()
+    assert os.path.realpath(L.LIB_PATH).endswith("libmisonet_hip.so")
+    blob = open(L.LIB_PATH, "rb").read()
+    names = set(re.findall(rb"MISONET_[A-Z0-9_]{3,}", blob))
+    assert not names, names
+    assert b"getenv" not in blob
+    assert L.lib().misonet_version() >= 430
+    src = "".join(open(f).read() for f in __import__("glob").glob(os.path.join(ROOT, "misonet_amd", "csrc", "*.hip")))
+    assert "getenv" not in src                                   # every switch goes through kernels.hpp exp_env()
+
+
 def _make(in_ch=12, out_ch=4, en=(24, 32, 32, 32, 32, 64, 128), de=(128, 64, 32, 32, 32, 32, 24), nf=129, tcn_norm=0):
     L = _lib()
     cfg = L.Cfg(in_ch, out_ch, (C.c_int * 7)(*en), (C.c_int * 7)(*de), nf, tcn_norm)
@@ -141,6 +156,7 @@ def test_precision_switch_host_side():
     lib = L.lib()
     assert lib.misonet_net_get_precision(h) == 3                 # bf16x6 (fp32-faithful, the bench's mode) by default
     assert lib.misonet_net_set_precision(h, 1) == 0 and lib.misonet_net_get_precision(h) == 1
+    assert lib.misonet_net_set_precision(h, 5) == 0 and lib.misonet_net_get_precision(h) == 5   # f32w
     assert lib.misonet_net_set_precision(h, 7) == L.EINVAL
     lib.misonet_net_destroy(h)
     import misonet_amd as mz
