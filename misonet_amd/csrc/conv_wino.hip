@@ -587,8 +587,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
           W_DSW(red_a + (unsigned)((wave * 32 + co_l) * 2) * 4u, x2, 4)
         }
         W_BARRIER
-        if (tid < 64) {
-          const int co_l = tid >> 1, which = tid & 1;
+        if (lane < 16) {                       // 16 of the 64 (channel, statistic) pairs per wave: no wave carries the whole tail
+          const int pr = wave * 16 + lane;
+          const int co_l = pr >> 1, which = pr & 1;
           const int co = cbase + co_l;
           if (co < a.Cout) {
             float tot = 0.f;
