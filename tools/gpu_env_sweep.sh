@@ -1,5 +1,8 @@
 #!/bin/bash
 # usage: gpu_env_sweep.sh PREC "ENV1" "ENV2" ...   (each ENV is a space-free VAR=VAL, or "none")
+# the kernel switches this script sets exist only in the EXPERIMENT build of the library (make -C misonet_amd/csrc exp)
+export MISONET_LIB_PATH=${MISONET_LIB_PATH:-${GRAFT_REPO_ROOT:-/root/repo}/misonet_amd/libmisonet_hip_exp.so}
+[ -f "$MISONET_LIB_PATH" ] || { echo "missing $MISONET_LIB_PATH: run make -C misonet_amd/csrc exp" >&2; exit 1; }
 PREC=$1; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R

@@ -3,6 +3,9 @@
 # 128 / 64 active CUs): a kernel bound by its own pipeline loses throughput in proportion to the CUs taken away and keeps its
 # clock; a power-limited one gets part of it back as clock.  Per setting: utt/s, conv TF/s, the PMC clock and matrix-pipe busy
 # fraction of the same run (bench.py --pmc).   usage: gpu_slots_power.sh TAG      (table: profiles/r04_slots_power.txt)
+# the kernel switches this script sets exist only in the EXPERIMENT build of the library (make -C misonet_amd/csrc exp)
+export MISONET_LIB_PATH=${MISONET_LIB_PATH:-${GRAFT_REPO_ROOT:-/root/repo}/misonet_amd/libmisonet_hip_exp.so}
+[ -f "$MISONET_LIB_PATH" ] || { echo "missing $MISONET_LIB_PATH: run make -C misonet_amd/csrc exp" >&2; exit 1; }
 TAG=${1:-slots}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/${TAG}_slots_power.txt
