@@ -51,6 +51,7 @@ ALGO_BYTES_PER_UTT = 6.23e9     # 8 forwards x 0.776 GB +
 MODES = {
     "f32":     ("conv3x3_mfma", 0, True, 24),            # v_mfma_f32_32x32x2_f32: exact f32, bitwise an fmaf chain
     "f32w":    ("conv3x3_wino_f32", 0, True, 24),        # f32 MFMA, DenseBlock convs in Winograd F(2x2, 3x3) form (conv_wino.hip)
+    "bf16x6w": ("conv3x3_wino_x6", 6, True, 24),         # bf16x6 arithmetic, DenseBlock convs in Winograd F(2x2, 3x3) form (conv_wino6.hip)
     "bf16x6":  ("conv3x3_bf16x6", 6, True, 24),          # operands split EXACTLY into 3 bf16 pieces, 6 leading terms
     "f16x3":   ("conv3x3_bf16x3_dma2<F16>", 3, False, 22),   # 2 fp16 pieces (22 bits, "3xTF32"), 3 terms: measured at the
                                                          # f32 mode's error level, but the operands are rounded

@@ -41,6 +41,7 @@ struct ConvArgs {
   const float* w;           // packed [ncg][nchunk][9][CK][COP]
   const float* bias;        // [ncg*COP]
   const unsigned short* w16; // bf16x3 path: packed [ncg][nchunk16][hi|lo][9][2][COP][8] bf16, or nullptr
+  const void* ww6;          // bf16x6w path (conv_wino6.hip): the same weights as three bf16 pieces, [cg32][K-step of 16][xi][nu][piece][lane][8], or nullptr
   const float* ww;          // f32w path (conv_wino.hip): Winograd-domain weights U = G g G^T, [cg32][chunk of 8][pos / 4][ci][32 co][pos % 4], or nullptr
   long long in_bstride;     // floats per sample of the input buffer
   long long out_bstride;
@@ -115,6 +116,9 @@ hipError_t conv_init();                      // dynamic-LDS attributes
 bool conv_wino_ok(const ConvArgs& a);
 hipError_t launch_conv_wino(const ConvArgs& a, int n_samples, hipStream_t s);
 hipError_t conv_wino_init();
+bool conv_wino6_ok(const ConvArgs& a);
+hipError_t launch_conv_wino6(const ConvArgs& a, int n_samples, hipStream_t s);
+hipError_t conv_wino6_init();
 hipError_t launch_conv_bf16(const ConvArgs& a, int n_samples, hipStream_t s);   // conv_bf16.hip (needs a.w16)
 hipError_t conv_bf16_init();
 hipError_t launch_conv_bf16_dma(const ConvArgs& a, int n_samples, hipStream_t s);   // conv_bf16_dma.hip (oct input)

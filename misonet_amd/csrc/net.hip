@@ -114,6 +114,7 @@ struct ConvL {
   long long wf6_off = 0;            // offset (floats) of the float32 weights [cg][chunk of 8][tap][32][8] (conv_wprep6_k source)
   long long w6s_off = -1;           // first layer only: offset (floats) of the SHARED 3-part bf16 image [chunk][864 units]
   long long ww_off = -1;            // stride-1 same-padded layers: offset (floats) of the Winograd-domain weights (conv_wino.hip)
+  long long ww6_off = -1;           // the same in three bf16 pieces (conv_wino6.hip)
   float wscale = 1.f;               // f16x3: power of two that brings max |W| of the layer to [32, 64)
 };
 
@@ -161,7 +162,7 @@ struct misonet_net {
                                  // dense-block convs in Winograd F(2x2, 3x3) form ("f32w": planar float32 layout like mode 0)
 };
 // the planar-float32 modes: every activation buffer is float32 [c][f][Tp], instance norm applied while staging
-static inline bool planar_f32(const misonet_net* n) { return n->precision == 0 || n->precision == 5; }
+static inline bool planar_f32(const misonet_net* n) { return n->precision == 0 || n->precision == 5 || n->precision == 6; }
 
 static int find_tensor(const misonet_net* n, const std::string& name) {
   for (size_t i = 0; i < n->tensors.size(); ++i)
@@ -337,7 +338,7 @@ static long long align_up(long long x, long long a) { return (x + a - 1) / a * a
 // and the TCN stay planar float32, and so do the F <= 3 bottleneck buffers except in bf16x6.  Returns the ConvArgs::in_oct /
 // out_oct code.
 static inline int buf_oct(const misonet_net* n, int b) {
-  if (n->precision < 2 || n->precision == 5) return 0;
+  if (n->precision < 2 || n->precision >= 5) return 0;
   const bool o = (b >= B_E0 && b <= B_E4) || (b >= B_D2 && b <= B_D6) || (b >= B_X2 && b <= B_X6);
   // bf16x6 also keeps the F <= 3 bottleneck buffers D0 / D1 in its layout (the TCN reads / writes it at its two ends), so
   // that encoder 6 and decoders 0-1 run on the persistent kernel instead of the one-row-per-wave f32 kernel
@@ -465,6 +466,7 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
   a.bias = n->w_dev + c.b_off;
   a.w16 = !planar_f32(n) ? reinterpret_cast<const unsigned short*>(n->w_dev + c.w16_off) : nullptr;
   a.ww = (n->precision == 5 && c.ww_off >= 0) ? n->w_dev + c.ww_off : nullptr;
+  a.ww6 = (n->precision == 6 && c.ww6_off >= 0) ? n->w_dev + c.ww6_off : nullptr;
   a.in_bstride = bstride(n, L, c.in_buf);
   a.out_bstride = bstride(n, L, c.out_buf);
   a.in_sstride = n->bufs[c.in_buf].C;
@@ -541,6 +543,7 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
     ProfScope ps(s, PK_CONV);
     if (a.w16) HIPCHK(launch_conv_bf16(a, nb, s));
     else if (a.ww && conv_wino_ok(a)) HIPCHK(launch_conv_wino(a, nb, s));
+    else if (a.ww6 && conv_wino6_ok(a)) HIPCHK(launch_conv_wino6(a, nb, s));
     else HIPCHK(launch_conv(a, nb, s));
   }
   return MISONET_OK;
@@ -649,7 +652,7 @@ const char* misonet_strerror(int code) {
   }
 }
 const char* misonet_last_error(void) { return g_err; }
-int misonet_version(void) { return 430; }   // 410: misonet_pipeline_create accepts miso3 == NULL (separation-only pipeline); 420: misonet_istft; 430: misonet_frontend_init, precision mode 5 (f32w)
+int misonet_version(void) { return 440; }   // 410: misonet_pipeline_create accepts miso3 == NULL (separation-only pipeline); 420: misonet_istft; 430: misonet_frontend_init, precision mode 5 (f32w); 440: precision mode 6 (bf16x6w)
 
 int misonet_net_create(const misonet_cfg* cfg, misonet_net** out) {
   if (!cfg || !out) return fail(MISONET_EINVAL, "null argument");
@@ -843,6 +846,41 @@ static void pack_conv_wino(const misonet_net* n, const ConvL& c, std::vector<flo
         }
 }
 
+// ... and in the three-piece bf16 form of the bf16x6w mode (conv_wino6.hip): per (cg of 32 co, K-step of 16 ci) four QUARTERS
+// (position rows xi), each [nu][piece h | m | l][lane = co + 32 * (ci / 8 % 2)][8 bf16 = channels 8 * (ci / 8 % 2) .. + 7]: one
+// lane's MFMA A operand is 16 consecutive bytes.  U in double, rounded once to float32, then split exactly at fixed bit
+// positions (top 8 / next 8 / last 8 significant bits).  No sign flips (the kernel's transform is the plain B^T d B).
+static void pack_conv_wino6(const misonet_net* n, const ConvL& c, std::vector<float>& arena) {
+  if (c.ww6_off < 0) return;
+  const std::vector<float>& W = n->tensors[c.wt].host;
+  static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+  const int nk = (c.Cin + 15) / 16, ncg = (c.Cout + 31) / 32;
+  unsigned short* img = reinterpret_cast<unsigned short*>(arena.data() + c.ww6_off);
+  auto top16 = [](float x) { unsigned u; memcpy(&u, &x, 4); return (unsigned short)(u >> 16); };
+  for (int cg = 0; cg < ncg; ++cg)
+    for (int kk = 0; kk < nk; ++kk)
+      for (int pos = 0; pos < 16; ++pos)
+        for (int col = 0; col < 32; ++col)
+          for (int cil = 0; cil < 16; ++cil) {
+            const int ci = kk * 16 + cil, co = cg * 32 + col, xi = pos >> 2, nu = pos & 3;
+            double u = 0.0;
+            if (co < c.Cout && ci < c.Cin)
+              for (int kt = 0; kt < 3; ++kt)
+                for (int kf = 0; kf < 3; ++kf)
+                  u += G[xi][kf] * G[nu][kt] * (double)W[(((long long)co * c.Cin + ci) * 3 + kt) * 3 + kf];
+            const float v = (float)u;
+            unsigned vb; memcpy(&vb, &v, 4);
+            unsigned hb = vb & 0xffff0000u, wb = vb & 0xffffff00u;
+            float h, w; memcpy(&h, &hb, 4); memcpy(&w, &wb, 4);
+            const float m = w - h, l = v - w;
+            const int lane = col + 32 * (cil >> 3), j = cil & 7;
+            const long long q = (((long long)cg * nk + kk) * 4 + xi) * (3 * 4 * 64 * 8);
+            img[q + ((long long)(nu * 3 + 0) * 64 + lane) * 8 + j] = top16(h);
+            img[q + ((long long)(nu * 3 + 1) * 64 + lane) * 8 + j] = top16(m);
+            img[q + ((long long)(nu * 3 + 2) * 64 + lane) * 8 + j] = top16(l);
+          }
+}
+
 int misonet_net_commit(misonet_net* n) {
   if (!n) return fail(MISONET_EINVAL, "null argument");
   for (const Tensor& t : n->tensors)
@@ -863,6 +901,8 @@ int misonet_net_commit(misonet_net* n) {
       // the DenseBlock convs (stride 1, same padding, Cin a multiple of 8): Winograd-domain image for the f32w mode
       if (!c.transposed && c.sf == 1 && c.padf == 1 && c.Cin % 8 == 0 && c.Cin <= 256)
         c.ww_off = take((long long)((c.Cout + 31) / 32) * (c.Cin / 8) * 16 * 8 * 32);
+      if (!c.transposed && c.sf == 1 && c.padf == 1 && c.Cin % 8 == 0 && c.Cin >= 24 && c.Cin <= 256)
+        c.ww6_off = take((long long)((c.Cout + 31) / 32) * ((c.Cin + 15) / 16) * (16 * 3 * 64 * 16 / 4));
     }
   };
   place(n->enc);
@@ -878,8 +918,8 @@ int misonet_net_commit(misonet_net* n) {
       tb.h[h].o_nsh = take(128);
     }
   std::vector<float> arena((size_t)off, 0.f);
-  for (ConvL& c : n->enc) { pack_conv(n, c, arena); pack_conv_bf16(n, c, arena); pack_conv_wf6(n, c, arena); pack_conv_w6s(n, c, arena); pack_conv_wino(n, c, arena); }
-  for (ConvL& c : n->dec) { pack_conv(n, c, arena); pack_conv_bf16(n, c, arena); pack_conv_wf6(n, c, arena); pack_conv_wino(n, c, arena); }
+  for (ConvL& c : n->enc) { pack_conv(n, c, arena); pack_conv_bf16(n, c, arena); pack_conv_wf6(n, c, arena); pack_conv_w6s(n, c, arena); pack_conv_wino(n, c, arena); pack_conv_wino6(n, c, arena); }
+  for (ConvL& c : n->dec) { pack_conv(n, c, arena); pack_conv_bf16(n, c, arena); pack_conv_wf6(n, c, arena); pack_conv_wino(n, c, arena); pack_conv_wino6(n, c, arena); }
   for (const TcnBlock& tb : n->tcn)
     for (int h = 0; h < 2; ++h) {
       const TcnHalf& H = tb.h[h];
@@ -908,6 +948,7 @@ int misonet_net_commit(misonet_net* n) {
   HIPCHK(hipMemcpy(n->w_dev, arena.data(), arena.size() * sizeof(float), hipMemcpyHostToDevice));
   HIPCHK(conv_init());
   HIPCHK(conv_wino_init());
+  HIPCHK(conv_wino6_init());
   HIPCHK(conv_bf16_init());
   HIPCHK(conv_bf16_dma_init());
   HIPCHK(conv_bf16x6_init());
@@ -918,9 +959,9 @@ int misonet_net_commit(misonet_net* n) {
 
 int misonet_net_set_precision(misonet_net* n, int mode) {
   if (!n) return fail(MISONET_EINVAL, "null argument");
-  if (mode < 0 || mode > 5)
+  if (mode < 0 || mode > 6)
     return fail(MISONET_EINVAL, "precision mode must be 0 (f32), 1 (bf16x3, planar), 2 (bf16x3, DMA dataflow), 3 (bf16x6), 4 (f16x3) or "
-                                "5 (f32w: f32 with Winograd dense-block convs)");
+                                "5 (f32w: f32 with Winograd dense-block convs) or 6 (bf16x6w: the same convs in bf16x6 arithmetic)");
   n->precision = mode;
   return MISONET_OK;
 }

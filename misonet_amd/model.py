@@ -95,7 +95,7 @@ class _Trunk:
         self.training = False
         return self
 
-    PRECISIONS = {"f32": 0, "bf16x3p": 1, "bf16x3": 2, "bf16x6": 3, "f16x3": 4, "f32w": 5}
+    PRECISIONS = {"f32": 0, "bf16x3p": 1, "bf16x3": 2, "bf16x6": 3, "f16x3": 4, "f32w": 5, "bf16x6w": 6}
 
     def set_precision(self, mode: str):
         """Arithmetic of the 3x3 convolutions: "bf16x6" (the default; fp32-faithful: both operands split EXACTLY into

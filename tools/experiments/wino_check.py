@@ -31,7 +31,8 @@ x = torch.from_numpy(g["x"])
 taps = {}
 y_ref = miso_oracle.miso1_forward(x, sd1, taps).numpy()
 names = ["enc0_conv"] + [f"enc{b}" for b in range(7)] + ["tcn_out"] + [f"dec{b}" for b in range(7)]
-for mode in ("f32", "f32w"):
+MODES = tuple(os.environ.get("WINO_CHECK_MODES", "f32,f32w").split(","))
+for mode in MODES:
     m = net1(mode)
     m.keep_activations(True)
     y = m(x.cuda()).cpu().numpy()
