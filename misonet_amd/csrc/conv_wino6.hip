@@ -22,7 +22,7 @@
 //
 // PERSISTENT: one workgroup per CU walks its XCD's tile list (conv_wino.hip); the K-steps of all its tiles form one stream.
 // LDS: raw input double buffer, [16 channels][10 rows][68] fp32 per K-step (column c = frame t0 - 1 + c; columns 0-63 by
-// LDS-DMA, 64-65 through registers), a ring of five U QUARTERS (the three pieces of the four positions of one position row:
+// LDS-DMA row by row, 64-65 by two DMA instructions into a side array and an LDS -> LDS move), a ring of five U QUARTERS (the three pieces of the four positions of one position row:
 // 12 KB; a whole K-step of U is 48 KB and two of them do not fit beside the input), the norm tables.  One workgroup barrier
 // per position row: it publishes the next row's U quarter (and, in row 2, the next K-step's input) and frees the quarter
 // before; behind it the wave queues the quarter of the same row of the next K-step (and, in row 3, the input two K-steps
@@ -54,7 +54,8 @@ constexpr unsigned XNRM_B = XU_B + XNQ * XQ_B;
 constexpr unsigned XZERO_B = XNRM_B + 2u * XNRM_MAX * 8u;
 constexpr unsigned XRED_B = XZERO_B + XNRM_MAX * 8u;
 constexpr unsigned XBIAS_B = XRED_B + 4u * 64u * 4u;
-constexpr size_t WINO6_LDS = XBIAS_B + 128 * 4;
+constexpr unsigned XHALO_B = XBIAS_B + 128u * 4u;           // [wave][column 64 | 65][64 lanes] words: the two halo columns as the DMA leaves them
+constexpr size_t WINO6_LDS = XHALO_B + 4 * 2 * 64 * 4;
 static_assert(WINO6_LDS <= 160 * 1024, "one workgroup per CU: at most 160 KB of LDS");
 
 template <int P>
@@ -128,7 +129,7 @@ __device__ __forceinline__ void x6_fetch_u(XPipe& p, int buf, unsigned uq) {
 }
 
 // DBG (timing experiments, -DMISONET_EXPERIMENTS + MISONET_WINO6_DBG): 1 = no preparation of the next row (wrong results),
-// 2 = no epilogue, 4 = no DMA
+// 2 = no epilogue, 4 = no DMA, 8 = no waits and barriers in the row loop
 template <int DBG>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_x6(const ConvArgs a) {
   extern __shared__ __align__(16) float smem[];
@@ -213,27 +214,27 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_x6(const ConvArgs a) {
   // 64-frame row (columns 0-63 = frames t0 - 1 .. t0 + 62) per instruction; rows and frames outside the image read a word
   // that exists (the zero norm entry / the frame mask removes it; the padding may hold anything).  Columns 64, 65 (frames
   // t0 + 63, t0 + 64) go through two registers per lane < 40 and are written to LDS in front of the publishing barrier.
-  unsigned hv0 = 0, hv1 = 0, hla = 0;
-  auto issue_raw = [&](const Cur& c, int slot) __attribute__((always_inline)) {
+  unsigned hla = 0;
+  // part 0..3: the ten rows of the wave's channel `part`; part 4: the two register loads of columns 64, 65
+  auto issue_raw = [&](const Cur& c, int slot, auto part_) __attribute__((always_inline)) {
+    constexpr int part = decltype(part_)::value;
     if (DBG & 4) return;
     const __amdgpu_buffer_rsrc_t rs = rsrc_of(c);
-    int fr = c.t0 - 1 + lane;
-    fr = fr < 0 ? 0 : (fr >= Tp ? Tp - 1 : fr);
-    const unsigned dvo = (unsigned)fr * 4u;
-    const unsigned dst0 = XRAW_B + (unsigned)slot * XSLOT_B + (unsigned)(4 * wave) * (XNR * XRW * 4u);
-#pragma unroll
-    for (int cc = 0; cc < 4; ++cc) {
-      int ch = c.kk * XCK + 4 * wave + cc;
+    if constexpr (part < 4) {
+      int fr = c.t0 - 1 + lane;
+      fr = fr < 0 ? 0 : (fr >= Tp ? Tp - 1 : fr);
+      const unsigned dvo = (unsigned)fr * 4u;
+      const unsigned dst0 = XRAW_B + (unsigned)slot * XSLOT_B + (unsigned)(4 * wave + part) * (XNR * XRW * 4u);
+      int ch = c.kk * XCK + 4 * wave + part;
       ch = ch < Cin ? ch : Cin - 1;
 #pragma unroll
       for (int r = 0; r < XNR; ++r) {
         int f = c.f0 - 1 + r;
         f = f < 0 ? 0 : (f >= F ? F - 1 : f);
         const unsigned so = (unsigned)ch * plane_b + (unsigned)f * (unsigned)Tp * 4u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, MN_XLDS(smem_c + dst0 + (unsigned)(cc * XNR + r) * (XRW * 4u)), 4, dvo, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, MN_XLDS(smem_c + dst0 + (unsigned)r * (XRW * 4u)), 4, dvo, so, 0, 0);
       }
-    }
-    {
+    } else {
       const int l = lane < 40 ? lane : 39;
       const int cc = l / XNR, r = l - cc * XNR;
       int ch = c.kk * XCK + 4 * wave + cc;
@@ -243,16 +244,25 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_x6(const ConvArgs a) {
       int f1 = c.t0 + 63, f2 = c.t0 + 64;
       f1 = f1 >= Tp ? Tp - 1 : f1; f2 = f2 >= Tp ? Tp - 1 : f2;
       const unsigned ro = (unsigned)ch * plane_b + (unsigned)f * (unsigned)Tp * 4u;
-      hv0 = __builtin_amdgcn_raw_buffer_load_b32(rs, ro + (unsigned)f1 * 4u, 0, 0);
-      hv1 = __builtin_amdgcn_raw_buffer_load_b32(rs, ro + (unsigned)f2 * 4u, 0, 0);
+      // lane l < 40 <-> (channel l / 10, row l % 10) of the wave's 40 rows: a DMA instruction writes 64 CONSECUTIVE words, so the
+      // two columns land in a side array and are moved into their rows (LDS -> LDS, write_halo) in front of the publishing barrier
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, MN_XLDS(smem_c + XHALO_B + (unsigned)wave * 512u), 4, ro + (unsigned)f1 * 4u, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, MN_XLDS(smem_c + XHALO_B + (unsigned)wave * 512u + 256u), 4, ro + (unsigned)f2 * 4u, 0, 0, 0);
       hla = lds0 + XRAW_B + (unsigned)slot * XSLOT_B + (unsigned)((4 * wave + cc) * XNR + r) * (XRW * 4u) + 64u * 4u;
     }
   };
+  auto issue_raw_all = [&](const Cur& c, int slot) __attribute__((always_inline)) {
+    wfor<5>([&](auto pp) __attribute__((always_inline)) { issue_raw(c, slot, pp); });
+  };
+  // (asm: a C++ LDS access would make the compiler wait for every DMA in flight)
+  const unsigned hsrc = lds0 + XHALO_B + (unsigned)wave * 512u + (unsigned)lane * 4u;
   auto write_halo = [&]() __attribute__((always_inline)) {
     if (DBG & 4) return;
+    unsigned h0, h1;
+    asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:256\n\ts_waitcnt lgkmcnt(0)" : "=&v"(h0), "=&v"(h1) : "v"(hsrc) : "memory");
     if (lane < 40) {
-      asm volatile("ds_write_b32 %0, %1" ::"v"(hla), "v"(hv0) : "memory");
-      asm volatile("ds_write_b32 %0, %1 offset:4" ::"v"(hla), "v"(hv1) : "memory");
+      asm volatile("ds_write_b32 %0, %1" ::"v"(hla), "v"(h0) : "memory");
+      asm volatile("ds_write_b32 %0, %1 offset:4" ::"v"(hla), "v"(h1) : "memory");
     }
   };
   // U quarter (position row xi) of the K-step of cursor c -> ring slot rq
@@ -299,14 +309,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_x6(const ConvArgs a) {
   L = D;
   const bool l_new = advance(L);
   __syncthreads();                                   // s_zero, s_nrm of C (and D) visible
-  issue_raw(C, 0);
+  issue_raw_all(C, 0);
   X_VMCNT0
   write_halo();
-  issue_raw(D, 1);
+  issue_raw_all(D, 1);
   issue_u(C, 0, 0); issue_u(C, 1, 1); issue_u(C, 2, 2); issue_u(C, 3, 3);
   X_VMCNT0
   // (slot 1's columns 64, 65 are written in front of the barrier of row 2 of the first K-step, like every later one's)
-  unsigned hv0_d = hv0, hv1_d = hv1, hla_d = hla;   // D's halo words wait in registers
   X_BARRIER
   if (l_new) fill_nrm(L);                            // (two samples in flight: C's and L's; D's is one of them)
 
@@ -363,14 +372,22 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_x6(const ConvArgs a) {
       }                                                                                                                   \
     }                                                                                                                     \
     if constexpr (S == 11) {                                                                                              \
-      /* everything this wave has queued has landed; publish; then queue the same row's quarter of K-step g + 1 into the  \
-         ring slot of the row before this one, and (row 3) the input of K-step g + 2 into the slot K-step g has emptied */ \
-      X_VMCNT0                                                                                                            \
-      if ((XI) == 2) { hv0 = hv0_d; hv1 = hv1_d; hla = hla_d; write_halo(); }                                             \
+      /* VMEM queue of a wave, in issue order, per K-step g: [row 0] U(g+1,0) x3  [row 1] U(g+1,1) x3  [row 2] U(g+1,2) x3   \
+         [row 3] U(g+1,3) x3, input(g+2) x42.  The barrier of row xi publishes the quarter of row xi + 1 (queued one K-step  \
+         ago) and, in row 2, the input of K-step g + 1: what may still be in flight behind them is 48 / 48 / 6 / 6          \
+         instructions (a tile epilogue's stores, queued in front of row 0, only make rows 0 and 1 wait longer).  Then the   \
+         quarter of this row of K-step g + 1 goes into the ring slot of the row before this one */                          \
+      if (!(DBG & 8)) {                                                                                                   \
+      if constexpr ((XI) < 2) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");                                           \
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                               \
+      if constexpr ((XI) == 2) write_halo();                                                                              \
       X_BARRIER                                                                                                           \
+      }                                                                                                                   \
       issue_u(D, (XI), uq_cur == 0 ? XNQ - 1 : uq_cur - 1);                                                               \
-      if ((XI) == 3) { issue_raw(L, (int)(g & 1u)); hv0_d = hv0; hv1_d = hv1; hla_d = hla; }                              \
     }                                                                                                                     \
+    /* row 3: the input of K-step g + 2 into the slot K-step g has emptied, spread over five slots */                     \
+    if constexpr ((XI) == 3 && S >= 12 && S <= 20 && (S & 1) == 0)                                                        \
+      issue_raw(L, (int)(g & 1u), std::integral_constant<int, (S - 12) / 2>{});                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                                    \
   });
 
@@ -475,8 +492,22 @@ bool conv_wino6_ok(const ConvArgs& a) {
          !a.out_oct && a.ww6 != nullptr;
 }
 
+#ifdef MISONET_EXPERIMENTS
+static int wino6_dbg_env() {
+  static const int v = exp_env("MISONET_WINO6_DBG", 0);
+  return v;
+}
+#define X6_DBGS(M) M(1) M(2) M(4) M(8) M(12) M(13) M(14) M(15) M(3)
+#endif
+
 hipError_t conv_wino6_init() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_x6<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO6_LDS);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_x6<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO6_LDS);
+#ifdef MISONET_EXPERIMENTS
+#define X_ATTR(D) if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_x6<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO6_LDS);
+  X6_DBGS(X_ATTR)
+#undef X_ATTR
+#endif
+  return e;
 }
 
 hipError_t launch_conv_wino6(const ConvArgs& a_in, int n_samples, hipStream_t s) {
@@ -490,6 +521,14 @@ hipError_t launch_conv_wino6(const ConvArgs& a_in, int n_samples, hipStream_t s)
   const long long tiles = (long long)n_samples * a.ntx * a.nty * a.ncg;
   const unsigned grid = (unsigned)(tiles < cus ? tiles : cus);
   const dim3 g(a.xcd ? (unsigned)cus : grid);
+#ifdef MISONET_EXPERIMENTS
+  switch (wino6_dbg_env()) {
+#define X_CASE(D) case D: hipLaunchKernelGGL(conv3x3_wino_x6<D>, g, dim3(256), WINO6_LDS, s, a); return hipGetLastError();
+    X6_DBGS(X_CASE)
+#undef X_CASE
+    default: break;
+  }
+#endif
   hipLaunchKernelGGL(conv3x3_wino_x6<0>, g, dim3(256), WINO6_LDS, s, a);
   return hipGetLastError();
 }
