@@ -129,7 +129,7 @@ __device__ __forceinline__ void x6_fetch_u(XPipe& p, int buf, unsigned uq) {
 }
 
 // DBG (timing experiments, -DMISONET_EXPERIMENTS + MISONET_WINO6_DBG): 1 = no preparation of the next row (wrong results),
-// 2 = no epilogue, 4 = no DMA, 8 = no waits and barriers in the row loop
+// 2 = no epilogue, 4 = no DMA, 8 = no waits and barriers in the row loop, 16 / 32 = no input / weight DMA
 template <int DBG>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_x6(const ConvArgs a) {
   extern __shared__ __align__(16) float smem[];
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_x6(const ConvArgs a) {
   // part 0..3: the ten rows of the wave's channel `part`; part 4: the two register loads of columns 64, 65
   auto issue_raw = [&](const Cur& c, int slot, auto part_) __attribute__((always_inline)) {
     constexpr int part = decltype(part_)::value;
-    if (DBG & 4) return;
+    if (DBG & (4 | 16)) return;
     const __amdgpu_buffer_rsrc_t rs = rsrc_of(c);
     if constexpr (part < 4) {
       int fr = c.t0 - 1 + lane;
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_x6(const ConvArgs a) {
   // (asm: a C++ LDS access would make the compiler wait for every DMA in flight)
   const unsigned hsrc = lds0 + XHALO_B + (unsigned)wave * 512u + (unsigned)lane * 4u;
   auto write_halo = [&]() __attribute__((always_inline)) {
-    if (DBG & 4) return;
+    if (DBG & (4 | 16)) return;
     unsigned h0, h1;
     asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:256\n\ts_waitcnt lgkmcnt(0)" : "=&v"(h0), "=&v"(h1) : "v"(hsrc) : "memory");
     if (lane < 40) {
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_x6(const ConvArgs a) {
   };
   // U quarter (position row xi) of the K-step of cursor c -> ring slot rq
   auto issue_u = [&](const Cur& c, int xi, int rq) __attribute__((always_inline)) {
-    if (DBG & 4) return;
+    if (DBG & (4 | 32)) return;
     const unsigned so = (unsigned)((c.cg * nk + c.kk) * 4 + xi) * XQ_B;
     const unsigned dst = XU_B + (unsigned)rq * XQ_B + (unsigned)wave * 3072u;
     // (the instruction offset moves BOTH addresses: LDS address = M0 + offset + lane * 16)
@@ -497,7 +497,7 @@ static int wino6_dbg_env() {
   static const int v = exp_env("MISONET_WINO6_DBG", 0);
   return v;
 }
-#define X6_DBGS(M) M(1) M(2) M(4) M(8) M(12) M(13) M(14) M(15) M(3)
+#define X6_DBGS(M) M(1) M(2) M(4) M(8) M(12) M(13) M(14) M(15) M(3) M(16) M(32) M(24) M(40)
 #endif
 
 hipError_t conv_wino6_init() {

@@ -113,7 +113,7 @@ def test_device_handling(sd1, sd3):
     assert y0.shape == (1, 2, 8, 129)
 
 
-@pytest.mark.parametrize("mode", ["f32", "f32w", "bf16x6", "f16x3", "bf16x3"])
+@pytest.mark.parametrize("mode", ["f32", "f32w", "bf16x6", "bf16x6w", "f16x3", "bf16x3"])
 def test_one_chunk_layers(mode):
     """8-channel dense-block growth: layers of ONE and TWO 8-channel K-chunks (the bf16x6 producers fold the set-up of the
     coming tile into fewer iterations there) and output groups of 8 channels."""
@@ -133,7 +133,7 @@ def test_one_chunk_layers(mode):
     _assert_parity(y, ref, f"[{mode}] 8-channel growth (en={en})")
 
 
-@pytest.mark.parametrize("mode", ["f32", "f32w", "bf16x6", "f16x3", "bf16x3"])
+@pytest.mark.parametrize("mode", ["f32", "f32w", "bf16x6", "bf16x6w", "f16x3", "bf16x3"])
 def test_non_default_geometry(mode):
     """A geometry other than config/NN_BSS.yml's: 4 microphones, 3 speakers, bottleneck channels
     (16,24,40,32,48,64,128) -- output groups of 16/24/40/48 channels, 2-chunk layers, a dense block that grows to 200
@@ -420,3 +420,37 @@ def test_norm_type_pipeline_mixed(sd3):
     e = min(rel_l2(got, y_ref), rel_l2(got[::-1], y_ref))          # (the clean alignment may swap the speakers)
     assert e < 1e-3, e
     assert torch.isfinite(torch.view_as_real(out)).all()
+
+
+def test_bf16x6w_mode_goldens_ragged_shapes_batch_invariance(sd1, sd3):
+    """bf16x6w (conv_wino6.hip: the DenseBlock convs in Winograd F(2x2,3x3) form, bf16x6 arithmetic): reference goldens G1 / G3,
+    ragged batched shapes against the oracle (row tiles of 7 / 15 / 31 / 63 / 127 rows, column tiles that end inside a tile, T
+    below one tile), bit-exact batch invariance, and the float32-faithful accuracy class (within 3 x of the exact-f32 mode's
+    distance to the float64 oracle)."""
+    _need_gpu()
+    import misonet_amd as mz
+    from misonet_amd import weights as W
+    from oracle import miso_oracle
+    m = mz.MISO_1(2, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN").cuda(0)
+    m.load_state_dict(sd1)
+    m.eval().set_precision("bf16x6w")
+    for name in ("g1_miso1_T32.npz", "g1_miso1_T96.npz"):
+        g = golden(name)
+        _assert_parity(m(torch.from_numpy(g["x"]).cuda()).cpu().numpy(), g["y"], f"[bf16x6w] {name}")
+    for B, T in [(3, 40), (2, 130), (1, 5), (2, 257)]:
+        r = np.random.default_rng(B * 1000 + T)
+        x = (r.standard_normal((B, 6, T, 129)) + 1j * r.standard_normal((B, 6, T, 129))).astype(np.complex64)
+        x[1:] *= 3.0
+        y = m(torch.from_numpy(x).cuda()).cpu().numpy()
+        ref = np.concatenate([miso_oracle.miso1_forward(torch.from_numpy(x[b:b + 1]), sd1).numpy() for b in range(B)])
+        _assert_parity(y, ref, f"[bf16x6w] B={B} T={T}")
+        y1 = np.concatenate([m(torch.from_numpy(x[b:b + 1]).cuda()).cpu().numpy() for b in range(B)])
+        assert np.array_equal(y, y1), f"bf16x6w: batch of {B} differs from its utterances one by one (T={T})"
+    g96 = golden("g1_miso1_T96.npz")
+    with miso_oracle.precision(torch.float64):
+        y64 = miso_oracle.miso1_forward(torch.from_numpy(g96["x"]), sd1).numpy()
+    err = {}
+    for mode in ("f32", "bf16x6w"):
+        m.set_precision(mode)
+        err[mode] = rel_l2(np.abs(m(torch.from_numpy(g96["x"]).cuda()).cpu().numpy()), np.abs(y64))
+    assert err["bf16x6w"] <= 3.0 * err["f32"] + 2e-6, err

@@ -157,6 +157,7 @@ def test_precision_switch_host_side():
     assert lib.misonet_net_get_precision(h) == 3                 # bf16x6 (fp32-faithful, the bench's mode) by default
     assert lib.misonet_net_set_precision(h, 1) == 0 and lib.misonet_net_get_precision(h) == 1
     assert lib.misonet_net_set_precision(h, 5) == 0 and lib.misonet_net_get_precision(h) == 5   # f32w
+    assert lib.misonet_net_set_precision(h, 6) == 0 and lib.misonet_net_get_precision(h) == 6   # bf16x6w
     assert lib.misonet_net_set_precision(h, 7) == L.EINVAL
     lib.misonet_net_destroy(h)
     import misonet_amd as mz

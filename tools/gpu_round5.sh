@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-5 measurement bundle: the default bench line (timed), kernel stats + per-layer reports for bf16x6 / f32w / f32.
+# round-5 measurement bundle: the default bench line (timed), kernel stats + per-layer reports for bf16x6 / f32w / f32 / bf16x6w.
 # usage: gpu_round5.sh TAG
 TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -10,5 +10,6 @@ python -c "import time,sys; print('bench wall: %.1f s' % (time.time() - float(sy
 bash tools/gpu_layers.sh $TAG bf16x6 | tail -2
 bash tools/gpu_layers.sh ${TAG}_f32w f32w | tail -2
 bash tools/gpu_layers.sh ${TAG}_f32 f32 | tail -2
+bash tools/gpu_layers.sh ${TAG}_bf16x6w bf16x6w | tail -2
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=8 > gpurun_out/${TAG}_gpu_tests.log 2>&1; tail -14 gpurun_out/${TAG}_gpu_tests.log

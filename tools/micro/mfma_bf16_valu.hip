@@ -9,7 +9,7 @@
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int P, int MODE> __device__ __forceinline__ void mf(s16x8 a, s16x8 b) {
-  if (MODE == 1) asm volatile("v_mfma_f32_32x32x16_bf16 a[%0:%1], %2, %3, a[%0:%1]" ::"n"(16 * (P % 6)), "n"(16 * (P % 6) + 15), "v"(a), "v"(b) : "a95");
+  if (MODE == 1 || MODE == 3) asm volatile("v_mfma_f32_32x32x16_bf16 a[%0:%1], %2, %3, a[%0:%1]" ::"n"(16 * (P % 6)), "n"(16 * (P % 6) + 15), "v"(a), "v"(b) : "a95");
   else asm volatile("v_mfma_f32_32x32x16_bf16 a[%0:%1], %2, %3, a[%0:%1]" ::"n"(16 * P), "n"(16 * P + 15), "v"(a), "v"(b) : "a255");
 }
 template <int KIND, int N> __device__ __forceinline__ void fill(float (&x)[16], unsigned (&u)[6]) {
@@ -25,7 +25,7 @@ template <int KIND, int N> __device__ __forceinline__ void fill(float (&x)[16], 
     if (KIND == 8) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(x[i % 16]) : "v"(x[(i + 5) % 16]));
     if (KIND == 9) asm volatile("v_and_b32 %0, 0xffff0000, %0" : "+v"(x[i % 16]));
     if (KIND == 10) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x[i % 16]) : "v"(x[(i + 5) % 16]));
-    if (KIND == 11) asm volatile("v_dot2_f32_bf16 %0, %1, %2, %0" : "+v"(x[i % 16]) : "v"(x[(i + 5) % 16]), "v"(0xbf80u));
+    if (KIND == 11) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(*reinterpret_cast<f32x2*>(&x[2 * (i % 8)])) : "v"(*reinterpret_cast<f32x2*>(&x[2 * ((i + 3) % 8)])));
     if (KIND == 12) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x[i % 16]) : "v"(x[(i + 5) % 16]));
     if (KIND == 14) {   // dot2-based exact split of the pair x[2j], x[2j+1]: 7 instructions
       const int j = i % 8;
@@ -56,15 +56,32 @@ template <int KIND, int N> __device__ __forceinline__ void fill(float (&x)[16], 
   }
 }
 template <int KIND, int N, int MODE>   // MODE 0: MFMA + fillers; 2: fillers only; 1: 2 waves per SIMD, both do MFMA + fillers (128 AGPRs each)
-__global__ __launch_bounds__(MODE == 1 ? 512 : 256, 1) void k(float* out, unsigned long long* cyc, int slot) {
+__global__ __launch_bounds__((MODE == 1 || MODE == 3) ? 512 : 256, 1) void k(float* out, unsigned long long* cyc, int slot) {
   float x[16]; unsigned u[6] = {0, 0, 0, 0, 0, 0};
   for (int i = 0; i < 16; ++i) x[i] = (float)(threadIdx.x + i) * 1e-3f;
   s16x8 a, b;
   for (int i = 0; i < 8; ++i) { a[i] = (short)(0x3f80 + i); b[i] = (short)(0x3f00 + threadIdx.x % 7); }
   const unsigned long long t0 = __builtin_readcyclecounter();
+  if (MODE == 3) {
+    // two waves per SIMD, waves 0-3 MFMAs only, waves 4-7 fillers only (the warp-specialised shape of conv_bf16x6.hip): ONE branch
+    if (threadIdx.x < 256) {
+#pragma unroll 1
+      for (int it = 0; it < 200; ++it) {
+#define SM(P) mf<P, MODE>(a, b);
+        SM(0) SM(1) SM(2) SM(3) SM(4) SM(5) SM(6) SM(7) SM(8) SM(9) SM(10) SM(11) SM(12) SM(13) SM(14) SM(15)
+      }
+    } else {
+#pragma unroll 1
+      for (int it = 0; it < 6400 / (N > 0 ? N : 1); ++it) {      // (runs longer than the MFMA waves)
+#define SF(P) fill<KIND, N>(x, u);
+        SF(0) SF(1) SF(2) SF(3) SF(4) SF(5) SF(6) SF(7) SF(8) SF(9) SF(10) SF(11) SF(12) SF(13) SF(14) SF(15)
+      }
+    }
+  } else
 #pragma unroll 1
   for (int it = 0; it < 200; ++it) {
-#define ST(P) if (MODE != 2) mf<P, MODE>(a, b); fill<KIND, N>(x, u);
+    const bool do_m = MODE != 2, do_f = true;
+#define ST(P) if (do_m) mf<P, MODE>(a, b); if (do_f) fill<KIND, N>(x, u);
     ST(0) ST(1) ST(2) ST(3) ST(4) ST(5) ST(6) ST(7) ST(8) ST(9) ST(10) ST(11) ST(12) ST(13) ST(14) ST(15)
   }
   const unsigned long long t1 = __builtin_readcyclecounter();
@@ -77,7 +94,7 @@ static float* o; static unsigned long long* c; static int slot = 0;
 static const char* names[64];
 template <int KIND, int N, int MODE> void run(const char* nm) {
   names[slot] = nm;
-  hipLaunchKernelGGL((k<KIND, N, MODE>), dim3(256), dim3(MODE == 1 ? 512 : 256), 0, 0, o, c, slot);
+  hipLaunchKernelGGL((k<KIND, N, MODE>), dim3(256), dim3((MODE == 1 || MODE == 3) ? 512 : 256), 0, 0, o, c, slot);
   ++slot;
 }
 __global__ void exact_k(const float* in, unsigned* bad, int n) {
@@ -114,19 +131,17 @@ int main() {
   }
   hipMalloc(&o, 1 << 22); hipMalloc(&c, 64 * 8);
   run<0, 0, 0>("1 wave/SIMD: bf16 MFMA only");
-  run<0, 6, 0>("+ 6 v_add_f32");          run<0, 6, 2>("  6 v_add_f32 only");
-  run<9, 6, 0>("+ 6 v_and_b32 literal");  run<9, 6, 2>("  6 v_and_b32 literal only");
-  run<5, 6, 0>("+ 6 v_dot2c_f32_bf16");   run<5, 6, 2>("  6 v_dot2c_f32_bf16 only");
-  run<11, 6, 0>("+ 6 v_dot2_f32_bf16");   run<11, 6, 2>("  6 v_dot2_f32_bf16 only");
-  run<7, 6, 0>("+ 6 v_perm_b32");         run<7, 6, 2>("  6 v_perm_b32 only");
-  run<8, 6, 0>("+ 6 v_cvt_pk_bf16_f32");  run<8, 6, 2>("  6 v_cvt_pk_bf16_f32 only");
-  run<10, 6, 0>("+ 6 v_fma_f32");         run<10, 6, 2>("  6 v_fma_f32 only");
-  run<1, 2, 0>("+ 2 v_pk_add_f32");       run<1, 6, 2>("  6 v_pk_add_f32 only");
-  run<4, 1, 0>("+ 1 pair split, and/sub (11+2 VALU)"); run<4, 1, 2>("  same only");
-  run<14, 1, 0>("+ 1 pair split, dot2 (7+4 VALU)"); run<14, 1, 2>("  same only");
-  run<0, 6, 1>("2 waves/SIMD: + 6 v_add_f32 each");
-  run<0, 7, 1>("2 waves/SIMD: + 7 v_add_f32 each");
-  run<14, 1, 1>("2 waves/SIMD: + 1 pair split dot2 each");
+  run<0, 6, 0>("+ 6 v_add_f32");
+  run<1, 2, 0>("+ 2 v_pk_add_f32");
+  run<0, 0, 3>("2 waves/SIMD: wave A MFMAs only, wave B idle (cycles of A per MFMA)");
+  run<0, 4, 3>("  wave B: 4 v_add_f32 per slot");
+  run<0, 8, 3>("  wave B: 8 v_add_f32 per slot");
+  run<0, 16, 3>("  wave B: 16 v_add_f32 per slot");
+  run<1, 2, 3>("  wave B: 2 v_pk_add_f32 per slot");
+  run<1, 4, 3>("  wave B: 4 v_pk_add_f32 per slot");
+  run<1, 8, 3>("  wave B: 8 v_pk_add_f32 per slot");
+  run<11, 4, 3>("  wave B: 4 v_pk_mul_f32 per slot");
+  run<10, 8, 3>("  wave B: 8 v_fma_f32 per slot");
   hipDeviceSynchronize();
   unsigned long long h[64]; hipMemcpy(h, c, 64 * 8, hipMemcpyDeviceToHost);
   for (int i = 0; i < slot; ++i) printf("%-60s %7.1f cycles per slot\n", names[i], (double)h[i] / (200.0 * 16));
