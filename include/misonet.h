@@ -86,6 +86,9 @@ int misonet_net_commit(misonet_net* net);
  *   5 "f32w"    (ABI 430) mode 0 with the DenseBlock convs (model.py:437-482: 94 % of the MACs) in Winograd F(2x2, 3x3) form:
  *               float32 products and sums on the same matrix cores, 2.25 x fewer of them (conv_wino.hip); measured 2.0e-6
  *               per forward against the reference (mode 0: 2.6e-6), 1.47 x mode 0's speed.  Same planar float32 layout.
+ *   6 "bf16x6w" (ABI 440) the same Winograd form in the arithmetic of mode 3 (exact three-piece split, six partial products per
+ *               Winograd-domain product; conv_wino6.hip).  fp32-faithful (1.8e-6), but SLOWER than mode 3 on MI355X: the split
+ *               of the transformed operand is vector-ALU work of the consumer (0.8 x mode 3).  Kept as a measured alternative.
  * The choice is internal to the workspace (whose size depends on it: misonet_net_workspace_bytes must be asked again
  * after a change): inputs, outputs and taps are the same float32 / complex64 tensors in every mode. */
 int misonet_net_set_precision(misonet_net* net, int mode);

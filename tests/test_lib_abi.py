@@ -36,7 +36,7 @@ def test_header_symbols_exported():
 def test_product_library_has_no_experiment_switches():
     """the kernel-variant / ablation / timeline switches (MISONET_X6_*, MISONET_DMA*, MISONET_SUBBATCH, ...)
     exist only in the experiment build (`make exp`, -DMISONET_EXPERIMENTS).  The product library reads NO environment
-    variable: not one MISONET_* name (nor a getenv import) is in the binary, and its ABI version says 430."""
+    variable: not one MISONET_* name (nor a getenv import) is in the binary, and its ABI version says at least 430 (440 since the bf16x6w mode)."""
     L = _lib()
     assert os.path.realpath(L.LIB_PATH).endswith("libmisonet_hip.so")
     blob = open(L.LIB_PATH, "rb").read()
