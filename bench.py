@@ -352,12 +352,11 @@ def roofline_objects(precision, B, T, steps, dt_conv_ms, n_launch, live=None):
     r_hbm = dict(common, bound="hbm", achieved=round(ach_tb * 1e3, 1), peak=PEAK_HBM_TBS * 1e3, unit="GB/s",
                  frac=round(ach_tb / PEAK_HBM_TBS, 4))
     # binding roofline: arithmetic intensity of the layer vs the ridge of the mode's effective matrix peak
-    # (Winograd modes: the ISSUED products against the direct-form peak -- the same ridge in issued units)
+    # (Winograd modes: priced against the matrix roofline of their issued products like the direct modes they are compared with;
+    # their algorithmic intensity per ISSUED product sits on the ridge, 52 FLOP/B, and bf16x6w is bound by neither: DESIGN 3.4)
     eff_peak = mfma_peak
     ai = flops_step / bytes_step
-    if wino:
-        eff_peak, ai = base_peak, issued / bytes_step
-    binding = r_mfma if ai >= eff_peak * 1e12 / (PEAK_HBM_TBS * 1e12) else r_hbm
+    binding = r_mfma if (wino or ai >= eff_peak * 1e12 / (PEAK_HBM_TBS * 1e12)) else r_hbm
     return binding, (r_hbm if binding is r_mfma else r_mfma)
 
 
