@@ -22,8 +22,9 @@
 //
 // PERSISTENT: one workgroup per CU walks its XCD's tile list (conv_wino.hip); the K-steps of all its tiles form one stream.
 // LDS: raw input double buffer, [16 channels][10 rows][68] fp32 per K-step (column c = frame t0 - 1 + c; columns 0-63 by
-// LDS-DMA row by row, 64-65 by two DMA instructions into a side array and an LDS -> LDS move), a ring of five U QUARTERS (the three pieces of the four positions of one position row:
-// 12 KB; a whole K-step of U is 48 KB and two of them do not fit beside the input), the norm tables.  One workgroup barrier
+// LDS-DMA row by row, 64-65 by two DMA instructions into a side array and an LDS -> LDS move), a ring of five U QUARTERS (the
+// three pieces of the four positions of one position row: 12 KB; a whole K-step of U is 48 KB and two of them do not fit beside
+// the input), the norm tables.  One workgroup barrier
 // per position row: it publishes the next row's U quarter (and, in row 2, the next K-step's input) and frees the quarter
 // before; behind it the wave queues the quarter of the same row of the next K-step (and, in row 3, the input two K-steps
 // ahead).
@@ -213,9 +214,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_x6(const ConvArgs a) {
   // ---- DMA of one K-step's raw input into raw slot `slot`: wave w owns channels 4 w .. 4 w + 3 of the K-step, one
   // 64-frame row (columns 0-63 = frames t0 - 1 .. t0 + 62) per instruction; rows and frames outside the image read a word
   // that exists (the zero norm entry / the frame mask removes it; the padding may hold anything).  Columns 64, 65 (frames
-  // t0 + 63, t0 + 64) go through two registers per lane < 40 and are written to LDS in front of the publishing barrier.
+  // t0 + 63, t0 + 64) go through a side array (two more DMA instructions) and are moved into their rows in front of the publishing barrier.
   unsigned hla = 0;
-  // part 0..3: the ten rows of the wave's channel `part`; part 4: the two register loads of columns 64, 65
+  // part 0..3: the ten rows of the wave's channel `part`; part 4: columns 64, 65 of the wave's 40 rows
   auto issue_raw = [&](const Cur& c, int slot, auto part_) __attribute__((always_inline)) {
     constexpr int part = decltype(part_)::value;
     if (DBG & (4 | 16)) return;
