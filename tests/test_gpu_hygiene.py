@@ -67,6 +67,13 @@ def test_long_utterance_no_frame_limit(sd1):
     y = m1.eval()(torch.from_numpy(mx[None]).cuda())
     y_ref = miso_oracle.miso1_forward(torch.from_numpy(mx[None]), sd1).numpy()
     _assert_parity(y.cpu().numpy(), y_ref, "miso1 T=2500 vs oracle")
+    m1.keep_activations(False)
+    for mode in ("f32w", "bf16x6w"):                   # the persistent Winograd kernels: 40 column tiles per row tile, the last one ragged
+        m1.set_precision(mode)
+        _assert_parity(m1(torch.from_numpy(mx[None]).cuda()).cpu().numpy(), y_ref, f"miso1 T=2500 vs oracle [{mode}]")
+    m1.set_precision("bf16x6")
+    m1.keep_activations(True)
+    y = m1(torch.from_numpy(mx[None]).cuda())
     tcn = m1.tap("tcn_out", 1, 2500).cpu().numpy()
     taps = {}
     miso_oracle.miso1_forward(torch.from_numpy(mx[None]), sd1, taps)
