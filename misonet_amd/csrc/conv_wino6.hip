@@ -216,6 +216,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_x6(const ConvArgs a) {
   // that exists (the zero norm entry / the frame mask removes it; the padding may hold anything).  Columns 64, 65 (frames
   // t0 + 63, t0 + 64) go through a side array (two more DMA instructions) and are moved into their rows in front of the publishing barrier.
   unsigned hla = 0;
+  unsigned rowoff_v = 0;                     // lane r < 10: byte offset of staged row r of the load cursor's tile inside a channel plane
+  auto row_setup = [&](const Cur& c) __attribute__((always_inline)) {
+    int f = c.f0 - 1 + (lane < XNR ? lane : 0);
+    f = f < 0 ? 0 : (f >= F ? F - 1 : f);
+    rowoff_v = (unsigned)f * (unsigned)Tp * 4u;
+  };
   // part 0..3: the ten rows of the wave's channel `part`; part 4: columns 64, 65 of the wave's 40 rows
   auto issue_raw = [&](const Cur& c, int slot, auto part_) __attribute__((always_inline)) {
     constexpr int part = decltype(part_)::value;
@@ -228,11 +234,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_x6(const ConvArgs a) {
       const unsigned dst0 = XRAW_B + (unsigned)slot * XSLOT_B + (unsigned)(4 * wave + part) * (XNR * XRW * 4u);
       int ch = c.kk * XCK + 4 * wave + part;
       ch = ch < Cin ? ch : Cin - 1;
+      const unsigned cho = (unsigned)ch * plane_b;
 #pragma unroll
-      for (int r = 0; r < XNR; ++r) {
-        int f = c.f0 - 1 + r;
-        f = f < 0 ? 0 : (f >= F ? F - 1 : f);
-        const unsigned so = (unsigned)ch * plane_b + (unsigned)f * (unsigned)Tp * 4u;
+      for (int r = 0; r < XNR; ++r) {      // (row offsets of the tile: lane r of rowoff_v -- recomputing the clamp per row cost 12 SALU per DMA)
+        const unsigned so = cho + (unsigned)__builtin_amdgcn_readlane((int)rowoff_v, r);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, MN_XLDS(smem_c + dst0 + (unsigned)r * (XRW * 4u)), 4, dvo, so, 0, 0);
       }
     } else {
@@ -310,10 +315,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_x6(const ConvArgs a) {
   L = D;
   const bool l_new = advance(L);
   __syncthreads();                                   // s_zero, s_nrm of C (and D) visible
+  row_setup(C);
   issue_raw_all(C, 0);
   X_VMCNT0
   write_halo();
+  row_setup(D);
   issue_raw_all(D, 1);
+  row_setup(L);
   issue_u(C, 0, 0); issue_u(C, 1, 1); issue_u(C, 2, 2); issue_u(C, 3, 3);
   X_VMCNT0
   // (slot 1's columns 64, 65 are written in front of the barrier of row 2 of the first K-step, like every later one's)
@@ -484,7 +492,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_x6(const ConvArgs a) {
     }
     C = D;
     D = L;
-    if (advance(L)) fill_nrm(L);
+    {
+      const unsigned q_old = L.q;
+      if (advance(L)) fill_nrm(L);
+      if (L.q != q_old) row_setup(L);
+    }
   }
 }
 
