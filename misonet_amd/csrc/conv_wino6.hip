@@ -21,7 +21,7 @@
 //   24 MFMAs of row xi run.  One wave per SIMD, 256 fixed accumulator AGPRs; workgroup = 4 waves = 8 output rows x 64 frames.
 //
 // PERSISTENT: one workgroup per CU walks its XCD's tile list (conv_wino.hip); the K-steps of all its tiles form one stream.
-// LDS: raw input double buffer, [16 channels][10 rows][68] fp32 per K-step (column c = frame t0 - 1 + c; columns 0-63 by
+// LDS: raw input double buffer, [16 channels][10 rows][66] fp32 per K-step (column c = frame t0 - 1 + c; columns 0-63 by
 // LDS-DMA row by row, 64-65 by two DMA instructions into a side array and an LDS -> LDS move), a ring of five U QUARTERS (the
 // three pieces of the four positions of one position row: 12 KB; a whole K-step of U is 48 KB and two of them do not fit beside
 // the input), the norm tables.  One workgroup barrier
@@ -44,8 +44,8 @@ typedef float xf4 __attribute__((ext_vector_type(4)));
 
 constexpr int XCK = 16;                        // input channels per K-step
 constexpr int XTT = 64, XFT = 8;               // output frames / rows per workgroup
-constexpr int XNR = 10, XRW = 68;              // staged rows, floats per staged row
-constexpr unsigned XSLOT_B = XCK * XNR * XRW * 4u;          // 43520
+constexpr int XNR = 10, XRW = 66;              // staged rows, floats per staged row (66: the two K-halves of a wave read disjoint LDS banks: 8 channels x 10 x 66 = 32 mod 64 dwords)
+constexpr unsigned XSLOT_B = XCK * XNR * XRW * 4u;          // 42240
 constexpr unsigned XQ_B = 4u * 3u * 64u * 16u;              // 12288: [nu][piece][lane] x 16 bytes
 constexpr int XNQ = 5;
 constexpr int XNRM_MAX = 256;
