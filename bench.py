@@ -535,8 +535,10 @@ def main():
     my_utts = rank_utterances(rank, world, B)
     for u in my_utts:
         obs, s0, s1 = W.synthetic_utterance(u, n)
-        mixes.append(stft.stft(torch.from_numpy(obs.T.copy()).to(dev)))                       # [M,T,F]
-        cleans.append(torch.stack([stft.stft(torch.from_numpy(s[:, 0].copy()).to(dev)) for s in (s0, s1)]))
+        # the product's own front end (csrc/stft.hip), not torch.stft: rocFFT's run-time compiled kernels gave ONE of eight
+        # processes that started together on one GPU a wrong spectrogram (1e-2) in a quarter of the runs (round 5: the 8-rank test)
+        mixes.append(stft.stft_hip(torch.from_numpy(obs[None].copy()).to(dev))[0])           # [M,T,F]
+        cleans.append(stft.stft_hip(torch.from_numpy(np.stack([s0[:, 0], s1[:, 0]], axis=1)[None].copy()).to(dev))[0])
     mix = torch.stack(mixes).contiguous()
     clean = torch.stack(cleans).contiguous()
     out = torch.empty((B, N_SPK, T, 129), dtype=torch.complex64, device=dev)
@@ -568,12 +570,37 @@ def main():
         from misonet_amd.pipeline import gather_outputs
         enh.enhance(mix, clean, check_nan=False, out=out)
         torch.cuda.synchronize()
+        # run-to-run repeatability on every rank (the ranks of a one-device run share the CUs: a latent race would show here)
+        first = out.clone()
+        enh.enhance(mix, clean, check_nan=False, out=out)
+        torch.cuda.synchronize()
+        rep_equal = bool(torch.equal(first, out))
         if dist is not None:
             dist.barrier()
         tg = time.perf_counter()
         allout = gather_outputs(out, world * B) if dist is not None else out
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - tg) * 1e3
+        # the gather moved what every rank computed: a float64 checksum of each rank's own result, gathered as scalars, against the
+        # checksum of its shard of the gathered tensor
+        sums_ok = None
+        if dist is not None:
+            mine = torch.view_as_real(out).double().abs().sum().reshape(1)
+            alls = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(alls, mine)
+            got_s = [float(torch.view_as_real(allout[r * B:(r + 1) * B]).double().abs().sum()) for r in range(world)]
+            sums_ok = [bool(float(a.item()) == g) for a, g in zip(alls, got_s)]
+            if os.environ.get("MISONET_BENCH_DEBUG_INPUTS"):      # (debugging aid: is every rank's device STFT of its first utterance right?)
+                from oracle import pipeline_oracle as _po
+                obs_, _s0, _s1 = W.synthetic_utterance(my_utts[0], n)
+                mref = _po.stft_chunk(obs_)
+                e_in = float(np.linalg.norm(mix[0].cpu().numpy() - mref) / np.linalg.norm(mref))
+                rep_equal = rep_equal and e_in < 1e-4
+                print(f"[rank {rank}] input STFT rel err {e_in:.3e}", file=sys.stderr, flush=True)
+            flag = torch.tensor([1.0 if rep_equal else 0.0], dtype=torch.float64, device=dev)
+            allf = [torch.zeros_like(flag) for _ in range(world)]
+            dist.all_gather(allf, flag)
+            rep_equal = [bool(f.item() == 1.0) for f in allf]
         if rank == 0:
             from oracle import pipeline_oracle
             u = (world - 1) * B                              # first utterance of the LAST rank's shard
@@ -584,7 +611,7 @@ def main():
             got = allout[u].cpu().numpy()
             err = float(np.linalg.norm(np.abs(got) - np.abs(ref)) / np.linalg.norm(np.abs(ref)))
             gather = {"gather_ms": round(gather_ms, 3), "gathered_shape": list(allout.shape),
-                      "bytes_per_rank": int(out.numel() * 8),
+                      "bytes_per_rank": int(out.numel() * 8), "shard_checksums_match": sums_ok, "second_pass_bit_identical": rep_equal,
                       "gather_parity": {"utterance": u, "from_rank": world - 1,
                                         "rel_l2_magnitudes_vs_oracle": float(f"{err:.3e}"), "tolerance": 1e-3,
                                         "ok": bool(np.isfinite(err) and err < 1e-3)}}
