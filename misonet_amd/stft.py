@@ -48,7 +48,10 @@ def stft_hip(wav: torch.Tensor) -> torch.Tensor:
 
 
 def stft(wav: torch.Tensor) -> torch.Tensor:
-    """wav float [..., L] -> complex64 [..., T, F] with T = L // 64 + 1, F = 129 (un-normalised, as fed to MISO_1)."""
+    """wav float [..., L] -> complex64 [..., T, F] with T = L // 64 + 1, F = 129 (un-normalised, as fed to MISO_1).
+    Host tool and test reference (torch.stft).  On a DEVICE tensor this is rocFFT with run-time compiled kernels: fine in one
+    process, but one of eight processes started together on one GPU got a wrong spectrogram in a quarter of the runs (round 5,
+    LAB section 0) -- device code paths use :func:`stft_hip` (or the wav entry points of the pipeline)."""
     lead = wav.shape[:-1]
     x = wav.reshape(-1, wav.shape[-1]).float()
     z = torch.stft(x, n_fft=NPERSEG, hop_length=HOP, win_length=NPERSEG, window=_window(x.device), center=True,
