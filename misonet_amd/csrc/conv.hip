@@ -30,7 +30,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 
 int conv_cop(int Cout) { return Cout <= 32 ? 32 : 64; }
-int conv_rows(int sf, int tr2) { return tr2 ? 3 : sf * (FT - 1) + 3; }
+int conv_rows(int sf, int tr2) { return tr2 ? 3 : sf * (FT - 1) + 3; }   // (the staged rows of the row-per-wave geometry: conv_bf16*.hip)
+// staged input rows of conv3x3_mfma: MODE 2 (stride-2 transposed) runs a PAIR of output rows per wave = 8 output rows per
+// workgroup, which need input rows m0 - 1 .. m0 + 3; MODE 3 (stride-1 transposed on ONE input row) stages that row only
+static int f32_rows(const ConvArgs& a) { return a.tr2 ? 5 : a.sf * (FT - 1) + 3; }
 
 // MFMA work of one K-chunk for one wave: one output row, four 32-frame column tiles, NCO 32-channel row tiles.
 // The (tap, channel-pair) steps are flattened into one fully unrolled sequence with an explicit two-deep operand
@@ -41,7 +44,8 @@ int conv_rows(int sf, int tr2) { return tr2 ? 3 : sf * (FT - 1) + 3; }
 // last tile costs MFMAs, not correctness (T = 1001 and T = 501 both end in a tile that needs four anyway).
 // NCP: channel pairs of the chunk that hold channels (4 = all of CK; 2 for a last chunk with <= 4 channels -- the 12-channel
 // network input (model.py:44) leaves half of its second chunk empty: a quarter of that layer's MFMAs).
-template <int NCO, int NR, int SF, bool TR2, int KFMASK, int NCP = CK / 2>
+// ROW0: every selected tap reads staged row 0 (MODE 3: the layer has one input row).
+template <int NCO, int NR, int SF, bool TR2, int KFMASK, int NCP = CK / 2, bool ROW0 = false>
 __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[NCO][4], const float* s_in, const float* s_w, int frel,
                                            int half, int l31) {
   constexpr int COP = NCO * 32;
@@ -52,7 +56,7 @@ __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[NCO][4], const float* s
   const float* ibase[3];
 #pragma unroll
   for (int kf = 0; kf < 3; ++kf) {
-    const int rl = TR2 ? ((frel + kf) >> 1) : (SF * frel + kf);
+    const int rl = ROW0 ? 0 : (TR2 ? ((frel + kf) >> 1) : (SF * frel + kf));
     ibase[kf] = s_in + (half * NR + rl) * TW + l31 + 3;
   }
   float av[2][NCO], bv[2][4];
@@ -60,7 +64,7 @@ __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[NCO][4], const float* s
   {                                                                                             \
     constexpr int tap_ = (ST) / NCP, cp_ = (ST) % NCP;                                          \
     constexpr int kt_ = tap_ / NKF, ks_ = tap_ % NKF;                                           \
-    constexpr int kf_ = (NKF == 3) ? ks_ : ((KFMASK == 2) ? 1 : (ks_ == 0 ? 0 : 2));            \
+    constexpr int kf_ = (NKF == 3) ? ks_ : (NKF == 1 ? (KFMASK == 1 ? 0 : (KFMASK == 2 ? 1 : 2)) : (ks_ == 0 ? 0 : 2)); \
     _Pragma("unroll") for (int j = 0; j < NCO; ++j)                                             \
         av[BUF][j] = wbase[((kt_ * 3 + kf_) * CK + cp_ * 2) * COP + j * 32];                    \
     _Pragma("unroll") for (int q = 0; q < 4; ++q)                                               \
@@ -75,7 +79,7 @@ __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[NCO][4], const float* s
       const int nx = st + 1;
       const int tap_ = nx / NCP, cp_ = nx % NCP;
       const int kt_ = tap_ / NKF, ks_ = tap_ % NKF;
-      const int kf_ = (NKF == 3) ? ks_ : ((KFMASK == 2) ? 1 : (ks_ == 0 ? 0 : 2));
+      const int kf_ = (NKF == 3) ? ks_ : (NKF == 1 ? (KFMASK == 1 ? 0 : (KFMASK == 2 ? 1 : 2)) : (ks_ == 0 ? 0 : 2));
 #pragma unroll
       for (int j = 0; j < NCO; ++j) av[cur ^ 1][j] = wbase[((kt_ * 3 + kf_) * CK + cp_ * 2) * COP + j * 32];
 #pragma unroll
@@ -93,7 +97,12 @@ __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[NCO][4], const float* s
 }
 
 // MODE 0: forward / stride-1-transposed conv (sf = 1, NR = 6 staged rows); MODE 1: stride-2 conv (NR = 9);
-// MODE 2: stride-2 transposed conv (NR = 3).
+// MODE 2: stride-2 transposed conv: a wave owns the output row PAIR (2m, 2m + 1) -- the even row takes taps kf = 0, 2 of input
+//   rows m - 1, m, the odd row tap kf = 1 of row m: 9 tap steps per wave and chunk, the same for every wave (one output row
+//   per wave gave the even rows 6 steps and the odd rows 3: every barrier waited for the even rows, 75 % of the matrix time at
+//   best).  Workgroup = 8 output rows, NR = 5 staged rows, 32-channel groups only (two rows x 4 column tiles = 128 registers).
+// MODE 3: stride-1 transposed conv on ONE input row (decoder 0 behind the F = 1 bottleneck, model.py:64): output row f reads
+//   the row through tap kf = 2 - f only; NR = 1, one tap step per wave instead of three (two of them on staged zeros).
 //
 // Software pipeline per K-chunk (guide T14, "issue early / write late"): the global loads of chunk k+1 (NR float4 of
 // the input patch + 1 halo scalar + the weight slab share per thread) are issued into registers BEFORE the MFMA loop
@@ -108,10 +117,12 @@ __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[NCO][4], const float* s
 // mode -36 %); tests/test_build_resources.py holds the hot instantiations to ScratchSize == 0.
 template <int NCO, int MODE, int OCTP = 0, bool HALFK = false>
 __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0 && !HALFK) ? 3 : 2)) void conv3x3_mfma(const ConvArgs a) {
+  static_assert(MODE != 2 || NCO == 1, "stride-2 transposed: two output rows per wave, 32-channel groups");
   constexpr int COP = NCO * 32;
-  constexpr int NR = MODE == 0 ? 6 : (MODE == 1 ? 9 : 3);
+  constexpr int NR = MODE == 0 ? 6 : (MODE == 1 ? 9 : (MODE == 2 ? 5 : 1));
   constexpr int SF = MODE == 1 ? 2 : 1;
   constexpr bool TR2 = MODE == 2;
+  constexpr int FTO = TR2 ? 2 * FT : FT;         // output rows per workgroup
   constexpr int NW4 = 9 * CK * COP / 4;          // float4 per weight slab
   constexpr int NWI = (NW4 + 255) / 256;
   extern __shared__ __align__(16) float smem[];
@@ -125,12 +136,12 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0 && !HALFK
   const ConvTile ct = conv_tile(a);
   if (!ct.valid) return;
   const int t0 = ct.t_tile * TT;
-  const int f0 = ct.f_tile * FT;
+  const int f0 = ct.f_tile * FTO;
   const int n = ct.n;
   const int cg = ct.cg;
   const int T = a.T, Tp = a.Tp, Fin = a.Fin, Cin = a.Cin;
   const int nchunk = (Cin + CK - 1) / CK;
-  const int fin0 = TR2 ? (f0 >> 1) - 1 : SF * f0 - a.padf;
+  const int fin0 = MODE == 3 ? 0 : (TR2 ? (f0 >> 1) - 1 : SF * f0 - a.padf);
 
   // instance-norm parameters of the input channels (normalise-on-load)
   for (int c = tid; c < nchunk * CK; c += 256) {
@@ -237,18 +248,19 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0 && !HALFK
     }                                                                                            \
   }
 
-  const int f = f0 + wave;
+  const int f = TR2 ? f0 + 2 * wave : f0 + wave;        // (TR2: the even row of the pair; f + 1 is the odd one)
   const bool row_ok = f < a.Fout;                       // wave-uniform
   int nseg = (T - t0 + 31) >> 5;
   nseg = nseg > 4 ? 4 : nseg;
 
   f32x16 acc[NCO][4];
+  f32x16 acc_o[NCO][4];                                 // TR2: the odd row of the pair (never touched otherwise)
 #pragma unroll
   for (int j = 0; j < NCO; ++j)
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][s][r] = 0.f;
+      for (int r = 0; r < 16; ++r) { acc[j][s][r] = 0.f; if (TR2) acc_o[j][s][r] = 0.f; }
 
   const int half = lane >> 5, l31 = lane & 31;
 
@@ -262,8 +274,11 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0 && !HALFK
     if (more) STAGE_ISSUE(kc + 1)
     if (row_ok) {
       if (TR2) {
-        if ((f - f0) & 1) chunk_mfma<NCO, NR, SF, TR2, 2>(acc, s_in, s_w, f - f0, half, l31);
-        else chunk_mfma<NCO, NR, SF, TR2, 5>(acc, s_in, s_w, f - f0, half, l31);
+        chunk_mfma<NCO, NR, SF, TR2, 5>(acc, s_in, s_w, f - f0, half, l31);
+        chunk_mfma<NCO, NR, SF, TR2, 2>(acc_o, s_in, s_w, f - f0 + 1, half, l31);
+      } else if (MODE == 3) {
+        // (ONE body: the tap kf = 2 - f is a wave-uniform offset into the weight slab, the staged row is row 0)
+        chunk_mfma<NCO, NR, SF, TR2, 1, CK / 2, true>(acc, s_in, s_w + (2 - wave) * (CK * COP), 0, half, l31);
       } else if (HALFK && kc == nchunk - 1) {
         chunk_mfma<NCO, NR, SF, TR2, 7, CK / 4>(acc, s_in, s_w, f - f0, half, l31);      // half-empty last chunk
       } else {
@@ -277,8 +292,13 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0 && !HALFK
     }
   }
 
-  float* s_red = smem;   // [FT waves][COP][2]  (safe: the loop ends with a barrier after the last reads)
-  conv_epilogue<NCO, 4, OCTP, true>(a, acc, n, cg, f, t0, row_ok, lane, s_red + wave * (COP * 2));
+  float* s_red = smem;   // [FTO rows][COP][2]  (safe: the loop ends with a barrier after the last reads)
+  if (TR2) {
+    conv_epilogue<NCO, 4, OCTP, true>(a, acc, n, cg, f, t0, row_ok, lane, s_red + (2 * wave) * (COP * 2));
+    conv_epilogue<NCO, 4, OCTP, true>(a, acc_o, n, cg, f + 1, t0, f + 1 < a.Fout, lane, s_red + (2 * wave + 1) * (COP * 2));
+  } else {
+    conv_epilogue<NCO, 4, OCTP, true>(a, acc, n, cg, f, t0, row_ok, lane, s_red + wave * (COP * 2));
+  }
   if (a.act) {
     __syncthreads();
     if (tid < COP * 2) {
@@ -286,7 +306,7 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0 && !HALFK
       const int co = cg * COP + co_l;
       if (co < a.Cout) {
         float tot = 0.f;
-        for (int w = 0; w < FT; ++w)
+        for (int w = 0; w < FTO; ++w)
           if (f0 + w < a.Fout) tot += s_red[(w * COP + co_l) * 2 + which];
         dstat_add(a.out_stats + (((long long)n * a.out_sstride + a.out_c0 + co) * 2 + which) * DS_NL, (double)tot);
       }
@@ -315,18 +335,17 @@ hipError_t conv_init() {
   if ((e = set_lds_attr<1, 2>()) != hipSuccess) return e;
   if ((e = set_lds_attr<2, 0>()) != hipSuccess) return e;
   if ((e = set_lds_attr<2, 1>()) != hipSuccess) return e;
-  if ((e = set_lds_attr<2, 2>()) != hipSuccess) return e;
+  if ((e = set_lds_attr<1, 3>()) != hipSuccess) return e;
+  if ((e = set_lds_attr<2, 3>()) != hipSuccess) return e;
   if ((e = set_lds_attr<1, 0, 3>()) != hipSuccess) return e;
   if ((e = set_lds_attr<1, 2, 3>()) != hipSuccess) return e;
   if ((e = set_lds_attr<2, 0, 3>()) != hipSuccess) return e;
-  if ((e = set_lds_attr<2, 2, 3>()) != hipSuccess) return e;
   if ((e = set_lds_attr<1, 0, 4>()) != hipSuccess) return e;
   if ((e = set_lds_attr<1, 2, 4>()) != hipSuccess) return e;
   if ((e = set_lds_attr<2, 0, 4>()) != hipSuccess) return e;
   if ((e = set_lds_attr<1, 0, 0, true>()) != hipSuccess) return e;
   if ((e = set_lds_attr<1, 0, 3, true>()) != hipSuccess) return e;
-  if ((e = set_lds_attr<1, 0, 4, true>()) != hipSuccess) return e;
-  return set_lds_attr<2, 2, 4>();
+  return set_lds_attr<1, 0, 4, true>();
 }
 
 int device_cus() {
@@ -352,10 +371,11 @@ hipError_t launch_conv(const ConvArgs& a_in, int n_samples, hipStream_t s) {
   // XCD-aware order deals whole SAMPLES to the 8 XCDs (n % 8 == xcd): with a sample count that is not a multiple of 8 some
   // XCDs get nothing (B = 1: MISO3 runs 2 samples -> 6 of 8 XCDs idle, the first layer took 114 us instead of ~30); the
   // natural (t, f, n) grid is used then
-  const dim3 grid = conv_grid(a, n_samples, TT, FT, (n_samples % 8 == 0) ? conv_xcd_env() : 0);
+  const int mode = a.tr2 ? 2 : (a.sf == 2 ? 1 : ((a.padf == 2 && a.Fin == 1 && !a.out_oct) ? 3 : 0));
+  a.NR = mode == 3 ? 1 : (mode == 0 ? 6 : f32_rows(a));
+  if (mode == 2 && a.cop != 32) return hipErrorInvalidValue;   // (net.hip packs stride-2 transposed layers in 32-channel groups)
+  const dim3 grid = conv_grid(a, n_samples, TT, mode == 2 ? 2 * FT : FT, (n_samples % 8 == 0) ? conv_xcd_env() : 0);
   const size_t lds = conv_lds_bytes(a.NR, a.cop, a.Cin);
-  const int mode = a.tr2 ? 2 : (a.sf == 2 ? 1 : 0);
-  if (a.NR != conv_rows(a.sf, a.tr2)) return hipErrorInvalidValue;
 #define MN_LAUNCH(NCO, MODE) hipLaunchKernelGGL((conv3x3_mfma<NCO, MODE>), grid, dim3(256), lds, s, a)
 #define MN_LAUNCH3(NCO, MODE) hipLaunchKernelGGL((conv3x3_mfma<NCO, MODE, 3>), grid, dim3(256), lds, s, a)
 #define MN_LAUNCH4(NCO, MODE) hipLaunchKernelGGL((conv3x3_mfma<NCO, MODE, 4>), grid, dim3(256), lds, s, a)
@@ -368,15 +388,15 @@ hipError_t launch_conv(const ConvArgs& a_in, int n_samples, hipStream_t s) {
     if ((a.out_oct != 3 && a.out_oct != 4) || mode == 1 || (a.Cout & 7) || (a.out_c0 & 7) || (a.out_sstride & 7)) return hipErrorInvalidValue;
     if (a.out_oct == 3) {
       if (a.cop == 32) { if (halfk) MN_LAUNCH_H(3); else if (mode == 0) MN_LAUNCH3(1, 0); else MN_LAUNCH3(1, 2); }
-      else { if (mode == 0) MN_LAUNCH3(2, 0); else MN_LAUNCH3(2, 2); }
+      else { if (mode == 0) MN_LAUNCH3(2, 0); else return hipErrorInvalidValue; }
     } else {
       if (a.cop == 32) { if (halfk) MN_LAUNCH_H(4); else if (mode == 0) MN_LAUNCH4(1, 0); else MN_LAUNCH4(1, 2); }
-      else { if (mode == 0) MN_LAUNCH4(2, 0); else MN_LAUNCH4(2, 2); }
+      else { if (mode == 0) MN_LAUNCH4(2, 0); else return hipErrorInvalidValue; }
     }
   } else if (a.cop == 32) {
-    if (halfk) MN_LAUNCH_H(0); else if (mode == 0) MN_LAUNCH(1, 0); else if (mode == 1) MN_LAUNCH(1, 1); else MN_LAUNCH(1, 2);
+    if (halfk) MN_LAUNCH_H(0); else if (mode == 0) MN_LAUNCH(1, 0); else if (mode == 1) MN_LAUNCH(1, 1); else if (mode == 2) MN_LAUNCH(1, 2); else MN_LAUNCH(1, 3);
   } else {
-    if (mode == 0) MN_LAUNCH(2, 0); else if (mode == 1) MN_LAUNCH(2, 1); else MN_LAUNCH(2, 2);
+    if (mode == 0) MN_LAUNCH(2, 0); else if (mode == 1) MN_LAUNCH(2, 1); else MN_LAUNCH(2, 3);
   }
 #undef MN_LAUNCH
 #undef MN_LAUNCH3

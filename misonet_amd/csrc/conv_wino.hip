@@ -59,11 +59,14 @@ constexpr int WIN_FLOATS = WCK * WNR * WTW;    // 5280
 constexpr int WW_FLOATS = 16 * WCK * 32;       // 4096: [pos / 4][ci][co][pos % 4]
 constexpr int WSTAGE_FLOATS = WIN_FLOATS + WW_FLOATS;
 constexpr int WNSTAGE = 3;
-constexpr int WNRM_MAX = 256;                  // input channels (s_nrm entries per parity)
+constexpr int WNRM_MAX = 192;                  // input channels (s_nrm entries per parity); the network's widest DenseBlock conv has 192
+constexpr int WCO_MAX = 64;                    // output channels (epilogue table entries)
 
-template <int P>
+// Z: the accumulator STARTS here (C = 0, the first K-step of a tile): no v_accvgpr_write pass over the 256 registers per tile
+template <int P, bool Z = false>
 __device__ __forceinline__ void wino_mfma(float uu, float vv) {
-  asm volatile("v_mfma_f32_32x32x2_f32 a[%0:%1], %2, %3, a[%0:%1]" ::"n"(16 * P), "n"(16 * P + 15), "v"(uu), "v"(vv) : W_ACLOB);
+  if (Z) asm volatile("v_mfma_f32_32x32x2_f32 a[%0:%1], %2, %3, 0" ::"n"(16 * P), "n"(16 * P + 15), "v"(uu), "v"(vv) : W_ACLOB);
+  else asm volatile("v_mfma_f32_32x32x2_f32 a[%0:%1], %2, %3, a[%0:%1]" ::"n"(16 * P), "n"(16 * P + 15), "v"(uu), "v"(vv) : W_ACLOB);
 }
 // packed f32 forms (semantics checked on the GPU by tools/micro/pk_opsel.hip)
 __device__ __forceinline__ wf2 pk_add(wf2 a, wf2 b) { wf2 d; asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
@@ -72,31 +75,41 @@ __device__ __forceinline__ wf2 pk_sub(wf2 a, wf2 b) { wf2 d; asm volatile("v_pk_
 __device__ __forceinline__ wf2 pk_t01(wf2 a, wf2 b) { wf2 d; asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(d) : "v"(a), "v"(b)); return d; }
 // (a1 - b0, a1 - b1)
 __device__ __forceinline__ wf2 pk_t23(wf2 a, wf2 b) { wf2 d; asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+// (a0 + a1, a0 - a1)
+__device__ __forceinline__ wf2 pk_spm(wf2 a) { wf2 d; asm volatile("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(d) : "v"(a)); return d; }
+// (a0 + b0, a1 - b1)
+__device__ __forceinline__ wf2 pk_add_nh(wf2 a, wf2 b) { wf2 d; asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ wf2 pk_mul(wf2 a, wf2 b) { wf2 d; asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ wf2 pk_fma(wf2 a, wf2 b, wf2 c) { wf2 d; asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+// The hazard recogniser does not look INSIDE inline asm: a hazard between an instruction in an asm block and a compiler-generated
+// neighbour is ours to cover.  Two occur in the epilogue (round 6: a packed consumer scheduled directly behind v_exp_f32 gave
+// timing-dependent garbage): (i) gfx950 needs one wait state between a TRANS instruction (v_exp_f32) and a VALU instruction that
+// reads its result -- the exp2 below carries it; (ii) two wait states between a VALU write and a DPP read of the register --
+// elu_pick's result feeds the DPP lane exchange of the stores.
+__device__ __forceinline__ float exp2_ws(float x) {
+  float r;
+  asm volatile("v_exp_f32 %0, %1\n\ts_nop 0" : "=v"(r) : "v"(x));
+  return r;
+}
+// y >= +0 ? pos : neg as ONE v_bfi_b32 on the sign of y (conv_epilogue.hpp elu_select: no compare, NaN-transparent)
+__device__ __forceinline__ float elu_pick(float y, float neg, float pos) {
+  const int m = __builtin_bit_cast(int, y) >> 31;
+  float r;
+  asm volatile("v_bfi_b32 %0, %1, %2, %3\n\ts_nop 1" : "=v"(r) : "v"(m), "v"(neg), "v"(pos));
+  return r;
+}
 // (x0 * n0 + n1, x1 * n0 + n1)
 __device__ __forceinline__ wf2 pk_nrm(wf2 x, wf2 nr) { wf2 d; asm volatile("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(x), "v"(nr)); return d; }
-// s_waitcnt vmcnt(n) with a RUN-TIME n: the wave's outstanding-VMEM count is readable (IB_STS.VM_CNT [3:0] + VM_CNT_HI [23:22];
-// checked on gfx950 by tools/micro/ibsts_vmcnt.hip).  SALU only, so it costs nothing beside the matrix pipe; the spin is bounded
-// (then the plain full wait), a wrong reading can never hang the GPU.
-__device__ __forceinline__ void wait_vm_le(int n) {
-  int spins = 0;
-  for (;;) {
-    const int lo = __builtin_amdgcn_s_getreg(7 | (0 << 6) | (3 << 11));
-    const int hi = __builtin_amdgcn_s_getreg(7 | (22 << 6) | (1 << 11));
-    if ((lo | (hi << 4)) <= n) return;
-    if (++spins > (1 << 20)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
-  }
-}
-
 // LDS map: 3 stages {normalised input [8][10][WTW] | U image 16 KB} | raw ring: 2 slots {80 items x 64 frames as the DMA leaves
-// them | 256 halo words} | s_nrm[2][WNRM_MAX] float2 | s_zero[WNRM_MAX] float2 | s_red [4][32][2] | 64 dummy words | bias [128]
+// them | 256 halo words} | s_nrm[2][WNRM_MAX] float2 | s_zero[WNRM_MAX] float2 | s_red [4][32][2] | 64 dummy words | epilogue table [WCO_MAX] x {(b, b), (-c, -c), (-1 - c, -1 - c)}, c = ELU(b)
 constexpr int WRAW_FLOATS = WCK * WNR * WTT + 256;
 constexpr unsigned WRAW_B = (unsigned)(WNSTAGE * WSTAGE_FLOATS) * 4u;
 constexpr unsigned WNRM_B = WRAW_B + 2u * WRAW_FLOATS * 4u;
 constexpr unsigned WZERO_B = WNRM_B + 2u * WNRM_MAX * 8u;
 constexpr unsigned WRED_B = WZERO_B + WNRM_MAX * 8u;
 constexpr unsigned WDUMMY_B = WRED_B + 4u * 64u * 4u;
-constexpr unsigned WBIAS_B = WDUMMY_B + 64u * 4u;       // the layer's bias (<= 128 channels): the epilogue must not queue VMEM loads behind the DMA
-constexpr size_t WINO_LDS = WBIAS_B + 128 * 4;
+constexpr unsigned WBIAS_B = WDUMMY_B + 64u * 4u;       // per output channel: bias and the ELU centring constants as PAIRS for the packed epilogue (LDS: the epilogue must not queue VMEM loads behind the DMA)
+constexpr size_t WINO_LDS = WBIAS_B + WCO_MAX * 24;
 static_assert(WINO_LDS <= 160 * 1024, "one workgroup per CU: at most 160 KB of LDS");
 
 // DBG (timing experiments only, -DMISONET_EXPERIMENTS + MISONET_WINO_DBG): 1 = no staging side work in the chunk loop (wrong
@@ -135,8 +148,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
   if (q0 >= Q) return;
   const unsigned ntile = (Q - q0 + qstep - 1) / qstep;
   for (int i = tid; i < WNRM_MAX; i += 256) s_zero[i] = wf2{0.f, 0.f};
-  float* s_bias = reinterpret_cast<float*>(smem_c + WBIAS_B);
-  if (tid < 128) s_bias[tid] = tid < a.ncg * 32 ? a.bias[tid] : 0.f;
+  if (tid < WCO_MAX) {
+    const float b = tid < a.ncg * 32 ? a.bias[tid] : 0.f;
+    const float c = elu_fast(b);
+    wf2* tb = reinterpret_cast<wf2*>(smem_c + WBIAS_B + tid * 24);
+    tb[0] = wf2{b, b}; tb[1] = wf2{-c, -c}; tb[2] = wf2{-1.f - c, -1.f - c};
+  }
 
   const unsigned row_e = (unsigned)Tp;
   const unsigned plane_b = (unsigned)F * row_e * 4u;
@@ -355,7 +372,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
 #else
 #define W_STAMP(ID)
 #endif
-#define W_MF(P) wino_mfma<P>(u[(P) >> 2][(P) & 3], vp[(P) >> 2][((P) & 3) >> 1][(P) & 1]);
+#define W_MF(P, CS) wino_mfma<P, (POST == 2 && (CS) == 0)>(u[(P) >> 2][(P) & 3], vp[(P) >> 2][((P) & 3) >> 1][(P) & 1]);
 #define W_NONE
 #define W_X(...) if (!(DBG & (1 | 32))) { __VA_ARGS__ }      /* staging arithmetic, norm / raw reads, LDS writes */
 #define W_XL(...) if (!(DBG & (1 | 16))) { __VA_ARGS__ }     /* raw input DMA */
@@ -366,23 +383,23 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
   // group's items; X7, X9-X11, X13, X14: norm entries and raw words for this group's items, or DMA pieces; XB: barrier (step
   // 3 only, after slot 3, in front of every access to the next chunk's stage); XG: this step's staging arithmetic.
 #define W_STEP(CS, FD_, FU_, FS, X1, X2, X3, XB, X7, X9, X10, X11, X13, X14, XG)                      \
-  W_MF(0) W_FU(3, uc, CS) W_SB                                                                        \
-  W_MF(1) X1 W_SB                                                                                     \
-  W_MF(2) X2 W_SB                                                                                     \
-  W_MF(3) X3 W_SB                                                                                     \
+  W_MF(0, CS) W_FU(3, uc, CS) W_SB                                                                        \
+  W_MF(1, CS) X1 W_SB                                                                                     \
+  W_MF(2, CS) X2 W_SB                                                                                     \
+  W_MF(3, CS) X3 W_SB                                                                                     \
   XB                                                                                                  \
-  W_MF(4) W_FU(0, FU_, FS) W_SB                                                                       \
-  W_MF(5) W_FD(0, FD_) W_SB                                                                           \
-  W_MF(6) W_FD(2, FD_) W_SB                                                                           \
-  W_MF(7) X7 W_SB                                                                                     \
-  W_MF(8) W_FU(1, FU_, FS) W_SB                                                                       \
-  W_MF(9) X9 W_SB                                                                                     \
-  W_MF(10) X10 W_SB                                                                                   \
-  W_MF(11) X11 W_SB                                                                                   \
-  W_MF(12) W_FU(2, FU_, FS) W_SB                                                                      \
-  W_MF(13) X13 W_SB                                                                                   \
-  W_MF(14) X14 W_SB                                                                                   \
-  W_MF(15) W_SB                                                                                       \
+  W_MF(4, CS) W_FU(0, FU_, FS) W_SB                                                                       \
+  W_MF(5, CS) W_FD(0, FD_) W_SB                                                                           \
+  W_MF(6, CS) W_FD(2, FD_) W_SB                                                                           \
+  W_MF(7, CS) X7 W_SB                                                                                     \
+  W_MF(8, CS) W_FU(1, FU_, FS) W_SB                                                                       \
+  W_MF(9, CS) X9 W_SB                                                                                     \
+  W_MF(10, CS) X10 W_SB                                                                                   \
+  W_MF(11, CS) X11 W_SB                                                                                   \
+  W_MF(12, CS) W_FU(2, FU_, FS) W_SB                                                                      \
+  W_MF(13, CS) X13 W_SB                                                                                   \
+  W_MF(14, CS) X14 W_SB                                                                                   \
+  W_MF(15, CS) W_SB                                                                                       \
   W_TRANSFORM XG W_SB
 
   // Chunk g on the matrix pipe from stage ST.  Chunk g + 1: raw ring -> stage STN (the wave's own DMA of two iterations ago:
@@ -495,42 +512,57 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
                                : ((r1ok && t - 2 < T) ? vbase + (unsigned)Tp * 4u - 8u : 0x80000000u);
       const float m00 = (r0ok && c0ok) ? 1.f : 0.f, m01 = (r0ok && c1ok) ? 1.f : 0.f;
       const float m10 = (r1ok && c0ok) ? 1.f : 0.f, m11 = (r1ok && c1ok) ? 1.f : 0.f;
-      const bool act = a.act != 0;
-      const unsigned bias_a = lds0 + WBIAS_B + (unsigned)(4 * half) * 4u;      // explicit LDS addresses: a generic-pointer access is a
-      const unsigned red_a = lds0 + WRED_B;                                    // FLAT op, and a flat op waits for vmcnt(0) = for every store
+      // explicit LDS addresses (a generic-pointer access is a FLAT op, and a flat op waits for vmcnt(0) = for every store), the
+      // table base laundered: one register + immediates instead of an address add per access (WBIAS_B is beyond the 16-bit offset)
+      const unsigned tab_a = launder(lds0 + WBIAS_B + (unsigned)(cbase + 4 * half) * 24u);
+      const unsigned red_a = lds0 + WRED_B;
+      // The epilogue is VALU work the matrix pipe waits for (one wave per SIMD, and the f32 MFMA shares the vector ALU anyway):
+      // it is written in PACKED f32 -- (e0, e1) = the two output columns of a position row, (y00, y01) / (y10, y11) = the two
+      // frames of an output row -- 8 + 6 packed adds instead of 16 + 16 plain ones per channel, the ELU's scale / centring and
+      // the statistics packed as well; per-channel constants come as pairs from the LDS table.
+      // (laundered: the compiler otherwise re-materialises these pairs from their SGPR conditions for every channel)
+      wf2 l2e = {1.44269504088896341f, 1.44269504088896341f};
+      wf2 mt = {m00, m01}, mb = {m10, m11};
+      asm volatile("" : "+v"(l2e), "+v"(mt), "+v"(mb));
       float s1[16], s2[16];
       wfor<16>([&](auto rc) __attribute__((always_inline)) {
         constexpr int r = decltype(rc)::value;
         constexpr int kr = (r & 3) + 8 * (r >> 2);
         const unsigned coff = (unsigned)(cbase + kr) * P4;
-        const float b = *W_LP(const float, bias_a + (unsigned)(cbase + kr) * 4u);
-        const float cr = act ? elu_fast(b) : 0.f;
-        float e0[4], e1[4];
+        const wf2 bb = *W_LP(const wf2, tab_a + kr * 24);
+        wf2 E[4];
         wfor<4>([&](auto xc) __attribute__((always_inline)) {
           constexpr int x = decltype(xc)::value;
           const float m0 = agpr_get<(4 * x + 0) * 16 + r>(), m1 = agpr_get<(4 * x + 1) * 16 + r>();
           const float m2 = agpr_get<(4 * x + 2) * 16 + r>(), m3 = agpr_get<(4 * x + 3) * 16 + r>();
-          e0[x] = (m0 + m1) + m2;
-          e1[x] = (m1 - m2) - m3;
+          // (e0, e1) = (m0 + m1 + m2, m1 - m2 - m3) = (m1 + m2, m1 - m2) + (m0, -m3)
+          E[x] = pk_add_nh(pk_spm(wf2{m1, m2}), wf2{m0, m3});
         });
-        float y00 = (e0[0] + e0[1]) + e0[2] + b, y10 = (e0[1] - e0[2]) - e0[3] + b;
-        float y01 = (e1[0] + e1[1]) + e1[2] + b, y11 = (e1[1] - e1[2]) - e1[3] + b;
-        if (act && !(DBG & 256)) {
-          y00 = elu_fast(y00) - cr; y01 = elu_fast(y01) - cr;
-          y10 = elu_fast(y10) - cr; y11 = elu_fast(y11) - cr;
+        wf2 yt = pk_add(pk_add(E[0], E[1]), pk_add(E[2], bb));        // (y00, y01): row fa, frames t, t + 1
+        wf2 yb = pk_add(pk_sub(E[1], E[2]), pk_sub(bb, E[3]));        // (y10, y11): row fa + 1
+        if (!(DBG & 256)) {
+          // ELU(y) - c, c = ELU(bias):  y >= 0 ? y - c : exp(y) - (1 + c)   (elu_select's bit select on the sign of y)
+          const wf2 ncr = *W_LP(const wf2, tab_a + kr * 24 + 8), nc1 = *W_LP(const wf2, tab_a + kr * 24 + 16);
+          const wf2 xt = pk_mul(yt, l2e), xb = pk_mul(yb, l2e);
+          const wf2 et = pk_add(wf2{exp2_ws(xt.x), exp2_ws(xt.y)}, nc1);
+          const wf2 eb = pk_add(wf2{exp2_ws(xb.x), exp2_ws(xb.y)}, nc1);
+          const wf2 at = pk_add(yt, ncr), ab = pk_add(yb, ncr);
+          yt = wf2{elu_pick(yt.x, et.x, at.x), elu_pick(yt.y, et.y, at.y)};
+          yb = wf2{elu_pick(yb.x, eb.x, ab.x), elu_pick(yb.y, eb.y, ab.y)};
         }
         if (!(DBG & 64)) {
           // (quad_perm [1,0,3,2]: the neighbour's value; the compiler folds the move into v_cndmask_b32_dpp)
-          const float n00 = dpp_get<0xB1>(y00), n01 = dpp_get<0xB1>(y01), n10 = dpp_get<0xB1>(y10), n11 = dpp_get<0xB1>(y11);
-          const wf4 o = {ev ? y00 : n10, ev ? y01 : n11, ev ? n00 : y10, ev ? n01 : y11};
+          const float n00 = dpp_get<0xB1>(yt.x), n01 = dpp_get<0xB1>(yt.y), n10 = dpp_get<0xB1>(yb.x), n11 = dpp_get<0xB1>(yb.y);
+          const wf4 o = {ev ? yt.x : n10, ev ? yt.y : n11, ev ? n00 : yb.x, ev ? n01 : yb.y};
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rs_out, (DBG & 512) ? 0x80000000u : vo_x + coff, 0, 2);   // non-temporal: read back by the NEXT launch, long after it left the L2
         }
-        const float z00 = y00 * m00, z01 = y01 * m01, z10 = y10 * m10, z11 = y11 * m11;
-        s1[r] = (z00 + z01) + (z10 + z11);
-        s2[r] = fmaf(z00, z00, fmaf(z01, z01, fmaf(z10, z10, z11 * z11)));
+        const wf2 zt = pk_mul(yt, mt), zb = pk_mul(yb, mb);
+        const wf2 zs = pk_add(zt, zb), zq = pk_fma(zb, zb, pk_mul(zt, zt));
+        s1[r] = zs.x + zs.y;
+        s2[r] = zq.x + zq.y;
       });
       W_STAMP(11)
-      if (act && !(DBG & 128)) {
+      if (!(DBG & 128)) {
         const float x1 = reduce16_halfwave(s1, lane);
         const float x2 = reduce16_halfwave(s2, lane);
         if ((lane & 16) == 0) {
@@ -554,8 +586,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
       }
       }
       W_STAMP(12)
-      wfor<256>([&](auto i) __attribute__((always_inline)) { agpr_zero<decltype(i)::value>(); });
-      asm volatile("s_nop 4");
+      // (no zeroing: the next tile's first K-step starts its accumulators with C = 0 -- the POST == 2 chunk bodies; the
+      // ablation builds that skip the epilogue keep post = 0 and therefore the explicit pass)
+      if (DBG & (2 | 64)) {
+        wfor<256>([&](auto i) __attribute__((always_inline)) { agpr_zero<decltype(i)::value>(); });
+        asm volatile("s_nop 4");
+      }
       W_STAMP(13)
       kc = 0;
       qc += qstep;
@@ -571,10 +607,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
   }
 }
 
-// (Cin >= 24: every sample then contributes >= 3 consecutive chunks to a workgroup's stream, which is what the two-parity
+// (act: every DenseBlock conv is followed by ELU + InstanceNorm, model.py:444-445 -- the epilogue has no other form.
+// Cin >= 24: every sample then contributes >= 3 consecutive chunks to a workgroup's stream, which is what the two-parity
 // s_nrm table and the look-back of the DMA waits assume; the network's DenseBlock layers have 24 ... 192 input channels)
 bool conv_wino_ok(const ConvArgs& a) {
-  return a.Cin >= 3 * WCK && a.Cout <= 128 && a.sf == 1 && a.padf == 1 && !a.tr2 && a.Fin == a.Fout && (a.Cin % WCK) == 0 && a.Cin <= WNRM_MAX && !a.in_oct &&
+  return a.act && a.Cin >= 3 * WCK && a.Cout <= WCO_MAX && a.sf == 1 && a.padf == 1 && !a.tr2 && a.Fin == a.Fout && (a.Cin % WCK) == 0 && a.Cin <= WNRM_MAX && !a.in_oct &&
          !a.out_oct && a.ww != nullptr;
 }
 

@@ -42,6 +42,7 @@ struct ConvArgs {
   const float* bias;        // [ncg*COP]
   const unsigned short* w16; // bf16x3 path: packed [ncg][nchunk16][hi|lo][9][2][COP][8] bf16, or nullptr
   const void* ww6;          // bf16x6w path (conv_wino6.hip): the same weights as three bf16 pieces, [cg32][K-step of 16][xi][nu][piece][lane][8], or nullptr
+  const float* wsm;         // conv_few.hip (<= 4 output channels): [Cin][9 = kt * 3 + kf][4 co] conv-form taps, or nullptr
   const float* ww;          // f32w path (conv_wino.hip): Winograd-domain weights U = G g G^T, [cg32][chunk of 8][pos / 4][ci][32 co][pos % 4], or nullptr
   long long in_bstride;     // floats per sample of the input buffer
   long long out_bstride;
@@ -116,6 +117,10 @@ hipError_t conv_init();                      // dynamic-LDS attributes
 bool conv_wino_ok(const ConvArgs& a);
 hipError_t launch_conv_wino(const ConvArgs& a, int n_samples, hipStream_t s);
 hipError_t conv_wino_init();
+// <= 4 output channels, stride 1, no activation (the network's last layer) on the vector ALU (conv_few.hip; needs a.wsm)
+bool conv_few_ok(const ConvArgs& a);
+hipError_t launch_conv_few(const ConvArgs& a, int n_samples, hipStream_t s);
+hipError_t conv_few_init();
 bool conv_wino6_ok(const ConvArgs& a);
 hipError_t launch_conv_wino6(const ConvArgs& a, int n_samples, hipStream_t s);
 hipError_t conv_wino6_init();

@@ -115,6 +115,7 @@ struct ConvL {
   long long w6s_off = -1;           // first layer only: offset (floats) of the SHARED 3-part bf16 image [chunk][864 units]
   long long ww_off = -1;            // stride-1 same-padded layers: offset (floats) of the Winograd-domain weights (conv_wino.hip)
   long long ww6_off = -1;           // the same in three bf16 pieces (conv_wino6.hip)
+  long long wsm_off = -1;           // <= 4 output channels, no activation (the last layer): [Cin][9][4] image of conv_few.hip
   float wscale = 1.f;               // f16x3: power of two that brings max |W| of the layer to [32, 64)
 };
 
@@ -193,7 +194,7 @@ static ConvL make_conv(misonet_net* n, const std::string& prefix, int in_buf, in
   }
   L.wt = add_tensor(n, prefix + ".weight", (long long)Cin * Cout * 9);
   L.bt = add_tensor(n, prefix + ".bias", Cout);
-  L.cop = conv_cop(Cout);
+  L.cop = L.tr2 ? 32 : conv_cop(Cout);       // (conv3x3_mfma runs two output rows per wave on the stride-2 transposed layers)
   L.ncg = (Cout + L.cop - 1) / L.cop;
   return L;
 }
@@ -467,6 +468,7 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
   a.w16 = !planar_f32(n) ? reinterpret_cast<const unsigned short*>(n->w_dev + c.w16_off) : nullptr;
   a.ww = (n->precision == 5 && c.ww_off >= 0) ? n->w_dev + c.ww_off : nullptr;
   a.ww6 = (n->precision == 6 && c.ww6_off >= 0) ? n->w_dev + c.ww6_off : nullptr;
+  a.wsm = (planar_f32(n) && c.wsm_off >= 0) ? n->w_dev + c.wsm_off : nullptr;
   a.in_bstride = bstride(n, L, c.in_buf);
   a.out_bstride = bstride(n, L, c.out_buf);
   a.in_sstride = n->bufs[c.in_buf].C;
@@ -542,6 +544,7 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
   {
     ProfScope ps(s, PK_CONV);
     if (a.w16) HIPCHK(launch_conv_bf16(a, nb, s));
+    else if (a.wsm && conv_few_ok(a)) HIPCHK(launch_conv_few(a, nb, s));
     else if (a.ww && conv_wino_ok(a)) HIPCHK(launch_conv_wino(a, nb, s));
     else if (a.ww6 && conv_wino6_ok(a)) HIPCHK(launch_conv_wino6(a, nb, s));
     else HIPCHK(launch_conv(a, nb, s));
@@ -819,6 +822,24 @@ static void pack_conv_w6s(const misonet_net* n, const ConvL& c, std::vector<floa
           }
 }
 
+// conv_few.hip (the <= 4-channel last layer on the vector ALU): [ci][tap = kt * 3 + kf][4 co] conv-form taps, zero padded
+static void pack_conv_few(const misonet_net* n, const ConvL& c, std::vector<float>& arena) {
+  if (c.wsm_off < 0) return;
+  const std::vector<float>& W = n->tensors[c.wt].host;
+  float* img = arena.data() + c.wsm_off;
+  for (int ci = 0; ci < c.Cin; ++ci)
+    for (int kt = 0; kt < 3; ++kt)
+      for (int kf = 0; kf < 3; ++kf)
+        for (int co = 0; co < 4; ++co) {
+          float v = 0.f;
+          if (co < c.Cout) {
+            if (c.transposed) v = W[(((long long)ci * c.Cout + co) * 3 + (2 - kt)) * 3 + (2 - kf)];
+            else v = W[(((long long)co * c.Cin + ci) * 3 + kt) * 3 + kf];
+          }
+          img[((long long)ci * 9 + (kt * 3 + kf)) * 4 + co] = v;
+        }
+}
+
 // f32w path: Winograd-domain weights U = G g G^T of a stride-1 same-padded conv (conv_wino.hip), G = [1 0 0; .5 .5 .5; .5 -.5 .5;
 // 0 0 1]; position pos = xi * 4 + nu with xi along frequency (kf) and nu along time (kt).  Image order: [cg of 32 co][chunk of
 // 8 ci][pos / 4][ci][co][pos % 4], zero padded past Cout.  Computed in double, rounded once.  Positions with nu = 2 carry a
@@ -901,6 +922,7 @@ int misonet_net_commit(misonet_net* n) {
       // the DenseBlock convs (stride 1, same padding, Cin a multiple of 8): Winograd-domain image for the f32w mode
       if (!c.transposed && c.sf == 1 && c.padf == 1 && c.Cin % 8 == 0 && c.Cin <= 256)
         c.ww_off = take((long long)((c.Cout + 31) / 32) * (c.Cin / 8) * 16 * 8 * 32);
+      if (c.Cout <= 4 && c.sf == 1 && !c.tr2 && !c.act && c.Cin % 4 == 0 && c.Cin <= 256) c.wsm_off = take((long long)c.Cin * 36);
       if (!c.transposed && c.sf == 1 && c.padf == 1 && c.Cin % 8 == 0 && c.Cin >= 24 && c.Cin <= 256)
         c.ww6_off = take((long long)((c.Cout + 31) / 32) * ((c.Cin + 15) / 16) * (16 * 3 * 64 * 16 / 4));
     }
@@ -919,7 +941,7 @@ int misonet_net_commit(misonet_net* n) {
     }
   std::vector<float> arena((size_t)off, 0.f);
   for (ConvL& c : n->enc) { pack_conv(n, c, arena); pack_conv_bf16(n, c, arena); pack_conv_wf6(n, c, arena); pack_conv_w6s(n, c, arena); pack_conv_wino(n, c, arena); pack_conv_wino6(n, c, arena); }
-  for (ConvL& c : n->dec) { pack_conv(n, c, arena); pack_conv_bf16(n, c, arena); pack_conv_wf6(n, c, arena); pack_conv_wino(n, c, arena); pack_conv_wino6(n, c, arena); }
+  for (ConvL& c : n->dec) { pack_conv_few(n, c, arena); pack_conv(n, c, arena); pack_conv_bf16(n, c, arena); pack_conv_wf6(n, c, arena); pack_conv_wino(n, c, arena); pack_conv_wino6(n, c, arena); }
   for (const TcnBlock& tb : n->tcn)
     for (int h = 0; h < 2; ++h) {
       const TcnHalf& H = tb.h[h];
@@ -948,6 +970,7 @@ int misonet_net_commit(misonet_net* n) {
   HIPCHK(hipMemcpy(n->w_dev, arena.data(), arena.size() * sizeof(float), hipMemcpyHostToDevice));
   HIPCHK(conv_init());
   HIPCHK(conv_wino_init());
+  HIPCHK(conv_few_init());
   HIPCHK(conv_wino6_init());
   HIPCHK(conv_bf16_init());
   HIPCHK(conv_bf16_dma_init());
