@@ -95,7 +95,7 @@ __device__ __forceinline__ float exp2_ws(float x) {
 __device__ __forceinline__ float elu_pick(float y, float neg, float pos) {
   const int m = __builtin_bit_cast(int, y) >> 31;
   float r;
-  asm volatile("v_bfi_b32 %0, %1, %2, %3\n\ts_nop 1" : "=v"(r) : "v"(m), "v"(neg), "v"(pos));
+  asm volatile("v_bfi_b32 %0, %1, %2, %3\n\ts_nop 1" : "=v"(r) : "v"(m), "v"(neg), "v"(pos));   // (in C, LLVM folds it back into v_cmp + v_cndmask)
   return r;
 }
 // (x0 * n0 + n1, x1 * n0 + n1)
@@ -530,34 +530,39 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
         constexpr int kr = (r & 3) + 8 * (r >> 2);
         const unsigned coff = (unsigned)(cbase + kr) * P4;
         const wf2 bb = *W_LP(const wf2, tab_a + kr * 24);
+        // The packed arithmetic is written as VECTOR expressions, not asm: the compiler forms the v_pk_*_f32 itself (op_sel / neg
+        // modifiers folded) and knows that no wait state is needed between two of them -- behind every asm block it pads an s_nop,
+        // 13 per channel, and outside the MFMA shadow every instruction of a lone wave costs its ~4-cycle issue slot.
         wf2 E[4];
         wfor<4>([&](auto xc) __attribute__((always_inline)) {
           constexpr int x = decltype(xc)::value;
           const float m0 = agpr_get<(4 * x + 0) * 16 + r>(), m1 = agpr_get<(4 * x + 1) * 16 + r>();
           const float m2 = agpr_get<(4 * x + 2) * 16 + r>(), m3 = agpr_get<(4 * x + 3) * 16 + r>();
-          // (e0, e1) = (m0 + m1 + m2, m1 - m2 - m3) = (m1 + m2, m1 - m2) + (m0, -m3)
-          E[x] = pk_add_nh(pk_spm(wf2{m1, m2}), wf2{m0, m3});
+          // (e0, e1) = (m0 + m1 + m2, m1 - m2 - M3) = (m1 + m2, m1 - m2) + (m0, m3): the weight image carries a minus sign at
+          // nu = 3, so m3 = -M3 (and at xi = 3, so E[3] = -E3): the only mixed-sign step left is the one op_sel / neg instruction
+          // below (in C the compiler builds the (m2, -m2) pair with a v_xor)
+          E[x] = pk_spm(wf2{m1, m2}) + wf2{m0, m3};
         });
-        wf2 yt = pk_add(pk_add(E[0], E[1]), pk_add(E[2], bb));        // (y00, y01): row fa, frames t, t + 1
-        wf2 yb = pk_add(pk_sub(E[1], E[2]), pk_sub(bb, E[3]));        // (y10, y11): row fa + 1
+        wf2 yt = (E[0] + E[1]) + (E[2] + bb);                         // (y00, y01): row fa, frames t, t + 1
+        wf2 yb = (E[1] - E[2]) + (bb + E[3]);                         // (y10, y11): row fa + 1
         if (!(DBG & 256)) {
           // ELU(y) - c, c = ELU(bias):  y >= 0 ? y - c : exp(y) - (1 + c)   (elu_select's bit select on the sign of y)
           const wf2 ncr = *W_LP(const wf2, tab_a + kr * 24 + 8), nc1 = *W_LP(const wf2, tab_a + kr * 24 + 16);
-          const wf2 xt = pk_mul(yt, l2e), xb = pk_mul(yb, l2e);
-          const wf2 et = pk_add(wf2{exp2_ws(xt.x), exp2_ws(xt.y)}, nc1);
-          const wf2 eb = pk_add(wf2{exp2_ws(xb.x), exp2_ws(xb.y)}, nc1);
-          const wf2 at = pk_add(yt, ncr), ab = pk_add(yb, ncr);
+          const wf2 xt = yt * l2e, xb = yb * l2e;
+          const wf2 et = wf2{__builtin_amdgcn_exp2f(xt.x), __builtin_amdgcn_exp2f(xt.y)} + nc1;
+          const wf2 eb = wf2{__builtin_amdgcn_exp2f(xb.x), __builtin_amdgcn_exp2f(xb.y)} + nc1;
+          const wf2 at = yt + ncr, ab = yb + ncr;
           yt = wf2{elu_pick(yt.x, et.x, at.x), elu_pick(yt.y, et.y, at.y)};
           yb = wf2{elu_pick(yb.x, eb.x, ab.x), elu_pick(yb.y, eb.y, ab.y)};
         }
         if (!(DBG & 64)) {
-          // (quad_perm [1,0,3,2]: the neighbour's value; the compiler folds the move into v_cndmask_b32_dpp)
+          // (quad_perm [1,0,3,2]: the neighbour's value)
           const float n00 = dpp_get<0xB1>(yt.x), n01 = dpp_get<0xB1>(yt.y), n10 = dpp_get<0xB1>(yb.x), n11 = dpp_get<0xB1>(yb.y);
           const wf4 o = {ev ? yt.x : n10, ev ? yt.y : n11, ev ? n00 : yb.x, ev ? n01 : yb.y};
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rs_out, (DBG & 512) ? 0x80000000u : vo_x + coff, 0, 2);   // non-temporal: read back by the NEXT launch, long after it left the L2
         }
-        const wf2 zt = pk_mul(yt, mt), zb = pk_mul(yb, mb);
-        const wf2 zs = pk_add(zt, zb), zq = pk_fma(zb, zb, pk_mul(zt, zt));
+        const wf2 zt = yt * mt, zb = yb * mb;
+        const wf2 zs = zt + zb, zq = __builtin_elementwise_fma(zb, zb, zt * zt);
         s1[r] = zs.x + zs.y;
         s2[r] = zq.x + zq.y;
       });

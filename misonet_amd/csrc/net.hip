@@ -842,8 +842,10 @@ static void pack_conv_few(const misonet_net* n, const ConvL& c, std::vector<floa
 
 // f32w path: Winograd-domain weights U = G g G^T of a stride-1 same-padded conv (conv_wino.hip), G = [1 0 0; .5 .5 .5; .5 -.5 .5;
 // 0 0 1]; position pos = xi * 4 + nu with xi along frequency (kf) and nu along time (kt).  Image order: [cg of 32 co][chunk of
-// 8 ci][pos / 4][ci][co][pos % 4], zero padded past Cout.  Computed in double, rounded once.  Positions with nu = 2 carry a
-// minus sign: the kernel's packed input transform produces -V there (conv_wino.hip, pk_t23).
+// 8 ci][pos / 4][ci][co][pos % 4], zero padded past Cout.  Computed in double, rounded once.  Signs: positions with nu = 2
+// carry a minus because the kernel's packed input transform produces -V there (conv_wino.hip, pk_t23); positions with nu = 3
+// and positions with xi = 3 carry one each (both: none) so that the inverse transform A^T M A = sums with a single mixed-sign
+// step per row (conv_wino.hip epilogue: the accumulators hold -M there).
 static void pack_conv_wino(const misonet_net* n, const ConvL& c, std::vector<float>& arena) {
   if (c.ww_off < 0) return;
   const std::vector<float>& W = n->tensors[c.wt].host;
@@ -862,7 +864,8 @@ static void pack_conv_wino(const misonet_net* n, const ConvL& c, std::vector<flo
               for (int kt = 0; kt < 3; ++kt)
                 for (int kf = 0; kf < 3; ++kf)
                   u += G[xi][kf] * G[nu][kt] * (double)W[(((long long)co * c.Cin + ci) * 3 + kt) * 3 + kf];
-            img[(((((long long)cg * nchunk + kc) * 4 + (pos >> 2)) * 8 + cil) * 32 + col) * 4 + (pos & 3)] = (float)(nu == 2 ? -u : u);
+            const bool minus = (nu == 2) != ((nu == 3) != (xi == 3));
+            img[(((((long long)cg * nchunk + kc) * 4 + (pos >> 2)) * 8 + cil) * 32 + col) * 4 + (pos & 3)] = (float)(minus ? -u : u);
           }
         }
 }
