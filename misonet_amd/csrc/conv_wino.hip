@@ -382,24 +382,24 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
   // patch of the next step is fetched in slots 5-6 and transformed in the VALU group.  X1-X3: LDS writes of the previous
   // group's items; X7, X9-X11, X13, X14: norm entries and raw words for this group's items, or DMA pieces; XB: barrier (step
   // 3 only, after slot 3, in front of every access to the next chunk's stage); XG: this step's staging arithmetic.
-#define W_STEP(CS, FD_, FU_, FS, X1, X2, X3, XB, X7, X9, X10, X11, X13, X14, XG)                      \
-  W_MF(0, CS) W_FU(3, uc, CS) W_SB                                                                        \
-  W_MF(1, CS) X1 W_SB                                                                                     \
-  W_MF(2, CS) X2 W_SB                                                                                     \
-  W_MF(3, CS) X3 W_SB                                                                                     \
+#define W_STEP(CS, FD_, FU_, FS, X1, X2, X3, XB, X4, X5, X6, X7, X8, X9, X10, X11, X13, X14, XG)      \
+  W_MF(0, CS) W_FU(3, uc, CS) W_SB                                                                    \
+  W_MF(1, CS) X1 W_SB                                                                                 \
+  W_MF(2, CS) X2 W_SB                                                                                 \
+  W_MF(3, CS) X3 W_SB                                                                                 \
   XB                                                                                                  \
-  W_MF(4, CS) W_FU(0, FU_, FS) W_SB                                                                       \
-  W_MF(5, CS) W_FD(0, FD_) W_SB                                                                           \
-  W_MF(6, CS) W_FD(2, FD_) W_SB                                                                           \
-  W_MF(7, CS) X7 W_SB                                                                                     \
-  W_MF(8, CS) W_FU(1, FU_, FS) W_SB                                                                       \
-  W_MF(9, CS) X9 W_SB                                                                                     \
-  W_MF(10, CS) X10 W_SB                                                                                   \
-  W_MF(11, CS) X11 W_SB                                                                                   \
-  W_MF(12, CS) W_FU(2, FU_, FS) W_SB                                                                      \
-  W_MF(13, CS) X13 W_SB                                                                                   \
-  W_MF(14, CS) X14 W_SB                                                                                   \
-  W_MF(15, CS) W_SB                                                                                       \
+  W_MF(4, CS) W_FU(0, FU_, FS) X4 W_SB                                                                \
+  W_MF(5, CS) W_FD(0, FD_) X5 W_SB                                                                    \
+  W_MF(6, CS) W_FD(2, FD_) X6 W_SB                                                                    \
+  W_MF(7, CS) X7 W_SB                                                                                 \
+  W_MF(8, CS) W_FU(1, FU_, FS) X8 W_SB                                                                \
+  W_MF(9, CS) X9 W_SB                                                                                 \
+  W_MF(10, CS) X10 W_SB                                                                               \
+  W_MF(11, CS) X11 W_SB                                                                               \
+  W_MF(12, CS) W_FU(2, FU_, FS) W_SB                                                                  \
+  W_MF(13, CS) X13 W_SB                                                                               \
+  W_MF(14, CS) X14 W_SB                                                                               \
+  W_MF(15, CS) W_SB                                                                                   \
   W_TRANSFORM XG W_SB
 
   // Chunk g on the matrix pipe from stage ST.  Chunk g + 1: raw ring -> stage STN (the wave's own DMA of two iterations ago:
@@ -411,20 +411,51 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
   // epilogue (post = 2, 1) the waits that look across them allow 16 more -- a run-time threshold (wait_vm_le).  Measured:
   // waiting for the stores instead costs their HBM round trip per tile (the epilogue appeared twice as expensive), branching
   // between two s_waitcnt immediates 13 % of the chunk time in instruction fetch.
+  // The BOOKKEEPING of the chunk stream lives inside step 3 (round 6).  With one wave per SIMD nothing hides an instruction
+  // that is issued while the matrix pipe is idle: every one -- scalar, branch, LDS -- costs its ~4-cycle issue slot, and the
+  // ~110 instructions that used to sit between two chunk bodies (state hand-down L -> D -> C, stream advance, stage
+  // rotation, loop control) were 12 % of the kernel (timeline: 890 cycles between the last MFMA of a chunk and the first of
+  // the next, against 116 for a K-step's own VALU group).  Behind an MFMA, scalar instructions are free: the DMA issue is
+  // spread one piece per slot over slots 4-14 (two per slot cost 0.4 %: a DMA instruction takes ~30 cycles to issue, measured by
+  // ablation -- the 10 pieces are ~6 % of the kernel), the scalar bookkeeping (W_BK_S1 .. S3) rides in slot 14, the vector part (W_BK_V: the norm-address
+  // hand-down and the stage rotation -- VALU costs its time wherever it stands) joins the transform's VALU group.  What is left
+  // between two bodies: the tile-end test, the load-side tile change (once per tile) and the body dispatch.
+#define W_BK_S1 /* latch, scalar part; the chunk offset the vector part adds to the norm addresses */  \
+  const unsigned klo_ = (unsigned)(kl * WCK * 8);                                                     \
+  Cfull = Dfull; Dfull = Lfull;                                                                       \
+  Dwso = (unsigned)(Lcg * nchunk + kl) * (unsigned)(WW_FLOATS * 4);
+#define W_BK_S2 /* advance the load side (the tile change itself -- W_LOAD_SETUP -- stays behind the body) */ \
+  lslot ^= 1; ++kl;
+#define W_BK_S3 /* stage rotation deltas, loop state */                                               \
+  const unsigned dl_n_ = (ph3 == 1) ? 0u - 2u * STAGE_B : STAGE_B;      /* stage n = ph3 + 1 -> ph3 + 2 */ \
+  ph3 = ph3 == 2 ? 0 : ph3 + 1;                                                                       \
+  post = post > 0 ? post - 1 : 0;                                                                     \
+  cslot ^= 1;                                                                                         \
+  stnn = ph3 == 0 ? 2 : ph3 - 1;                       /* stage of the NEXT body's chunk g + 2 */     \
+  const unsigned rsl_ = cslot ? (unsigned)(WRAW_FLOATS * 4) : 0u;
+#define W_BK_V                                                                                        \
+  _Pragma("unroll") for (int i = 0; i < 6; ++i) { Cnr[i] = Dnr[i]; Dnr[i] = Lnr[i] + klo_; }          \
+  Cmask = Dmask; Dmask = Lmask;                                                                       \
+  d1 = d0n + STEP_B; d2 = d0n + 2 * STEP_B; d3 = d0n + 3 * STEP_B;                                    \
+  uc = un;                                                                                            \
+  d0n += dl_n_; un += dl_n_; cn += dl_n_;                                                             \
+  hn += hrole ? dl_n_ : 0u;                                                                           \
+  rofs = rofs0 + rsl_; rhofs = rhofs0 + rsl_;
 #define W_CHUNK_                                                                                      \
-  W_STEP(0, d1, uc, 1, W_NONE, W_NONE, W_NONE, W_NONE,                                                \
-         W_X(W_STAMP(1) if (POST) { W_VMCNT(26) } else { W_VMCNT(10) } W_STAMP(2) W_RR(rwa, 0)), W_X(W_RR(rwb, 1)), W_X(W_NR(nra, 0)), W_X(W_NR(nrb, 1)), W_NONE, W_NONE, \
+  W_STEP(0, d1, uc, 1, W_NONE, W_NONE, W_NONE, W_NONE, W_NONE, W_NONE, W_NONE,                        \
+         W_X(W_STAMP(1) if (POST) { W_VMCNT(26) } else { W_VMCNT(10) } W_STAMP(2) W_RR(rwa, 0)), W_NONE, W_X(W_RR(rwb, 1)), W_X(W_NR(nra, 0)), W_X(W_NR(nrb, 1)), W_NONE, W_NONE, \
          W_X(W_CC(cva, rwa, nra) W_CC(cvb, rwb, nrb)))                                                \
-  W_STEP(1, d2, uc, 2, W_X(W_CW(cva, 0)), W_X(W_CW(cvb, 1)), W_NONE, W_NONE,                          \
-         W_X(W_RR(rwa, 2)), W_X(W_RR(rwb, 3)), W_X(W_NR(nra, 2)), W_X(W_NR(nrb, 3)), W_NONE, W_NONE,  \
+  W_STEP(1, d2, uc, 2, W_X(W_CW(cva, 0)), W_X(W_CW(cvb, 1)), W_NONE, W_NONE, W_NONE, W_NONE, W_NONE,  \
+         W_X(W_RR(rwa, 2)), W_NONE, W_X(W_RR(rwb, 3)), W_X(W_NR(nra, 2)), W_X(W_NR(nrb, 3)), W_NONE, W_NONE,  \
          W_X(W_CC(cva, rwa, nra) W_CC(cvb, rwb, nrb)))                                                \
-  W_STEP(2, d3, uc, 3, W_X(W_CW(cva, 2)), W_X(W_CW(cvb, 3)), W_NONE, W_NONE,                          \
-         W_X(W_RR(rwa, 4)), W_X(W_RRH), W_X(W_NR(nra, 4)), W_X(W_NR(nrb, 5)), W_NONE, W_NONE,         \
+  W_STEP(2, d3, uc, 3, W_X(W_CW(cva, 2)), W_X(W_CW(cvb, 3)), W_NONE, W_NONE, W_NONE, W_NONE, W_NONE,  \
+         W_X(W_RR(rwa, 4)), W_NONE, W_X(W_RRH), W_X(W_NR(nra, 4)), W_X(W_NR(nrb, 5)), W_NONE, W_NONE, \
          W_X(W_CC(cva, rwa, nra) W_CCH(nrb)))                                                         \
   W_STEP(3, d0n, un, 0, W_X(W_CW(cva, 4)), W_X(W_CWH), W_NONE,                                        \
          W_STAMP(3) W_XW(if (POST == 2) { W_VMCNT(22) } else { W_VMCNT(6) }) W_STAMP(4) W_BARRIER W_STAMP(5), \
-         W_XW(W_ISSUE_W(0, stnn, Dwso) W_ISSUE_W(1, stnn, Dwso)), W_XW(W_ISSUE_W(2, stnn, Dwso) W_ISSUE_W(3, stnn, Dwso)), \
-         W_XL(W_ISSUE_I(0) W_ISSUE_I(1)), W_XL(W_ISSUE_I(2) W_ISSUE_I(3)), W_XL(W_ISSUE_I(4)), W_XL(W_ISSUE_H), W_NONE)
+         W_XW(W_ISSUE_W(0, stnn, Dwso)), W_XW(W_ISSUE_W(1, stnn, Dwso)), W_XW(W_ISSUE_W(2, stnn, Dwso)), W_XW(W_ISSUE_W(3, stnn, Dwso)), \
+         W_XL(W_ISSUE_I(0)), W_XL(W_ISSUE_I(1)), W_XL(W_ISSUE_I(2)), W_XL(W_ISSUE_I(3)), W_XL(W_ISSUE_I(4)),  \
+         W_XL(W_ISSUE_H) W_BK_S1 W_BK_S2 W_BK_S3, W_BK_V)
 
   // ---- prologue: raw chunks 0, 1, 2 and the U images of chunks 0, 1 on their way, chunk 0 staged, operands of (chunk 0,
   // step 0) fetched and transformed ----
@@ -468,23 +499,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
   int ph3 = 0;                                       // stage of chunk g = g mod 3
   int post = 0;                                      // iterations since a tile epilogue: 2, 1, then 0
   const unsigned G = ntile * (unsigned)nchunk;
+  int stnn = 2;                                      // stage of chunk g + 2 (the bodies keep it current)
   for (unsigned g = 0; g < G; ++g) {
     // six bodies: frame masks in the staging arithmetic or not (only the last column tile of an utterance stages frames that
     // do not exist) x the distance to the last tile epilogue (the immediates of two waits)
-    const int stnn = ph3 == 0 ? 2 : ph3 - 1;         // stage of chunk g + 2
     if (Cfull) {
       constexpr bool RAG = false;
       if (post == 0) { constexpr int POST = 0; W_CHUNK_ } else if (post == 1) { constexpr int POST = 1; W_CHUNK_ } else { constexpr int POST = 2; W_CHUNK_ }
     } else {
       constexpr bool RAG = true;
       if (post == 0) { constexpr int POST = 0; W_CHUNK_ } else if (post == 1) { constexpr int POST = 1; W_CHUNK_ } else { constexpr int POST = 2; W_CHUNK_ }
-    }
-    {                                                // every stage address moves one stage on (the one after ph3 + 1 for d0n, un, cn, hn)
-      const unsigned dl_n = (ph3 == 1) ? 0u - 2u * STAGE_B : STAGE_B;      // stage n = ph3 + 1 -> ph3 + 2
-      d1 = d0n + STEP_B; d2 = d0n + 2 * STEP_B; d3 = d0n + 3 * STEP_B;
-      uc = un;
-      d0n += dl_n; un += dl_n; cn += dl_n;
-      hn += hrole ? dl_n : 0u;
     }
     if (++kc == nchunk) {
       // ---- tile epilogue: Y = A^T M A per (channel, tile), + bias, ELU, centring, stores, statistics ----
@@ -600,15 +624,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
       W_STAMP(13)
       kc = 0;
       qc += qstep;
-      post = (DBG & (2 | 64)) ? 0 : 3;
+      post = (DBG & (2 | 64)) ? 0 : 2;               // (the body has already counted this iteration down)
     }
-    ph3 = ph3 == 2 ? 0 : ph3 + 1;
-    post = post > 0 ? post - 1 : 0;
-    W_LATCH
-    W_ADVANCE
-    cslot ^= 1;
-    rofs = cslot ? rofs0 + WRAW_FLOATS * 4 : rofs0;
-    rhofs = cslot ? rhofs0 + WRAW_FLOATS * 4 : rhofs0;
+    if (kl == nchunk) {                              // the load side has finished a tile (the body advanced kl)
+      if (ql + qstep < Q) { kl = 0; ql += qstep; W_LOAD_SETUP(ql) }
+      else kl = nchunk - 1;                          // end of the stream: the last chunk again (never consumed)
+    }
   }
 }
 
