@@ -11,12 +11,13 @@ A "step" = one pass of the complete reference semantics (6 x MISO_1 forward over
 shift alignment + clean alignment + 2 x MVDR + 2 x MISO_3 forward; reference tester.py:865-939) over one batch of
 synthetic 6-mic / 16 kHz / 4 s utterances (T = 1001 frames, F = 129) already resident in HBM.  Workload at N = 1 =
 BASELINE.json configs[3] (batch 16, full pipeline); at N = 8 = configs[4] (batch 128 = 8 x 16): utterances are sharded
-over ranks with no data-path collective (weak scaling; ``config.workload`` names what ran).  ``--verify-gather`` adds the
-path's one collective (all_gather of the results over RCCL) after the timed loop, checked by the oracle.  Prints ONE
-JSON line on rank 0.
+over ranks with no data-path collective (weak scaling; ``config.workload`` names what ran).  Every N > 1 line verifies itself
+(after the timed loop: each rank repeats its pass bit for bit, the results are all_gathered over RCCL -- the path's one
+collective -- checksummed per shard, and rank 0 checks an utterance of the LAST rank against the CPU oracle: ``parity``,
+``shard_checksums_match``, ``second_pass_bit_identical``; ``--no-verify-gather`` skips it).  Prints ONE JSON line on rank 0.
 
-The timed loop is un-instrumented.  The headline arithmetic is fp32-faithful (``HEADLINE_PRECISION``); the other
-arithmetic modes are timed beside it with the same steps / warm-up and reported under ``alt_precision``.
+The timed loop is un-instrumented.  The headline arithmetic is ``HEADLINE_PRECISION``; the other two product modes are timed
+beside it with the same steps / warm-up and reported under ``alt_precision``.
 
 Extra objects on the line:
   roofline     -- dominant kernel (the 3x3 conv launches, MFMA bound): algorithmic FLOPs / summed launch time, from a
@@ -49,10 +50,12 @@ ALGO_BYTES_PER_UTT = 6.23e9     # 8 forwards x 0.776 GB +
 # arithmetic of the 3x3 convs: name -> (dominant kernel, 16-bit MFMA products issued per algorithmic product, or 0 for
 # the f32 MFMA, operands exact float32?, significant bits per operand)
 MODES = {
+    # ---- the product library's three modes ----
     "f32":     ("conv3x3_mfma", 0, True, 24),            # v_mfma_f32_32x32x2_f32: exact f32, bitwise an fmaf chain
     "f32w":    ("conv3x3_wino_f32", 0, True, 24),        # f32 MFMA, DenseBlock convs in Winograd F(2x2, 3x3) form (conv_wino.hip)
-    "bf16x6w": ("conv3x3_wino_x6", 6, True, 24),         # bf16x6 arithmetic, DenseBlock convs in Winograd F(2x2, 3x3) form (conv_wino6.hip)
     "bf16x6":  ("conv3x3_bf16x6", 6, True, 24),          # operands split EXACTLY into 3 bf16 pieces, 6 leading terms
+    # ---- experiment build only (csrc: make exp; MISONET_LIB_PATH): measured alternatives that are not product modes ----
+    "bf16x6w": ("conv3x3_wino_x6", 6, True, 24),         # bf16x6 arithmetic, DenseBlock convs in Winograd F(2x2, 3x3) form (conv_wino6.hip)
     "f16x3":   ("conv3x3_bf16x3_dma2<F16>", 3, False, 22),   # 2 fp16 pieces (22 bits, "3xTF32"), 3 terms: measured at the
                                                          # f32 mode's error level, but the operands are rounded
     "bf16x3":  ("conv3x3_bf16x3_dma2", 3, False, 16),    # 2 bf16 pieces (16 bits), 3 terms: inside 1e-3, not fp32-faithful
@@ -267,7 +270,7 @@ def pmc_live(precision, B, T, timeout_s=150):
 
 def _traffic_entry(precision):
     """measured HBM bytes per conv launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/)"""
-    for name in ("r05_traffic.json", "r04z_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r06_traffic.json", "r05_traffic.json", "r04z_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", name)))
             if precision in tj:
@@ -307,7 +310,8 @@ def roofline_objects(precision, B, T, steps, dt_conv_ms, n_launch, live=None):
               "traffic_over_layout_bytes": round(traffic / (lay_step * steps / max(n_launch, 1)), 3) if traffic else None,
               "traffic_source": ("live: rocprofv3 --pmc passes of this script on this box (FETCH_SIZE x2 + WRITE_SIZE; "
                                  f"{live.get('conv_launches')} conv launches, {live.get('collect_seconds')} s)") if live
-              else ((tsrc + " (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, x2 fetch correction)") if tsrc else None),
+              else ((tsrc + " (committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of the N = 1 command on the builder's box, x2 "
+                             "fetch correction: NOT this run's counters)") if tsrc else None),
               # the three PMC-derived fields (traffic, mfma_busy_frac_pmc, clock_ghz_observed_pmc): live = counters of THIS
               # box at THIS tree (bench.py re-executes itself under rocprofv3 --pmc, one pass per counter group); otherwise
               # the committed measurement of the same command (another box / day), stamped with the commit it was taken at
@@ -351,12 +355,11 @@ def roofline_objects(precision, B, T, steps, dt_conv_ms, n_launch, live=None):
         r_mfma["frac_of_raw_16bit_peak"] = round(ach_tf / raw_peak, 4)
     r_hbm = dict(common, bound="hbm", achieved=round(ach_tb * 1e3, 1), peak=PEAK_HBM_TBS * 1e3, unit="GB/s",
                  frac=round(ach_tb / PEAK_HBM_TBS, 4))
-    # binding roofline: arithmetic intensity of the layer vs the ridge of the mode's effective matrix peak
-    # (Winograd modes: priced against the matrix roofline of their issued products like the direct modes they are compared with;
-    # their algorithmic intensity per ISSUED product sits on the ridge, 52 FLOP/B, and bf16x6w is bound by neither: DESIGN 3.4)
+    # binding roofline: arithmetic intensity of the layer vs the ridge of the mode's effective matrix peak (f32w: 107 FLOP/B against a
+    # ridge of 333 TF/s / 8 TB/s = 42); the other object is on the line as roofline_other
     eff_peak = mfma_peak
     ai = flops_step / bytes_step
-    binding = r_mfma if (wino or ai >= eff_peak * 1e12 / (PEAK_HBM_TBS * 1e12)) else r_hbm
+    binding = r_mfma if ai >= eff_peak * 1e12 / (PEAK_HBM_TBS * 1e12) else r_hbm
     return binding, (r_hbm if binding is r_mfma else r_mfma)
 
 
@@ -472,8 +475,9 @@ def main():
     ap.add_argument("--precision", choices=sorted(MODES), default=HEADLINE_PRECISION,
                     help="arithmetic of the 3x3 convs (default: the fp32-faithful headline mode)")
     ap.add_argument("--no-alt", action="store_true", help="skip the runs of the other precision modes (N = 1 only)")
-    ap.add_argument("--alt", default="f32,f32w,bf16x6w,bf16x6,f16x3,bf16x3",
-                    help="comma-separated precision modes timed beside the headline (alt_precision on the line)")
+    ap.add_argument("--alt", default="f32,f32w,bf16x6",
+                    help="comma-separated precision modes timed beside the headline (alt_precision on the line); the default is "
+                         "the product library's other two modes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--wav", action="store_true",
                     help="time the reference's real unit of work, wav in -> int16 wav out (HIP STFT front-end, pipeline, batched "
@@ -486,10 +490,15 @@ def main():
                     help="do not re-execute under rocprofv3 --pmc for the live counters of the roofline object (traffic, matrix-"
                          "pipe busy fraction, observed clock): ~2 min; the fields then come from profiles/*_traffic.json")
     ap.add_argument("--verify-gather", action="store_true",
-                    help="after the timed loop: all_gather every rank's enhanced spectrograms over the process group (RCCL "
-                         "on GPUs; 33 MB per rank at batch 16, SURVEY.md 8(e)) and let rank 0 check one utterance that came "
-                         "from the LAST rank against the CPU oracle; adds gather_ms / gather_parity to the line")
+                    help="after the timed loop: every rank repeats its pass (bit-identical?), all_gather of the enhanced "
+                         "spectrograms over the process group (RCCL on GPUs; 33 MB per rank at batch 16, SURVEY.md 8(e)), shard "
+                         "checksums, and rank 0 checks one utterance that came from the LAST rank against the CPU oracle "
+                         "(~3 s at 16 threads): parity / gather_parity / shard_checksums_match / second_pass_bit_identical on "
+                         "the line.  ON BY DEFAULT when N > 1 (a multi-GPU line without correctness evidence is not a result)")
+    ap.add_argument("--no-verify-gather", action="store_true", help="N > 1: skip the verification leg")
     args = ap.parse_args()
+    if args.gpus > 1 and not args.no_verify_gather:
+        args.verify_gather = True
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(relaunch_under_torchrun(args.gpus))
@@ -662,7 +671,8 @@ def main():
                 alts.append(a)
             m1.set_precision(args.precision)
             m3.set_precision(args.precision)
-            # The literal-float32 figures INSIDE the roofline object (the driver keeps that object whole): "exact_f32" = every
+            # The literal-float32 figures once more inside the roofline object (they are also alt_precision entries; the driver's
+            # parsed record keeps neither whole -- the stdout tail does): "exact_f32" = every
             # conv an fmaf chain on v_mfma_f32_32x32x2_f32 (the reference's own arithmetic, model.py:77-80, 401-416);
             # "winograd_f32" = the same matrix cores with the DenseBlock convs in Winograd F(2x2, 3x3) form.
             if roof is not None:
@@ -764,7 +774,12 @@ def main():
             "library": os.path.basename(_lib.LIB_PATH),
             "rccl_ranks": rccl_ranks, "per_rank_utt_per_s": [round(v, 3) for v in per_rank],
             "per_rank_utterances": rank_ranges, "backend": (backend if world > 1 else None),
-            "parity": (cpu or {}).pop("parity_of_headline", None) if cpu else None,
+            # N = 1: the oracle's utterances 0-3 against the timed batch (cpu_baseline's by-product); N > 1: the verification leg's
+            # oracle check of an utterance computed by the LAST rank
+            "parity": ((cpu or {}).pop("parity_of_headline", None) if cpu else
+                       ({"rel_l2_magnitudes_vs_oracle_by_utterance": {str(gather["gather_parity"]["utterance"]): gather["gather_parity"]["rel_l2_magnitudes_vs_oracle"]},
+                         "worst": gather["gather_parity"]["rel_l2_magnitudes_vs_oracle"], "tolerance": 1e-3,
+                         "checked_rank": gather["gather_parity"]["from_rank"]} if gather else None)),
             "roofline": roof, "roofline_other": roof2, "alt_precision": alts, "single_utterance": b1, "wav_path": wavp,
             "cpu_baseline": cpu,
         }
@@ -800,7 +815,8 @@ def cpu_baseline(sd1, sd3, T, gpu_out=None, gpu_pcm=None):
     """The oracle (kind "port": our stock-torch-CPU/NumPy restatement of the reference path, B = 1 per call as in
     tester.py:846-975) on this host's cores.  Bounded sample: one forward warm-up, one
     utterance at each of a ladder of thread counts (8 ... physical cores), then 3 different utterances end to end at
-    the fastest count (median reported, stages timed separately).  ``cores`` = the threads of the quoted value."""
+    the fastest count (median reported, stages timed separately).  ``cores`` = the host's physical cores, ``threads`` = the
+    thread count of the quoted value (B = 1 convolutions get SLOWER beyond 16-32 threads on the 2-socket boxes)."""
     from misonet_amd import weights as W
     from oracle import pipeline_oracle, miso_oracle
     logical = os.cpu_count() or 1
@@ -868,7 +884,7 @@ def cpu_baseline(sd1, sd3, T, gpu_out=None, gpu_pcm=None):
                     want = np.stack([pipeline_oracle.istft_int16(ref[s]) for s in range(ref.shape[0])])
                     lsb[str(u)] = int(np.abs(gpu_pcm[u].astype(np.int32) - want.astype(np.int32)).max())
             parity["wav_int16_max_abs_diff_lsb_by_utterance"] = lsb
-    return {"parity_of_headline": parity, "value": round(1.0 / med, 4), "unit": "utt/s", "cores": best, "kind": "port",
+    return {"parity_of_headline": parity, "value": round(1.0 / med, 4), "unit": "utt/s", "cores": physical, "threads": best, "kind": "port",
             "host_logical_cpus": logical, "host_physical_cores": physical, "usable_cpus": usable,
             "utt_per_s_by_threads": {str(c): round(1.0 / t, 4) for c, t in probes.items()},
             "stage_seconds_median": stage_med,

@@ -73,22 +73,12 @@ int misonet_net_commit(misonet_net* net);
  *               of a product, one float32 rounding); activations travel pre-split (oct3 layout: hi | mid | lo, 8 channels
  *               per 16-byte unit), the instance norm is folded into per-sample weights, staging is LDS-DMA.  Same error
  *               against the reference as mode 0 (2.3e-6 per forward) at 1.65 x its speed;
- *   4 "f16x3"   operands rounded to two fp16 pieces (22 bits; the weights carry a per-layer power-of-two scale), three
- *               terms, float32 accumulation: measured at or below mode 0's error on well-conditioned data (1.9e-6 per
- *               forward).  The raw first-layer output (un-normalised: its scale follows the input) stays in mode 3's exact
- *               layout and the dense block that reads it runs in mode 3's arithmetic; every other tensor is the output of
- *               layers with instance-normalised inputs.  Input range: the un-normalised output of that first dense block
- *               must stay inside fp16 (inputs up to ~1e4 x a unit-variance STFT; beyond: MISONET_ENAN, never silent);
- *   2 "bf16x3"  every product as w_hi*x_hi + w_hi*x_lo + w_lo*x_hi with 16-bit operands (2.4e-5 per forward, not
- *               fp32-faithful; loses |mean|/std of its accuracy when a layer's input has |mean| >> std), same dataflow
- *               with two parts -- the fastest mode;
- *   1 "bf16x3p" the arithmetic of mode 2 on planar float32 activations (normalise-on-load staging);
  *   5 "f32w"    (ABI 430) mode 0 with the DenseBlock convs (model.py:437-482: 94 % of the MACs) in Winograd F(2x2, 3x3) form:
  *               float32 products and sums on the same matrix cores, 2.25 x fewer of them (conv_wino.hip); measured 2.0e-6
  *               per forward against the reference (mode 0: 2.6e-6), 1.47 x mode 0's speed.  Same planar float32 layout.
- *   6 "bf16x6w" (ABI 440) the same Winograd form in the arithmetic of mode 3 (exact three-piece split, six partial products per
- *               Winograd-domain product; conv_wino6.hip).  fp32-faithful (1.8e-6), but SLOWER than mode 3 on MI355X: the split
- *               of the transformed operand is vector-ALU work of the consumer (0.8 x mode 3).  Kept as a measured alternative.
+ * Modes 1, 2 ("bf16x3": 16-bit operands), 4 ("f16x3": 22-bit operands) and 6 ("bf16x6w", ABI 440: the Winograd form in mode 3's
+ * arithmetic -- correct, 0.8 x mode 3's speed) are measured alternatives that are NOT product modes (ABI 450): only the experiment
+ * build of the library (csrc: `make exp`) contains them, the product library answers MISONET_EINVAL.
  * The choice is internal to the workspace (whose size depends on it: misonet_net_workspace_bytes must be asked again
  * after a change): inputs, outputs and taps are the same float32 / complex64 tensors in every mode. */
 int misonet_net_set_precision(misonet_net* net, int mode);

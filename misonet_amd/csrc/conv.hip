@@ -340,12 +340,14 @@ hipError_t conv_init() {
   if ((e = set_lds_attr<1, 0, 3>()) != hipSuccess) return e;
   if ((e = set_lds_attr<1, 2, 3>()) != hipSuccess) return e;
   if ((e = set_lds_attr<2, 0, 3>()) != hipSuccess) return e;
+#ifdef MISONET_EXPERIMENTS                         // (fp16-piece outputs: the f16x3 mode of the experiment build)
   if ((e = set_lds_attr<1, 0, 4>()) != hipSuccess) return e;
   if ((e = set_lds_attr<1, 2, 4>()) != hipSuccess) return e;
   if ((e = set_lds_attr<2, 0, 4>()) != hipSuccess) return e;
+  if ((e = set_lds_attr<1, 0, 4, true>()) != hipSuccess) return e;
+#endif
   if ((e = set_lds_attr<1, 0, 0, true>()) != hipSuccess) return e;
-  if ((e = set_lds_attr<1, 0, 3, true>()) != hipSuccess) return e;
-  return set_lds_attr<1, 0, 4, true>();
+  return set_lds_attr<1, 0, 3, true>();
 }
 
 int device_cus() {
@@ -390,8 +392,12 @@ hipError_t launch_conv(const ConvArgs& a_in, int n_samples, hipStream_t s) {
       if (a.cop == 32) { if (halfk) MN_LAUNCH_H(3); else if (mode == 0) MN_LAUNCH3(1, 0); else MN_LAUNCH3(1, 2); }
       else { if (mode == 0) MN_LAUNCH3(2, 0); else return hipErrorInvalidValue; }
     } else {
+#ifdef MISONET_EXPERIMENTS
       if (a.cop == 32) { if (halfk) MN_LAUNCH_H(4); else if (mode == 0) MN_LAUNCH4(1, 0); else MN_LAUNCH4(1, 2); }
       else { if (mode == 0) MN_LAUNCH4(2, 0); else return hipErrorInvalidValue; }
+#else
+      return hipErrorInvalidValue;
+#endif
     }
   } else if (a.cop == 32) {
     if (halfk) MN_LAUNCH_H(0); else if (mode == 0) MN_LAUNCH(1, 0); else if (mode == 1) MN_LAUNCH(1, 1); else if (mode == 2) MN_LAUNCH(1, 2); else MN_LAUNCH(1, 3);

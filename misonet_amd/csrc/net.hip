@@ -162,6 +162,15 @@ struct misonet_net {
                                  // default: fp32-faithful, what bench.py reports), 4: f16x3 DMA dataflow, 5: f32 MFMA with the
                                  // dense-block convs in Winograd F(2x2, 3x3) form ("f32w": planar float32 layout like mode 0)
 };
+// Product arithmetic modes: 0 "f32", 3 "bf16x6", 5 "f32w".  The measured alternatives that earn nothing (1 / 2 "bf16x3": 16-bit
+// operands, 4 "f16x3": 22-bit operands, 6 "bf16x6w": correct but slower than mode 3 -- DESIGN 3.4) exist only in the experiment
+// build (`make exp`): their kernels (conv_bf16.hip, conv_bf16_dma.hip, conv_wino6.hip), weight images and dispatch are compiled
+// out of the product library, which answers MISONET_EINVAL to them.
+#ifdef MISONET_EXPERIMENTS
+#define MN_ALT_MODES 1
+#else
+#define MN_ALT_MODES 0
+#endif
 // the planar-float32 modes: every activation buffer is float32 [c][f][Tp], instance norm applied while staging
 static inline bool planar_f32(const misonet_net* n) { return n->precision == 0 || n->precision == 5 || n->precision == 6; }
 
@@ -465,9 +474,9 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
   a.out_stats = stats_ptr(L, ws, c.out_buf);
   a.w = n->w_dev + c.w_off;
   a.bias = n->w_dev + c.b_off;
-  a.w16 = !planar_f32(n) ? reinterpret_cast<const unsigned short*>(n->w_dev + c.w16_off) : nullptr;
+  a.w16 = (MN_ALT_MODES && !planar_f32(n)) ? reinterpret_cast<const unsigned short*>(n->w_dev + c.w16_off) : nullptr;
   a.ww = (n->precision == 5 && c.ww_off >= 0) ? n->w_dev + c.ww_off : nullptr;
-  a.ww6 = (n->precision == 6 && c.ww6_off >= 0) ? n->w_dev + c.ww6_off : nullptr;
+  a.ww6 = (MN_ALT_MODES && n->precision == 6 && c.ww6_off >= 0) ? n->w_dev + c.ww6_off : nullptr;
   a.wsm = (planar_f32(n) && c.wsm_off >= 0) ? n->w_dev + c.wsm_off : nullptr;
   a.in_bstride = bstride(n, L, c.in_buf);
   a.out_bstride = bstride(n, L, c.out_buf);
@@ -528,6 +537,7 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
     HIPCHK(launch_conv_bf16x6(a, nb, s));
     return MISONET_OK;
   }
+#if MN_ALT_MODES
   if (a.in_oct) {
     a.wps = reinterpret_cast<char*>(ws) + L.wps_base + (long long)n0 * L.wps_nstride;
     a.wps_nstride = L.wps_nstride;
@@ -541,12 +551,18 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
     HIPCHK(launch_conv_bf16_dma(a, nb, s));
     return MISONET_OK;
   }
+#else
+  if (a.in_oct) return fail(MISONET_EINVAL, "activation layout %d exists only in the experiment build", a.in_oct);
+#endif
   {
     ProfScope ps(s, PK_CONV);
+#if MN_ALT_MODES
     if (a.w16) HIPCHK(launch_conv_bf16(a, nb, s));
-    else if (a.wsm && conv_few_ok(a)) HIPCHK(launch_conv_few(a, nb, s));
-    else if (a.ww && conv_wino_ok(a)) HIPCHK(launch_conv_wino(a, nb, s));
     else if (a.ww6 && conv_wino6_ok(a)) HIPCHK(launch_conv_wino6(a, nb, s));
+    else
+#endif
+    if (a.wsm && conv_few_ok(a)) HIPCHK(launch_conv_few(a, nb, s));
+    else if (a.ww && conv_wino_ok(a)) HIPCHK(launch_conv_wino(a, nb, s));
     else HIPCHK(launch_conv(a, nb, s));
   }
   return MISONET_OK;
@@ -655,7 +671,7 @@ const char* misonet_strerror(int code) {
   }
 }
 const char* misonet_last_error(void) { return g_err; }
-int misonet_version(void) { return 440; }   // 410: misonet_pipeline_create accepts miso3 == NULL (separation-only pipeline); 420: misonet_istft; 430: misonet_frontend_init, precision mode 5 (f32w); 440: precision mode 6 (bf16x6w)
+int misonet_version(void) { return 450; }   // 450: product modes 0 / 3 / 5 only (1, 2, 4, 6: experiment build); 410: misonet_pipeline_create accepts miso3 == NULL (separation-only pipeline); 420: misonet_istft; 430: misonet_frontend_init, precision mode 5 (f32w); 440: precision mode 6 (bf16x6w)
 
 int misonet_net_create(const misonet_cfg* cfg, misonet_net** out) {
   if (!cfg || !out) return fail(MISONET_EINVAL, "null argument");
@@ -737,6 +753,7 @@ static inline float bf16_to_f32(unsigned short h) {
 
 // bf16x3 path: [cg][chunk of 16 ci][hi|lo][tap][octet h][COP][8] bf16 (conv_bf16.hip)
 static void pack_conv_bf16(const misonet_net* n, ConvL& c, std::vector<float>& arena) {
+  if (!MN_ALT_MODES) return;
   const std::vector<float>& W = n->tensors[c.wt].host;
   {
     // f16x3: a static power of two per layer brings max |W| to [32, 64): with rstd in [2^-6, 2^9] the folded weights
@@ -916,8 +933,10 @@ int misonet_net_commit(misonet_net* n) {
       const int nchunk = (c.Cin + CK - 1) / CK;
       c.w_off = take((long long)c.ncg * nchunk * 9 * CK * c.cop);
       c.b_off = take((long long)c.ncg * c.cop);
-      c.w16_off = take((long long)((c.Cout + 31) / 32) * ((c.Cin + 15) / 16) * 2 * 9 * 2 * 32 * 8 / 2);   // u16 -> floats
-      c.wf_off = take((long long)((c.Cout + 31) / 32) * ((c.Cin + 15) / 16) * 9 * 2 * 32 * 8);
+      if (MN_ALT_MODES) {
+        c.w16_off = take((long long)((c.Cout + 31) / 32) * ((c.Cin + 15) / 16) * 2 * 9 * 2 * 32 * 8 / 2);   // u16 -> floats
+        c.wf_off = take((long long)((c.Cout + 31) / 32) * ((c.Cin + 15) / 16) * 9 * 2 * 32 * 8);
+      }
       c.wf6_off = take((long long)((c.Cout + 31) / 32) * ((c.Cin + 7) / 8) * 9 * 32 * 8);
       // the first layer (planar network input, consumed un-normalised, <= 16 in / <= 32 out channels): shared 3-part image
       if (c.in_buf == B_IN && !c.transposed && c.sf == 1 && c.Cin <= 16 && c.Cout <= 32 && c.ident_c >= c.Cin)
@@ -926,7 +945,7 @@ int misonet_net_commit(misonet_net* n) {
       if (!c.transposed && c.sf == 1 && c.padf == 1 && c.Cin % 8 == 0 && c.Cin <= 256)
         c.ww_off = take((long long)((c.Cout + 31) / 32) * (c.Cin / 8) * 16 * 8 * 32);
       if (c.Cout <= 4 && c.sf == 1 && !c.tr2 && !c.act && c.Cin % 4 == 0 && c.Cin <= 256) c.wsm_off = take((long long)c.Cin * 36);
-      if (!c.transposed && c.sf == 1 && c.padf == 1 && c.Cin % 8 == 0 && c.Cin >= 24 && c.Cin <= 256)
+      if (MN_ALT_MODES && !c.transposed && c.sf == 1 && c.padf == 1 && c.Cin % 8 == 0 && c.Cin >= 24 && c.Cin <= 256)
         c.ww6_off = take((long long)((c.Cout + 31) / 32) * ((c.Cin + 15) / 16) * (16 * 3 * 64 * 16 / 4));
     }
   };
@@ -974,9 +993,11 @@ int misonet_net_commit(misonet_net* n) {
   HIPCHK(conv_init());
   HIPCHK(conv_wino_init());
   HIPCHK(conv_few_init());
+#if MN_ALT_MODES
   HIPCHK(conv_wino6_init());
   HIPCHK(conv_bf16_init());
   HIPCHK(conv_bf16_dma_init());
+#endif
   HIPCHK(conv_bf16x6_init());
   { int rf = frontend_init(); if (rf) return rf; }     // STFT / iSTFT tables: never allocated inside an asynchronous call
   n->committed = true;
@@ -985,9 +1006,11 @@ int misonet_net_commit(misonet_net* n) {
 
 int misonet_net_set_precision(misonet_net* n, int mode) {
   if (!n) return fail(MISONET_EINVAL, "null argument");
-  if (mode < 0 || mode > 6)
-    return fail(MISONET_EINVAL, "precision mode must be 0 (f32), 1 (bf16x3, planar), 2 (bf16x3, DMA dataflow), 3 (bf16x6), 4 (f16x3) or "
-                                "5 (f32w: f32 with Winograd dense-block convs) or 6 (bf16x6w: the same convs in bf16x6 arithmetic)");
+  const bool product = (mode == 0 || mode == 3 || mode == 5);
+  if (!product && !(MN_ALT_MODES && mode >= 1 && mode <= 6))
+    return fail(MISONET_EINVAL, "precision mode must be 0 (f32), 3 (bf16x6) or 5 (f32w: f32 with the dense-block convs in Winograd form)%s",
+                MN_ALT_MODES ? "; experiment build: also 1 / 2 (bf16x3), 4 (f16x3), 6 (bf16x6w)"
+                             : "; modes 1, 2, 4, 6 exist only in the experiment build (make exp)");
   n->precision = mode;
   return MISONET_OK;
 }

@@ -96,21 +96,24 @@ class _Trunk:
         return self
 
     PRECISIONS = {"f32": 0, "bf16x3p": 1, "bf16x3": 2, "bf16x6": 3, "f16x3": 4, "f32w": 5, "bf16x6w": 6}
+    PRODUCT_PRECISIONS = ("f32", "f32w", "bf16x6")     # the others exist only in the experiment build (csrc: make exp)
 
     def set_precision(self, mode: str):
-        """Arithmetic of the 3x3 convolutions: "bf16x6" (the default; fp32-faithful: both operands split EXACTLY into
-        three bf16 pieces, the six leading partial products on the bf16 matrix cores with f32 accumulation -- same
-        accuracy class as "f32" at 2.67x its matrix rate, conv_bf16x6.hip), "f32" (exact float32 matrix cores), "f32w" (float32
-        matrix cores with the DenseBlock convs -- 94 % of the MACs -- in Winograd F(2x2, 3x3) form: 2.25x fewer matrix
-        instructions, float32 products and sums throughout, conv_wino.hip), "f16x3"
-        (operands rounded to two fp16 pieces = 22 bits, three terms, f32 accumulation: the "3xTF32" scheme; measured at the
-        f32 mode's error level, at the cost of "bf16x3"; activations must stay inside fp16's range), "bf16x3" (three-term bf16
-        split on the bf16 matrix cores, f32 accumulation, ~1e-5 relative per layer; activations travel pre-split in the
-        oct layout and are staged by LDS-DMA, conv_bf16_dma.hip) or "bf16x3p" (same arithmetic on planar float32
-        activations with normalise-on-load staging, conv_bf16.hip)."""
+        """Arithmetic of the 3x3 convolutions (99.4 % of the FLOPs; the reference computes them in float32, model.py:77-80):
+        "f32w" -- float32 matrix cores with the DenseBlock convs (94 % of the MACs) in Winograd F(2x2, 3x3) form: float32
+        products and sums throughout, 2.25x fewer matrix instructions (conv_wino.hip); "f32" -- the same matrix cores in the
+        direct form (bitwise an fmaf chain, conv.hip); "bf16x6" (the default of a new handle) -- fp32-faithful on the bf16 matrix
+        cores: both operands split EXACTLY into three bf16 pieces, the six leading partial products accumulated in float32
+        (conv_bf16x6.hip).  The measured alternatives "bf16x3" / "bf16x3p" (16-bit operands), "f16x3" (22-bit operands) and
+        "bf16x6w" (Winograd in the bf16x6 arithmetic: correct, slower than "bf16x6") are not product modes: they are compiled
+        only into the experiment library (`make exp`, loaded through MISONET_LIB_PATH)."""
         if mode not in self.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}")
-        _lib.check(_lib.lib().misonet_net_set_precision(self._net, self.PRECISIONS[mode]))
+        rc = _lib.lib().misonet_net_set_precision(self._net, self.PRECISIONS[mode])
+        if rc != 0 and mode not in self.PRODUCT_PRECISIONS:
+            raise ValueError(f"precision {mode!r} exists only in the experiment build of the library (csrc: `make exp`, "
+                             f"MISONET_LIB_PATH=.../libmisonet_hip_exp.so); product modes: {self.PRODUCT_PRECISIONS}")
+        _lib.check(rc)
         if mode != self.precision:
             self._ws.clear()           # the workspace layout (and size) depends on the arithmetic mode
         self.precision = mode

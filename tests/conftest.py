@@ -21,6 +21,20 @@ def pytest_configure(config):
         pass
 
 
+# Arithmetic modes: the product library has "f32", "f32w", "bf16x6"; the measured alternatives ("bf16x3", "bf16x3p", "f16x3",
+# "bf16x6w") exist only in the experiment build (csrc: make exp) and their tests run only when that library is loaded.
+PRODUCT_MODES = ("f32", "f32w", "bf16x6")
+ALT_MODES_BUILT = os.environ.get("MISONET_LIB_PATH", "").endswith("_exp.so")
+
+
+def modes(*names):
+    """the subset of `names` that the loaded library implements"""
+    return [m for m in names if m in PRODUCT_MODES or ALT_MODES_BUILT]
+
+
+needs_alt_modes = pytest.mark.skipif(not ALT_MODES_BUILT, reason="mode of the experiment build (MISONET_LIB_PATH=.../libmisonet_hip_exp.so)")
+
+
 def golden(name):
     return np.load(os.path.join(GOLDEN, name))
 

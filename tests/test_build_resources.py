@@ -23,7 +23,8 @@ HOT = [
     "mn::conv3x3_mfma<1, 0, 0, true>", "mn::conv3x3_mfma<1, 0, 3, true>",          # first layer (12 input channels)
     "mn::conv3x3_mfma<1, 0, 3, false>",                                            # (first layer on the f32 kernel: MISONET_X6_FIRST=0)
     "mn::conv3x3_wino_f32<0>",                                                     # f32w: the DenseBlock convs (Winograd F(2x2, 3x3))
-    "mn::conv3x3_wino_x6<0>",                                                      # bf16x6w: the same convs in bf16x6 arithmetic
+    "mn::conv3x3_few<4>", "mn::conv3x3_few<2>",                                    # the 4- / 2-channel last layer on the vector ALU (f32, f32w)
+    "mn::conv3x3_mfma<1, 3, 0, false>", "mn::conv3x3_mfma<2, 3, 0, false>",        # decoder 0 on the single bottleneck row
     "mn::conv3x3_x6_first<3>", "mn::conv3x3_x6_first<4>",                          # first layer in bf16x6 (round 4)
     "mn::conv3x3_bf16x6<0, 8, false, 4, false, false, 0>", "mn::conv3x3_bf16x6<0, 8, false, 3, false, false, 0>",    # 38 % + 28 % of the bf16x6 step
     "mn::conv3x3_bf16x6<0, 8, false, 4, false, true, 0>",                             # F <= 31 layers (two statistic units)
@@ -42,10 +43,8 @@ HOT = [
 # the opt-in modes / of shapes this network does not have.  A number going UP here is a regression too.
 TOLERATED = {
     "mn::conv3x3_mfma<2, 0, 3, false>": 64, "mn::conv3x3_mfma<2, 0, 4, false>": 32,      # 64-channel planar-in / oct-out: unused
-    "mn::conv3x3_mfma<2, 2, 0, false>": 400, "mn::conv3x3_mfma<2, 2, 3, false>": 480,    # stride-2 transposed, > 32 channels: unused
-    "mn::conv3x3_mfma<2, 2, 4, false>": 320,
-    "mn::conv3x3_bf16x6<0, 8, true, 4, false, false, 0>": 224,                                     # f16x3 hand-over layer (alt mode)
-    "mn::conv3x3_bf16x3<2, 1>": 32,                                                      # bf16x3p (alt mode)
+    "mn::conv3x3_mfma<1, 2, 3, false>": 28,                                              # row-pair transposed tile writing oct3: MISONET_X6_FIRST=0 runs only
+    "mn::conv3x3_bf16x6<0, 8, true, 4, false, false, 0>": 224,                                     # fp16-piece hand-over layer: experiment-build mode f16x3 only
     "mn::mvdr_scm_eig<8>": 600,                                                          # M = 8 microphones (tests only)
 }
 
@@ -55,7 +54,7 @@ def table():
     subprocess.run(["make", "-C", os.path.join(ROOT, "misonet_amd", "csrc"), "-j4"], check=True, stdout=subprocess.DEVNULL)
     import kernel_resources
     t = kernel_resources.parse()
-    assert len(t) >= 80, f"only {len(t)} kernels in build/*.res: was the library built by this Makefile?"
+    assert len(t) >= 60, f"only {len(t)} kernels in build/*.res: was the library built by this Makefile?"
     return t
 
 
@@ -128,36 +127,3 @@ def test_wino_kernel_register_files(table):
     assert total == own and total >= 512, (total, own)          # 256 reads in the epilogue + 2 x 256 zeroing writes
     assert dma >= 6 * 10, dma                                   # six chunk bodies x (4 U-image + 6 raw-input pieces)
     assert not any("flat_load" in ln or "flat_store" in ln or "scratch_" in ln for ln in asm)
-
-
-def test_wino6_kernel_register_files(table):
-    """conv3x3_wino_x6 (bf16x6w): the same fixed-AGPR discipline as the f32 Winograd kernel -- all 256 AGPRs, one wave per SIMD,
-    no VGPR spill (a scratch access is a VMEM instruction: it would sit in the in-order queue the hand-written s_waitcnt
-    vmcnt(N) of the row loop count), no compiler-generated v_accvgpr_*, and the only full vmcnt(0) waits are the prologue's."""
-    r = table["mn::conv3x3_wino_x6<0>"]
-    assert r["agprs"] == 256 and r["vgprs"] <= 256 and r["occupancy"] == 1, r
-    assert r["vgpr_spill"] == 0 and r["scratch"] == 0, r
-    csrc = os.path.join(ROOT, "misonet_amd", "csrc")
-    asm = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-S",
-                          "--cuda-device-only", "conv_wino6.hip", "-o", "-"], cwd=csrc, check=True, capture_output=True,
-                         text=True).stdout.splitlines()
-    inside, own, total, mfma, pk = False, 0, 0, 0, 0
-    for ln in asm:
-        t = ln.strip()
-        if t.startswith(";;#ASMSTART"):
-            inside = True
-        elif t.startswith(";;#ASMEND"):
-            inside = False
-        elif t.startswith("v_accvgpr"):
-            total += 1
-            own += inside
-        elif t.startswith("v_mfma_f32_32x32x16_bf16"):
-            mfma += 1
-        elif t.startswith("v_pk_") and "f32" in t:
-            pk += 1
-    assert total == own and total >= 512, (total, own)
-    assert mfma == 2 * 96, mfma                                 # the row loop with and without frame masks, nothing else
-    # packed fp32 instructions of the SAME wave stall behind its bf16 MFMAs (tools/micro/mfma_bf16_valu.hip: 12 cycles each):
-    # the row loop must not contain any (-fno-slp-vectorize; the epilogue is outside the MFMA stream)
-    assert not any("scratch_" in ln for ln in asm)
-    assert pk == 0 or pk < 200, pk

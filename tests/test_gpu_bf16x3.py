@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden, rel_l2, mag_parity
+from conftest import golden, rel_l2, mag_parity, modes
 from test_gpu_parity import _assert_parity, _utt_inputs, _need_gpu
 
 pytestmark = pytest.mark.gpu
@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 # "bf16x3": oct-layout activations, instance norm folded into per-sample weights, LDS-DMA staging (conv_bf16_dma.hip);
 # "bf16x3p": planar float32 activations, normalise-on-load staging (conv_bf16.hip)
-@pytest.fixture(scope="module", params=["bf16x6", "f16x3", "bf16x3", "bf16x3p"])
+@pytest.fixture(scope="module", params=modes("bf16x6", "f16x3", "bf16x3", "bf16x3p"))
 def nets_bf(request, sd1, sd3):
     _need_gpu()
     PREC = request.param

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden, rel_l2, mag_parity
+from conftest import golden, rel_l2, mag_parity, modes
 from test_gpu_parity import _assert_parity, _utt_inputs, _need_gpu
 
 pytestmark = pytest.mark.gpu
@@ -21,8 +21,7 @@ MODE_TOL = {"f32": 4e-5, "f32w": 4e-5, "bf16x6": 4e-5, "bf16x6w": 4e-5, "f16x3":
 
 
 def _modes():
-    from misonet_amd.model import _Trunk
-    return [m for m in ("f32", "f32w", "bf16x6", "bf16x6w", "f16x3", "bf16x3") if m in _Trunk.PRECISIONS]
+    return modes("f32", "f32w", "bf16x6", "bf16x6w", "f16x3", "bf16x3")
 
 
 @pytest.fixture(scope="module")
@@ -37,7 +36,7 @@ def bench_batch(sd1, sd3):
     return mix, clean, refs
 
 
-@pytest.mark.parametrize("mode", ["f32", "f32w", "bf16x6", "bf16x6w", "f16x3", "bf16x3"])
+@pytest.mark.parametrize("mode", modes("f32", "f32w", "bf16x6", "bf16x6w", "f16x3", "bf16x3"))
 def test_full_size_batch16_pipeline_vs_oracle(bench_batch, sd1, sd3, mode):
     import misonet_amd as mz
     from misonet_amd import weights as W
@@ -170,16 +169,18 @@ def test_folded_norm_ill_conditioned_statistics(sd1, dc, bias_sigma):
     print(f"[ill-conditioned dc={dc} bias_sigma={bias_sigma}] error vs float64 truth: " +
           "  ".join(f"{k} {v:.3e}" for k, v in err.items()))
     # yardstick: the exact-f32 MFMA mode of this library under the same conditioning (the float32 oracle is reported too)
-    assert np.isfinite(err["f32"]) and np.isfinite(err["bf16x6"]) and np.isfinite(err["bf16x3"]), err
+    assert all(np.isfinite(v) for v in err.values()), err
     assert err["bf16x6"] <= 4.0 * err["f32"] + 2e-6, err
     # Winograd's transforms add rounding steps with cancellation: under bad conditioning it may sit above the direct form, not
     # beyond the float32 class
     assert np.isfinite(err["f32w"]) and err["f32w"] <= 6.0 * err["f32"] + 4e-6, err
 
 
-def test_large_batch_offsets_beyond_4_gib(sd1, sd3):
+@pytest.mark.parametrize("mode", ["bf16x6", "f32w"])
+def test_large_batch_offsets_beyond_4_gib(sd1, sd3, mode):
     """40 utterances at T = 1001 (a 64 GB workspace: sample blocks far beyond 32-bit byte offsets) -- two distinct utterances
-    repeated: every copy returns the bits of the first one (exact statistics, per-sample blocks), wherever it sits."""
+    repeated: every copy returns the bits of the first one (exact statistics, per-sample blocks), wherever it sits.  In the
+    library default and in "f32w" (the persistent Winograd kernel walks 240 / 80 samples with its own descriptors)."""
     _need_gpu()
     import misonet_amd as mz
     from misonet_amd import weights as W
@@ -189,7 +190,7 @@ def test_large_batch_offsets_beyond_4_gib(sd1, sd3):
     m1.load_state_dict(sd1)
     m3 = mz.MISO_3(1, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN").cuda(0)
     m3.load_state_dict(sd3)
-    enh = mz.Enhancer(m1.eval(), m3.eval(), num_spks=2, ref_ch=0)
+    enh = mz.Enhancer(m1.eval().set_precision(mode), m3.eval().set_precision(mode), num_spks=2, ref_ch=0)
     a, b = _utt_inputs(1, 1001), _utt_inputs(2, 1001)
     mix = torch.from_numpy(np.stack([a[0], b[0]])).cuda().repeat(20, 1, 1, 1)
     clean = torch.from_numpy(np.stack([a[1], b[1]])).cuda().repeat(20, 1, 1, 1)

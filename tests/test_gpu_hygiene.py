@@ -6,7 +6,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 import torch
 
-from conftest import golden, rel_l2
+from conftest import golden, rel_l2, modes, needs_alt_modes
 from test_gpu_parity import _assert_parity, _utt_inputs, _need_gpu
 
 pytestmark = pytest.mark.gpu
@@ -68,7 +68,7 @@ def test_long_utterance_no_frame_limit(sd1):
     y_ref = miso_oracle.miso1_forward(torch.from_numpy(mx[None]), sd1).numpy()
     _assert_parity(y.cpu().numpy(), y_ref, "miso1 T=2500 vs oracle")
     m1.keep_activations(False)
-    for mode in ("f32w", "bf16x6w"):                   # the persistent Winograd kernels: 40 column tiles per row tile, the last one ragged
+    for mode in modes("f32w", "bf16x6w"):            # the persistent Winograd kernels: 40 column tiles per row tile, the last one ragged
         m1.set_precision(mode)
         _assert_parity(m1(torch.from_numpy(mx[None]).cuda()).cpu().numpy(), y_ref, f"miso1 T=2500 vs oracle [{mode}]")
     m1.set_precision("bf16x6")
@@ -120,7 +120,7 @@ def test_device_handling(sd1, sd3):
     assert y0.shape == (1, 2, 8, 129)
 
 
-@pytest.mark.parametrize("mode", ["f32", "f32w", "bf16x6", "bf16x6w", "f16x3", "bf16x3"])
+@pytest.mark.parametrize("mode", modes("f32", "f32w", "bf16x6", "bf16x6w", "f16x3", "bf16x3"))
 def test_one_chunk_layers(mode):
     """8-channel dense-block growth: layers of ONE and TWO 8-channel K-chunks (the bf16x6 producers fold the set-up of the
     coming tile into fewer iterations there) and output groups of 8 channels."""
@@ -140,7 +140,7 @@ def test_one_chunk_layers(mode):
     _assert_parity(y, ref, f"[{mode}] 8-channel growth (en={en})")
 
 
-@pytest.mark.parametrize("mode", ["f32", "f32w", "bf16x6", "bf16x6w", "f16x3", "bf16x3"])
+@pytest.mark.parametrize("mode", modes("f32", "f32w", "bf16x6", "bf16x6w", "f16x3", "bf16x3"))
 def test_non_default_geometry(mode):
     """A geometry other than config/NN_BSS.yml's: 4 microphones, 3 speakers, bottleneck channels
     (16,24,40,32,48,64,128) -- output groups of 16/24/40/48 channels, 2-chunk layers, a dense block that grows to 200
@@ -163,6 +163,7 @@ def test_non_default_geometry(mode):
     _assert_parity(y, ref, f"[{mode}] non-default geometry (4 mics, 3 speakers, en={en})")
 
 
+@needs_alt_modes
 def test_f16x3_overflow_fails_loudly(sd1):
     """f16x3 keeps activations as fp16 pieces: values beyond 65504 overflow.  That must surface as the library's NaN
     error (FloatingPointError), never as a silently wrong spectrogram; the float32-range modes take the same input."""
@@ -274,6 +275,7 @@ print("COLD_CAPTURE_OK")
     assert r.returncode == 0 and "COLD_CAPTURE_OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
 
 
+@needs_alt_modes
 @pytest.mark.parametrize("scale", [1e-4, 1e-2, 1e3])
 def test_f16x3_input_scale_range(sd1, scale):
     """f16x3 keeps the RAW first-layer output (whose scale follows the input) in the exact three-bf16 layout and runs the
@@ -429,6 +431,7 @@ def test_norm_type_pipeline_mixed(sd3):
     assert torch.isfinite(torch.view_as_real(out)).all()
 
 
+@needs_alt_modes
 def test_bf16x6w_mode_goldens_ragged_shapes_batch_invariance(sd1, sd3):
     """bf16x6w (conv_wino6.hip: the DenseBlock convs in Winograd F(2x2,3x3) form, bf16x6 arithmetic): reference goldens G1 / G3,
     ragged batched shapes against the oracle (row tiles of 7 / 15 / 31 / 63 / 127 rows, column tiles that end inside a tile, T

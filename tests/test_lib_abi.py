@@ -36,14 +36,14 @@ def test_header_symbols_exported():
 def test_product_library_has_no_experiment_switches():
     """the kernel-variant / ablation / timeline switches (MISONET_X6_*, MISONET_DMA*, MISONET_SUBBATCH, ...)
     exist only in the experiment build (`make exp`, -DMISONET_EXPERIMENTS).  The product library reads NO environment
-    variable: not one MISONET_* name (nor a getenv import) is in the binary, and its ABI version says at least 430 (440 since the bf16x6w mode)."""
+    variable: not one MISONET_* name (nor a getenv import) is in the binary, and its ABI version says at least 450 (product modes 0 / 3 / 5 only)."""
     L = _lib()
     assert os.path.realpath(L.LIB_PATH).endswith("libmisonet_hip.so")
     blob = open(L.LIB_PATH, "rb").read()
     names = set(re.findall(rb"MISONET_[A-Z0-9_]{3,}", blob))
     assert not names, names
     assert b"getenv" not in blob
-    assert L.lib().misonet_version() >= 430
+    assert L.lib().misonet_version() >= 450
     src = "".join(open(f).read() for f in __import__("glob").glob(os.path.join(ROOT, "misonet_amd", "csrc", "*.hip")))
     assert "getenv" not in src                                   # every switch goes through kernels.hpp exp_env()
 
@@ -155,17 +155,22 @@ def test_precision_switch_host_side():
     L, rc, h = _make()
     lib = L.lib()
     assert lib.misonet_net_get_precision(h) == 3                 # bf16x6 (fp32-faithful, the bench's mode) by default
-    assert lib.misonet_net_set_precision(h, 1) == 0 and lib.misonet_net_get_precision(h) == 1
+    assert lib.misonet_net_set_precision(h, 0) == 0 and lib.misonet_net_get_precision(h) == 0   # f32
     assert lib.misonet_net_set_precision(h, 5) == 0 and lib.misonet_net_get_precision(h) == 5   # f32w
-    assert lib.misonet_net_set_precision(h, 6) == 0 and lib.misonet_net_get_precision(h) == 6   # bf16x6w
-    assert lib.misonet_net_set_precision(h, 7) == L.EINVAL
+    # the product library has exactly three arithmetic modes; bf16x3 (1, 2), f16x3 (4), bf16x6w (6) are experiment-build modes
+    for alt in (1, 2, 4, 6):
+        assert lib.misonet_net_set_precision(h, alt) == L.EINVAL and lib.misonet_net_get_precision(h) == 5, alt
+    assert lib.misonet_net_set_precision(h, 7) == L.EINVAL and lib.misonet_net_set_precision(h, -1) == L.EINVAL
     lib.misonet_net_destroy(h)
     import misonet_amd as mz
     from misonet_amd import weights as W
     m = mz.MISO_3(1, 6, 7, list(W.DEFAULT_EN_CH), list(W.DEFAULT_DE_CH), "IN")
     assert m.precision == "bf16x6"
-    m.set_precision("bf16x3")
-    assert m.precision == "bf16x3"
+    m.set_precision("f32w")
+    assert m.precision == "f32w"
+    with pytest.raises(ValueError, match="experiment build"):
+        m.set_precision("bf16x3")
+    assert m.precision == "f32w"
     with pytest.raises(ValueError):
         m.set_precision("fp8")
 
@@ -186,7 +191,7 @@ def test_reference_checkpoint_format_roundtrip(tmp_path):
         assert torch.equal(back[k], sd[k])
 
 
-@pytest.mark.parametrize("prec", [0, 2, 3, 4])
+@pytest.mark.parametrize("prec", [0, 3, 5])
 def test_workspace_plan_never_overlaps_live_buffers(prec):
     """The lifetime-shared activation arena: for every arithmetic mode and several utterance lengths, two
     buffers that are alive at the same step of a forward never share a byte, the skip buffers D[i] live from their encoder
