@@ -170,8 +170,8 @@ int misonet_pipeline_run_wav(misonet_pipeline* p, const float* wav_dev, const fl
 
 /* ---- STFT front-end alone: AudioDataset_Test.STFT + "/scale" + permute (dataloader/data.py:505-522, 540-544) ------ */
 /* wav_dev float32 [B, n_samples, M] -> out_dev complex64 [B, M, T, 129], T = n_samples/64 + 1: hann-256, hop 64,
- * zero boundary padding, un-normalised.  The twiddle table (295 KB) is allocated once per device, on first use there
- * (the one allocation outside *_commit). */
+ * zero boundary padding, un-normalised.  The twiddle tables (0.3 MB per device) are built by misonet_net_commit,
+ * misonet_pipeline_create or misonet_frontend_init (ABI 430; see misonet_istft below for a process that calls none of them). */
 int misonet_stft_frames(int n_samples);
 long long misonet_stft_workspace_bytes(int B, int M, int n_samples);
 /* STFT + iSTFT tables (0.3 MB) and kernel attributes of the CURRENT device; idempotent (ABI 430) */

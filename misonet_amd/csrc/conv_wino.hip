@@ -406,11 +406,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
   // behind it in the wave's VMEM queue are the 10 pieces of the last iteration, hence vmcnt(10)).  After the barrier: U image
   // of chunk g + 2 -> stage STNN, raw input of chunk g + 3 -> the raw slot this iteration has emptied.  In front of the
   // barrier the U image of chunk g + 1 must have landed: behind it are the 6 raw pieces of the same iteration, vmcnt(6).
-  // vmcnt counts in issue order, stores included, and a tile epilogue queues exactly 16 stores (+ the statistics atomics of
-  // wave 0, which only make a wait more conservative) behind the DMA of its tile's last chunk: in the two iterations after an
-  // epilogue (post = 2, 1) the waits that look across them allow 16 more -- a run-time threshold (wait_vm_le).  Measured:
-  // waiting for the stores instead costs their HBM round trip per tile (the epilogue appeared twice as expensive), branching
-  // between two s_waitcnt immediates 13 % of the chunk time in instruction fetch.
+  // vmcnt counts in issue order, stores included, and a tile epilogue queues exactly 16 stores (+ the statistics atomics, which
+  // only make a wait more conservative) behind the DMA of its tile's last chunk: in the two iterations after an epilogue (POST =
+  // 2, 1) the waits that look across them allow 16 more.  Six chunk bodies (frame masks x POST) carry the immediates; measured
+  // alternatives: waiting for the stores instead costs their HBM round trip per tile (the epilogue appeared twice as expensive),
+  // branching between two s_waitcnt immediates 13 % of the chunk time in instruction fetch, polling IB_STS.VM_CNT (readable:
+  // tools/micro/ibsts_vmcnt.hip) 8 %.  The immediates are tied to the issue counts here -- change a W_ISSUE_* list or the epilogue's
+  // stores and these fail to compile:
+  constexpr int W_NDMA_W = 4, W_NDMA_I = 6, W_NSTORE = 16;       // per wave and iteration: U-image pieces, raw-input pieces (5 + halo); stores per tile epilogue
+  static_assert(W_NDMA_W * 256 * 16 == WW_FLOATS * 4, "U image = 4 pieces of 256 threads x 16 bytes");
+  static_assert(5 * 256 * 16 == WCK * WNR * WTT * 4 && 2 * WCK * WNR <= 256, "raw input = 5 pieces of 256 x 16 bytes + one 4-byte halo piece");
+  static_assert(W_NDMA_W + W_NDMA_I == 10 && W_NDMA_I == 6 && 10 + W_NSTORE == 26 && 6 + W_NSTORE == 22,
+                "the s_waitcnt vmcnt immediates of W_CHUNK_ (10 / 26 in step 0, 6 / 22 in front of the barrier)");
   // The BOOKKEEPING of the chunk stream lives inside step 3 (round 6).  With one wave per SIMD nothing hides an instruction
   // that is issued while the matrix pipe is idle: every one -- scalar, branch, LDS -- costs its ~4-cycle issue slot, and the
   // ~110 instructions that used to sit between two chunk bodies (state hand-down L -> D -> C, stream advance, stage

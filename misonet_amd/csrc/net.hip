@@ -712,12 +712,10 @@ int misonet_net_set_tensor(misonet_net* n, const char* key, const float* host, l
   return MISONET_OK;
 }
 
-static void pack_conv(const misonet_net* n, const ConvL& c, std::vector<float>& arena) {
-  const std::vector<float>& W = n->tensors[c.wt].host;
-  const std::vector<float>& Bv = n->tensors[c.bt].host;
-  const int nchunk = (c.Cin + CK - 1) / CK;
-  const int COP = c.cop;
-  float* w = arena.data() + c.w_off;
+// conv3x3_mfma's weight image [cg][chunk of CK ci][tap = kt * 3 + kf][ci][COP co] (conv-form taps, zero padded)
+static void direct_image(const float* W, int Cin, int Cout, int COP, int ncg, bool transposed, float* w) {
+  struct { int Cin, Cout, ncg; bool transposed; } c = {Cin, Cout, ncg, transposed};
+  const int nchunk = (Cin + CK - 1) / CK;
   for (int cg = 0; cg < c.ncg; ++cg)
     for (int kc = 0; kc < nchunk; ++kc)
       for (int kt = 0; kt < 3; ++kt)
@@ -734,6 +732,11 @@ static void pack_conv(const misonet_net* n, const ConvL& c, std::vector<float>& 
               }
               w[((((long long)cg * nchunk + kc) * 9 + (kt * 3 + kf)) * CK + cil) * COP + col] = v;
             }
+}
+static void pack_conv(const misonet_net* n, const ConvL& c, std::vector<float>& arena) {
+  const std::vector<float>& Bv = n->tensors[c.bt].host;
+  const int COP = c.cop;
+  direct_image(n->tensors[c.wt].host.data(), c.Cin, c.Cout, c.cop, c.ncg, c.transposed, arena.data() + c.w_off);
   float* b = arena.data() + c.b_off;
   for (int co = 0; co < c.ncg * COP; ++co) b[co] = co < c.Cout ? Bv[co] : 0.f;
 }
@@ -863,12 +866,10 @@ static void pack_conv_few(const misonet_net* n, const ConvL& c, std::vector<floa
 // carry a minus because the kernel's packed input transform produces -V there (conv_wino.hip, pk_t23); positions with nu = 3
 // and positions with xi = 3 carry one each (both: none) so that the inverse transform A^T M A = sums with a single mixed-sign
 // step per row (conv_wino.hip epilogue: the accumulators hold -M there).
-static void pack_conv_wino(const misonet_net* n, const ConvL& c, std::vector<float>& arena) {
-  if (c.ww_off < 0) return;
-  const std::vector<float>& W = n->tensors[c.wt].host;
+static void wino_image(const float* W, int Cin, int Cout, float* img) {
+  struct { int Cin, Cout; } c = {Cin, Cout};
   static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
   const int nchunk = c.Cin / 8, ncg = (c.Cout + 31) / 32;
-  float* img = arena.data() + c.ww_off;
   for (int cg = 0; cg < ncg; ++cg)
     for (int kc = 0; kc < nchunk; ++kc)
       for (int cil = 0; cil < 8; ++cil)
@@ -885,6 +886,93 @@ static void pack_conv_wino(const misonet_net* n, const ConvL& c, std::vector<flo
             img[(((((long long)cg * nchunk + kc) * 4 + (pos >> 2)) * 8 + cil) * 32 + col) * 4 + (pos & 3)] = (float)(minus ? -u : u);
           }
         }
+}
+static void pack_conv_wino(const misonet_net* n, const ConvL& c, std::vector<float>& arena) {
+  if (c.ww_off < 0) return;
+  wino_image(n->tensors[c.wt].host.data(), c.Cin, c.Cout, arena.data() + c.ww_off);
+}
+
+// Run-time self-check of the f32w kernel, once per device at the first commit: conv3x3_wino_f32 drives 256 fixed
+// AGPRs and hand-placed wait states through inline asm -- the build guard (tools/check_wino_build.py) covers what the compiler
+// may do to it, this covers the machine: one small layer (40 -> 32 channels, 11 x 70, two samples: ragged row and column tiles,
+// two tiles per workgroup stream) through the Winograd kernel AND through conv3x3_mfma, compared element by element.  A mismatch
+// disables mode 5 on this device: misonet_net_set_precision(5) then fails loudly instead of computing garbage.
+static std::atomic<int> g_wino_state[MAX_DEV] = {};          // 0 not checked, 1 ok, 2 failed
+static std::mutex g_wino_mu;
+static int wino_selftest() {
+  const int d = cur_dev();
+  int st = g_wino_state[d].load(std::memory_order_acquire);
+  if (st) return st;
+  std::lock_guard<std::mutex> lk(g_wino_mu);
+  st = g_wino_state[d].load(std::memory_order_acquire);
+  if (st) return st;
+  const int Cin = 40, Cout = 32, F = 11, T = 70, Tp = frames_pitch(T), N = 2;
+  std::vector<float> W((size_t)Cout * Cin * 9), bias(Cout), x((size_t)N * Cin * F * Tp);
+  unsigned rng = 12345u;
+  auto rnd = [&rng]() { rng = rng * 1664525u + 1013904223u; return (float)((int)(rng >> 9) - (1 << 22)) * (1.f / (1 << 22)); };
+  for (float& v : W) v = 0.1f * rnd();
+  for (float& v : bias) v = 0.3f * rnd();
+  for (float& v : x) v = rnd();
+  const int nchunk = Cin / CK;
+  std::vector<float> wd((size_t)nchunk * 9 * CK * 32), ww((size_t)nchunk * 16 * 8 * 32);
+  direct_image(W.data(), Cin, Cout, 32, 1, false, wd.data());
+  wino_image(W.data(), Cin, Cout, ww.data());
+  const size_t out_n = (size_t)N * Cout * F * Tp, st_n = (size_t)N * Cout * 2 * DS_NL;
+  float *dx = nullptr, *dwd = nullptr, *dww = nullptr, *db = nullptr, *dy = nullptr;
+  dstat_t* dst = nullptr;
+  auto release = [&]() { (void)hipFree(dx); (void)hipFree(dwd); (void)hipFree(dww); (void)hipFree(db); (void)hipFree(dy); (void)hipFree(dst); };
+  bool ok = hipMalloc(reinterpret_cast<void**>(&dx), x.size() * 4) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&dwd), wd.size() * 4) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&dww), ww.size() * 4) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&db), 128 * 4) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&dy), 2 * out_n * 4) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&dst), 2 * st_n * 8) == hipSuccess;
+  std::vector<float> y(2 * out_n);
+  std::vector<dstat_t> sv(2 * st_n);
+  if (ok) {
+    std::vector<float> b128(128, 0.f);
+    std::copy(bias.begin(), bias.end(), b128.begin());
+    ok = hipMemcpy(dx, x.data(), x.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(dwd, wd.data(), wd.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(dww, ww.data(), ww.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(db, b128.data(), 128 * 4, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemset(dy, 0, 2 * out_n * 4) == hipSuccess && hipMemset(dst, 0, 2 * st_n * 8) == hipSuccess;
+  }
+  if (ok) {
+    ConvArgs a = {};
+    a.in = dx; a.in_stats = nullptr; a.w = dwd; a.bias = db; a.ww = dww;
+    a.in_bstride = (long long)Cin * F * Tp; a.out_bstride = (long long)Cout * F * Tp;
+    a.in_sstride = Cin; a.out_sstride = Cout;
+    a.in_c0 = 0; a.Cin = Cin; a.Fin = F; a.ident_c = Cin;              // input consumed as it is: no statistics to read
+    a.out_c0 = 0; a.Cout = Cout; a.Fout = F; a.T = T; a.Tp = Tp;
+    a.sf = 1; a.padf = 1; a.tr2 = 0; a.act = 1; a.NR = conv_rows(1, 0); a.ncg = 1; a.cop = 32;
+    a.wscale = a.descale = 1.f;
+    a.out = dy; a.out_stats = dst;
+    ok = conv_wino_ok(a) && launch_conv_wino(a, N, nullptr) == hipSuccess;
+    a.ww = nullptr; a.out = dy + out_n; a.out_stats = dst + st_n;
+    ok = ok && launch_conv(a, N, nullptr) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+         hipMemcpy(y.data(), dy, 2 * out_n * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+         hipMemcpy(sv.data(), dst, 2 * st_n * 8, hipMemcpyDeviceToHost) == hipSuccess;
+  }
+  release();
+  if (ok) {
+    double worst = 0.0, scale = 0.0;
+    for (int nn = 0; nn < N; ++nn)
+      for (int c = 0; c < Cout; ++c)
+        for (int f = 0; f < F; ++f)
+          for (int t = 0; t < T; ++t) {
+            const size_t i = (((size_t)nn * Cout + c) * F + f) * Tp + t;
+            worst = std::max(worst, (double)fabsf(y[i] - y[out_n + i]));
+            scale = std::max(scale, (double)fabsf(y[out_n + i]));
+          }
+    ok = std::isfinite(worst) && scale > 0.0 && worst <= 2e-5 * scale;
+    for (size_t i = 0; ok && i < st_n / DS_NL; ++i) {                    // the statistics of both kernels (sum, sum of squares)
+      auto rd = [](const dstat_t* p) { long long L[DS_NL]; for (int k = 0; k < DS_NL; ++k) L[k] = (long long)p[k]; return dstat_combine(L); };
+      const double a1 = rd(sv.data() + i * DS_NL), a2 = rd(sv.data() + st_n + i * DS_NL);
+      ok = std::isfinite(a1) && fabs(a1 - a2) <= 1e-4 * (fabs(a2) + 1.0);
+    }
+    if (!ok) fprintf(stderr, "[misonet] conv3x3_wino_f32 self-check FAILED on device %d (max |diff| %.3e of %.3e): mode f32w disabled\n", d, worst, scale);
+  }
+  st = ok ? 1 : 2;
+  g_wino_state[d].store(st, std::memory_order_release);
+  return st;
 }
 
 // ... and in the three-piece bf16 form of the bf16x6w mode (conv_wino6.hip): per (cg of 32 co, K-step of 16 ci) four QUARTERS
@@ -993,6 +1081,8 @@ int misonet_net_commit(misonet_net* n) {
   HIPCHK(conv_init());
   HIPCHK(conv_wino_init());
   HIPCHK(conv_few_init());
+  if (wino_selftest() != 1 && n->precision == 5)
+    return fail(MISONET_ESTATE, "the f32w kernel failed its self-check on this device (see stderr): use mode 0 (f32) or 3 (bf16x6)");
 #if MN_ALT_MODES
   HIPCHK(conv_wino6_init());
   HIPCHK(conv_bf16_init());
@@ -1011,6 +1101,8 @@ int misonet_net_set_precision(misonet_net* n, int mode) {
     return fail(MISONET_EINVAL, "precision mode must be 0 (f32), 3 (bf16x6) or 5 (f32w: f32 with the dense-block convs in Winograd form)%s",
                 MN_ALT_MODES ? "; experiment build: also 1 / 2 (bf16x3), 4 (f16x3), 6 (bf16x6w)"
                              : "; modes 1, 2, 4, 6 exist only in the experiment build (make exp)");
+  if (mode == 5 && g_wino_state[cur_dev()].load(std::memory_order_acquire) == 2)
+    return fail(MISONET_ESTATE, "the f32w kernel failed its self-check on this device: mode 5 is disabled (use 0 or 3)");
   n->precision = mode;
   return MISONET_OK;
 }
@@ -1171,8 +1263,9 @@ int misonet_pit_select(const void* anchor, const void* cand, int B, int S, int T
 // ---- STFT front-end ------------------------------------------------------------------------------------------------
 // twiddle table + the > 64 KB dynamic-LDS attribute of stft_pack_k, per device (the table lives in the memory of the
 // device that was current when it was first needed)
-static float* g_twid[MAX_DEV] = {};
-static float* g_itwid[MAX_DEV] = {};
+// (atomic: the getters read them outside the mutex -- acquire / release, a reader sees the table fully built or not at all)
+static std::atomic<float*> g_twid[MAX_DEV] = {};
+static std::atomic<float*> g_itwid[MAX_DEV] = {};
 static std::mutex g_front_mu;
 // Builds both tables on the CURRENT device (hipMalloc + synchronous copy + kernel attributes).  misonet_net_commit and
 // misonet_pipeline_create call it, so every path that runs a network has them before its first asynchronous call -- a HIP
@@ -1180,23 +1273,23 @@ static std::mutex g_front_mu;
 static int frontend_init() {
   const int d = cur_dev();
   std::lock_guard<std::mutex> lk(g_front_mu);
-  if (!g_twid[d]) {
+  if (!g_twid[d].load(std::memory_order_acquire)) {
     std::vector<float> tw((size_t)stft_twiddle_count());
     stft_build_twiddles(tw.data());
     float* p = nullptr;
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&p), tw.size() * sizeof(float)));
     HIPCHK(hipMemcpy(p, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(stft_init());
-    g_twid[d] = p;
+    g_twid[d].store(p, std::memory_order_release);
   }
-  if (!g_itwid[d]) {
+  if (!g_itwid[d].load(std::memory_order_acquire)) {
     std::vector<float> tw((size_t)istft_twiddle_count());
     istft_build_twiddles(tw.data());
     float* p = nullptr;
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&p), tw.size() * sizeof(float)));
     HIPCHK(hipMemcpy(p, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(istft_init());
-    g_itwid[d] = p;
+    g_itwid[d].store(p, std::memory_order_release);
   }
   return MISONET_OK;
 }
@@ -1206,14 +1299,14 @@ int misonet_frontend_init(void) { return frontend_init(); }
 // builds it on first use (that one call allocates and synchronises: not inside a stream capture; include/misonet.h)
 static int get_twiddles(const float** out) {
   const int d = cur_dev();
-  if (!g_twid[d]) { int r = frontend_init(); if (r) return r; }
-  *out = g_twid[d];
+  if (!g_twid[d].load(std::memory_order_acquire)) { int r = frontend_init(); if (r) return r; }
+  *out = g_twid[d].load(std::memory_order_acquire);
   return MISONET_OK;
 }
 static int get_itwiddles(const float** out) {
   const int d = cur_dev();
-  if (!g_itwid[d]) { int r = frontend_init(); if (r) return r; }
-  *out = g_itwid[d];
+  if (!g_itwid[d].load(std::memory_order_acquire)) { int r = frontend_init(); if (r) return r; }
+  *out = g_itwid[d].load(std::memory_order_acquire);
   return MISONET_OK;
 }
 

@@ -75,15 +75,17 @@ class CapturedPass:
     def __init__(self, graph, out, ws, mix, clean, key, owner=None):
         self.graph, self.out, self.mix, self.clean = graph, out, mix, clean
         self._ws, self.key = ws, key
-        self._owner = weakref.ref(owner) if owner is not None else None
+        # a STRONG reference: the graph's kernels read the Enhancer's pipeline handle and the nets' device weights, so they must
+        # outlive the graph -- and check() must stay usable for as long as replay() is (the Enhancer keeps only a WeakSet of its
+        # captured passes: no cycle)
+        self._owner = owner
 
     def check(self):
         """Synchronise and raise FloatingPointError if the last replay produced a NaN (the pass's flag word lives in the
         workspace this object owns, not in the Enhancer's eager workspace)."""
-        enh = self._owner() if self._owner is not None else None
-        if enh is None:
-            raise RuntimeError("the Enhancer this pass was captured from is gone")
-        enh.check(self.key[0], self.key[1], captured=self)
+        if self._owner is None:
+            raise RuntimeError("this pass was captured without an owning Enhancer")
+        self._owner.check(self.key[0], self.key[1], captured=self)
 
     def load(self, mix, clean=None):
         self.mix.copy_(mix)
@@ -392,6 +394,12 @@ class Enhancer:
                     sl["wav_d"].copy_(src_w, non_blocking=True)
                     if src_c is not None:
                         sl["clean_d"].copy_(src_c, non_blocking=True)
+                    # device-resident inputs are read by the copy-in stream: the caching allocator must not hand their blocks out
+                    # on the current stream before that copy is done, whatever the caller does with them after next() returns
+                    if src_w.is_cuda:
+                        src_w.record_stream(s_in)
+                    if src_c is not None and src_c.is_cuda:
+                        src_c.record_stream(s_in)
                     sl["ev_in"] = torch.cuda.Event()
                     sl["ev_in"].record(s_in)
                 cur.wait_event(sl["ev_in"])

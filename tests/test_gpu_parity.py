@@ -160,7 +160,11 @@ def test_miso1_shortest_inputs_vs_oracle(nets, sd1, T, request):
         print(f"[parity] miso1 T={T} sample {b}: encoder 5 {e5:.2e}, encoder 6 {e6:.2e} vs float64 truth; TCN on its own input "
               f"{et:.2e} (float32 oracle on the same input: {e32:.2e}); end result {eo:.2e} (ill-conditioned, not bounded at 1e-3)")
         assert e5 <= 2e-5 and e6 <= 1e-3, (T, b, e5, e6)      # encoder 6 is one instance norm over T values per channel
-        assert et <= max(5e-3, 10.0 * e32), (T, b, et, e32)
+        # f32 and bf16x6 keep the strict bound; only the mode whose encoder output lands on the ill-conditioned channel (f32w, T = 2)
+        # is measured against the float32 oracle's own distance on that input (a relaxed bound everywhere would let a
+        # real TCN regression through)
+        bound = max(5e-3, 10.0 * e32) if m1.precision == "f32w" else 5e-3
+        assert et <= bound, (m1.precision, T, b, et, e32)
         assert eo <= 0.2, (T, b, eo)
 
 
