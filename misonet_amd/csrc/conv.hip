@@ -96,6 +96,150 @@ __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[NCO][4], const float* s
 #undef MN_LOAD
 }
 
+// ---- W1D: the frequency-strided layers in 1-D Winograd F(2, 3) form along T (f32w mode, round 6) --------------------------
+// Every layer of the network has frame stride 1, so the three time taps of the stride-(1,2) convs and transposed convs
+// (model.py:47,52,67,71; the 2-D form of conv_wino.hip needs stride 1 in both directions) cost 4 instead of 6 products per two
+// output frames:  with d_i = x[2p - 1 + i],  V = (d0 - d2, d1 + d2, d2 - d1, d1 - d3),  U = (g0, (g0 + g1 + g2) / 2,
+// (g0 - g1 + g2) / 2, g2) per (co, ci, kf),  M_nu = sum U_nu V_nu,  y[2p] = M0 + M1 + M2,  y[2p + 1] = M1 - M2 - M3.
+// GEMM roles as in chunk_mfma with N = 32 frame PAIRS (64 frames) per column tile: a lane reads its pair's four inputs from
+// the staged tile (frame 2p - 1 sits at the ODD column 2p + 3 of the [.., TW] rows: 4-byte aligned, two ds_read2_b32), forms V in
+// registers (4 adds) and feeds 4 MFMAs per (kf, channel pair).
+// (The operand reads of step k + 1 -- raw frames and weights from the LDS -- are issued BEFORE the MFMAs of step k, as in
+// chunk_mfma: a sched_barrier per step keeps the compiler from sinking them back behind the matrix work.)
+struct W1dRaw { float d[4]; };
+__device__ __forceinline__ W1dRaw w1d_raw(const float* p) { W1dRaw r; r.d[0] = p[0]; r.d[1] = p[1]; r.d[2] = p[2]; r.d[3] = p[3]; return r; }
+__device__ __forceinline__ void w1d_vr(const W1dRaw& r, float (&v)[4]) {
+  v[0] = r.d[0] - r.d[2]; v[1] = r.d[1] + r.d[2]; v[2] = r.d[2] - r.d[1]; v[3] = r.d[1] - r.d[3];
+}
+// stride-2 conv: one output row per wave, 128 frames = 2 column tiles; s_w = [nu * 3 + kf][CK][32]
+template <int NR>
+__device__ __forceinline__ void chunk_w1d_s2(f32x16 (&acc)[4][2], const float* s_in, const float* s_w, int frel, int half, int l31) {
+  const float* wb = s_w + half * 32 + l31;
+  const float* ib0 = s_in + (half * NR + 2 * frel) * TW + 2 * l31 + 3;
+  constexpr int NSTEP = 3 * (CK / 2);
+  W1dRaw r0[2], r1[2];
+  float u[2][4];
+#define W1D_LOAD(ST, BUF)                                                                        \
+  {                                                                                              \
+    constexpr int kf_ = (ST) / (CK / 2), cp_ = (ST) % (CK / 2);                                  \
+    const float* ib_ = ib0 + kf_ * TW + cp_ * 2 * NR * TW;                                       \
+    r0[BUF] = w1d_raw(ib_); r1[BUF] = w1d_raw(ib_ + 64);                                         \
+    _Pragma("unroll") for (int nu = 0; nu < 4; ++nu) u[BUF][nu] = wb[((nu * 3 + kf_) * CK + cp_ * 2) * 32]; \
+  }
+  W1D_LOAD(0, 0)
+#pragma unroll
+  for (int st = 0; st < NSTEP; ++st) {
+    const int cur = st & 1;
+    if (st + 1 < NSTEP) {
+      const int kf_ = (st + 1) / (CK / 2), cp_ = (st + 1) % (CK / 2);
+      const float* ib_ = ib0 + kf_ * TW + cp_ * 2 * NR * TW;
+      r0[cur ^ 1] = w1d_raw(ib_); r1[cur ^ 1] = w1d_raw(ib_ + 64);
+#pragma unroll
+      for (int nu = 0; nu < 4; ++nu) u[cur ^ 1][nu] = wb[((nu * 3 + kf_) * CK + cp_ * 2) * 32];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float v0[4], v1[4];
+    w1d_vr(r0[cur], v0);
+    w1d_vr(r1[cur], v1);
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) {
+      acc[nu][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[cur][nu], v0[nu], acc[nu][0], 0, 0, 0);
+      acc[nu][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[cur][nu], v1[nu], acc[nu][1], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef W1D_LOAD
+}
+// stride-2 transposed conv: a wave owns the output row pair (2m, 2m + 1) over ONE column tile (64 frames): staged rows
+// pr (= input row m - 1) and pr + 1 (= m); even row: taps kf = 0 / 2 of them, odd row: tap kf = 1 of row m -- 12 MFMAs per
+// channel pair, the same for every wave; the V of row m serves both output rows
+// (acc[nu][0]: the even row, acc[nu][1]: the odd row)
+__device__ __forceinline__ void chunk_w1d_tr2(f32x16 (&acc)[4][2], const float* s_in, const float* s_w, int pr, int q, int half, int l31) {
+  constexpr int NR = 3;
+  const float* wb = s_w + half * 32 + l31;
+  const float* ib = s_in + (half * NR + pr) * TW + 2 * l31 + 3 + 64 * q;
+  W1dRaw ra[2], rb[2];
+  float u0[2][4], u1[2][4], u2[2][4];
+#define W1D_LOAD(CP, BUF)                                                                        \
+  {                                                                                              \
+    ra[BUF] = w1d_raw(ib + (CP) * 2 * NR * TW); rb[BUF] = w1d_raw(ib + (CP) * 2 * NR * TW + TW); \
+    _Pragma("unroll") for (int nu = 0; nu < 4; ++nu) {                                           \
+      u0[BUF][nu] = wb[((nu * 3 + 0) * CK + (CP) * 2) * 32];                                     \
+      u1[BUF][nu] = wb[((nu * 3 + 1) * CK + (CP) * 2) * 32];                                     \
+      u2[BUF][nu] = wb[((nu * 3 + 2) * CK + (CP) * 2) * 32];                                     \
+    }                                                                                            \
+  }
+  W1D_LOAD(0, 0)
+#pragma unroll
+  for (int cp = 0; cp < CK / 2; ++cp) {
+    const int cur = cp & 1;
+    if (cp + 1 < CK / 2) W1D_LOAD(cp + 1, cur ^ 1)
+    __builtin_amdgcn_sched_barrier(0);
+    float va[4], vb[4];
+    w1d_vr(ra[cur], va);
+    w1d_vr(rb[cur], vb);
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) {
+      acc[nu][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(u0[cur][nu], va[nu], acc[nu][0], 0, 0, 0);
+      acc[nu][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u1[cur][nu], vb[nu], acc[nu][1], 0, 0, 0);
+      acc[nu][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(u2[cur][nu], vb[nu], acc[nu][0], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef W1D_LOAD
+}
+// tile epilogue of the W1D forms: inverse transform, + bias, ELU, centring (conv_epilogue.hpp), 8-byte stores of the lane's frame
+// pair, statistics partials of this (row, column-tile range) into s_red [32][2].  Accumulator columns Q0 .. Q0 + NQ - 1 are
+// NQ consecutive column tiles of row f starting at frame tq.
+template <int Q0, int NQ>
+__device__ __forceinline__ void w1d_epilogue(const ConvArgs& a, f32x16 (&acc)[4][2], int n, int cg, int f, int tq, bool row_ok, int lane,
+                                             float* s_red) {
+  const int half = lane >> 5, l31 = lane & 31;
+  const int T = a.T, Tp = a.Tp;
+  const int cbase = cg * 32;
+  const unsigned P4 = (unsigned)a.Fout * (unsigned)Tp * 4u;
+  const float* ob = a.out + (long long)n * a.out_bstride + (long long)a.out_c0 * a.Fout * Tp;
+  const __amdgpu_buffer_rsrc_t rs = make_rsrc_e(reinterpret_cast<unsigned long long>(ob), (unsigned)a.Cout * P4);
+  const bool act = a.act != 0;
+  float s1[16], s2[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int kr = (r & 3) + 8 * (r >> 2);
+    const int co = cbase + kr + 4 * half;
+    const bool cok = co < a.Cout;
+    const float b = a.bias[co];                               // (zero padded to the group)
+    const float cr = act ? elu_fast(b) : 0.f;
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const float m0 = acc[0][Q0 + q][r], m1 = acc[1][Q0 + q][r], m2 = acc[2][Q0 + q][r], m3 = acc[3][Q0 + q][r];
+      float ye = (m0 + m1) + m2 + b, yo = (m1 - m2) - m3 + b;
+      if (act) { ye = elu_fast(ye) - cr; yo = elu_fast(yo) - cr; }
+      const int te = tq + 64 * q + 2 * l31;
+      const bool ok = row_ok && te < T;                      // (te + 1 >= T: the second word lands in the row's padding [T, Tp))
+      typedef unsigned int uu2 __attribute__((ext_vector_type(2)));
+      const float2 o = make_float2(ye, yo);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uu2, o), rs,
+                                            ok ? (unsigned)(f * Tp + te) * 4u + (unsigned)(4 * half) * P4 + (unsigned)(cbase + kr) * P4 : 0x80000000u, 0, 0);
+      const float ze = (ok && cok) ? ye : 0.f, zo = (ok && cok && te + 1 < T) ? yo : 0.f;
+      a1 += ze + zo;
+      a2 = fmaf(ze, ze, fmaf(zo, zo, a2));
+    }
+    s1[r] = a1;
+    s2[r] = a2;
+  }
+  if (act) {
+    const float x1 = reduce16_halfwave(s1, lane);
+    const float x2 = reduce16_halfwave(s2, lane);
+    if ((lane & 16) == 0) {
+      const int qq = lane & 15;
+      const int co_l = (qq & 3) + 8 * (qq >> 2) + 4 * half;
+      s_red[co_l * 2 + 0] = x1;
+      s_red[co_l * 2 + 1] = x2;
+    }
+  }
+}
+
 // MODE 0: forward / stride-1-transposed conv (sf = 1, NR = 6 staged rows); MODE 1: stride-2 conv (NR = 9);
 // MODE 2: stride-2 transposed conv: a wave owns the output row PAIR (2m, 2m + 1) -- the even row takes taps kf = 0, 2 of input
 //   rows m - 1, m, the odd row tap kf = 1 of row m: 9 tap steps per wave and chunk, the same for every wave (one output row
@@ -115,20 +259,24 @@ __device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[NCO][4], const float* s
 // that chunk runs half the channel pairs.  It is a separate instantiation because a second fully unrolled chunk_mfma body
 // inside the common kernel costs every MODE 0 instantiation its register allocation (round 3: 74-241 spilled VGPRs, f32
 // mode -36 %); tests/test_build_resources.py holds the hot instantiations to ScratchSize == 0.
-template <int NCO, int MODE, int OCTP = 0, bool HALFK = false>
-__global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0 && !HALFK) ? 3 : 2)) void conv3x3_mfma(const ConvArgs a) {
+// W1D: MODE 1 / 2 in the 1-D Winograd form above (a.w1d image, 12 taps = 4 positions x 3 kf; 32-channel groups; planar output).
+//   MODE 2 then keeps the 4-row tile (NR = 3): wave w owns row pair w >> 1 over column tile w & 1.
+template <int NCO, int MODE, int OCTP = 0, bool HALFK = false, bool W1D = false>
+__global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0 && !HALFK && !W1D) ? 3 : 2)) void conv3x3_mfma(const ConvArgs a) {
   static_assert(MODE != 2 || NCO == 1, "stride-2 transposed: two output rows per wave, 32-channel groups");
+  static_assert(!W1D || (NCO == 1 && (MODE == 1 || MODE == 2) && OCTP == 0 && !HALFK), "W1D: the frequency-strided layers, 32-channel groups, planar output");
   constexpr int COP = NCO * 32;
-  constexpr int NR = MODE == 0 ? 6 : (MODE == 1 ? 9 : (MODE == 2 ? 5 : 1));
+  constexpr int NR = MODE == 0 ? 6 : (MODE == 1 ? 9 : (MODE == 2 ? (W1D ? 3 : 5) : 1));
   constexpr int SF = MODE == 1 ? 2 : 1;
   constexpr bool TR2 = MODE == 2;
-  constexpr int FTO = TR2 ? 2 * FT : FT;         // output rows per workgroup
-  constexpr int NW4 = 9 * CK * COP / 4;          // float4 per weight slab
+  constexpr int FTO = (TR2 && !W1D) ? 2 * FT : FT;   // output rows per workgroup
+  constexpr int NTAP = W1D ? 12 : 9;
+  constexpr int NW4 = NTAP * CK * COP / 4;       // float4 per weight slab
   constexpr int NWI = (NW4 + 255) / 256;
   extern __shared__ __align__(16) float smem[];
   float* s_in = smem;                         // [CK][NR][TW]: col 3 = frame t0-1, cols 4..131 = t0..t0+127, col 132 = t0+128
-  float* s_w = s_in + CK * NR * TW;           // [9][CK][COP]
-  float2* s_nrm = reinterpret_cast<float2*>(s_w + 9 * CK * COP);   // [CinP] (mean, rstd)
+  float* s_w = s_in + CK * NR * TW;           // [NTAP][CK][COP]
+  float2* s_nrm = reinterpret_cast<float2*>(s_w + NTAP * CK * COP);   // [CinP] (mean, rstd)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -143,23 +291,8 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0 && !HALFK
   const int nchunk = (Cin + CK - 1) / CK;
   const int fin0 = MODE == 3 ? 0 : (TR2 ? (f0 >> 1) - 1 : SF * f0 - a.padf);
 
-  // instance-norm parameters of the input channels (normalise-on-load)
-  for (int c = tid; c < nchunk * CK; c += 256) {
-    float mean = 0.f, rstd = (c < Cin) ? 1.f : 0.f;       // channels beyond Cin stage as zeros
-    if (c >= a.ident_c && c < Cin) {
-      const dstat_t* st = a.in_stats + ((long long)n * a.in_sstride + a.in_c0 + c) * (2 * DS_NL);
-      const double cnt = (double)Fin * (double)T;
-      const double m = dstat_read(st) / cnt;
-      double var = dstat_read(st + DS_NL) / cnt - m * m;
-      var = var > 0.0 ? var : 0.0;
-      mean = (float)m;
-      rstd = (float)(1.0 / sqrt(var + (double)IN_EPS));
-    }
-    s_nrm[c] = make_float2(rstd, -mean * rstd);            // (scale, shift): x_norm = fma(x, scale, shift)
-  }
-
   const float* in_n = a.in + (long long)n * a.in_bstride + (long long)a.in_c0 * Fin * Tp;
-  const f32x4* w_g = reinterpret_cast<const f32x4*>(a.w + (long long)cg * nchunk * (9 * CK * COP));
+  const f32x4* w_g = reinterpret_cast<const f32x4*>((W1D ? a.w1d : a.w) + (long long)cg * nchunk * (NTAP * CK * COP));
 
   // staging roles
   const int sq = tid & 31, sci = tid >> 5;
@@ -199,36 +332,36 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0 && !HALFK
     roff_b[r] = ((unsigned)fin * row_e + tg_e) * 4u;
   }
 
-#define STAGE_ISSUE(KC)                                                                          \
+#define STAGE_ISSUE_S(KC, PIN, PH, PW)                                                                          \
   {                                                                                              \
     int c_ = (KC) * CK + sci;                                                                    \
     c_ = c_ < Cin ? c_ : Cin - 1;                                                                \
     const unsigned cb_ = (unsigned)c_ * plane_e * 4u;                                            \
-    _Pragma("unroll") for (int r = 0; r < NR; ++r) pin[r] = __builtin_bit_cast(                  \
+    _Pragma("unroll") for (int r = 0; r < NR; ++r) PIN[r] = __builtin_bit_cast(                  \
         f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, cb_ + roff_b[r], 0, 0));             \
     int c2_ = (KC) * CK + hci;                                                                   \
     c2_ = c2_ < Cin ? c2_ : Cin - 1;                                                             \
-    ph = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(                         \
+    PH = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(                         \
         rs_in, (unsigned)c2_ * plane_e * 4u + hoff_b, 0, 0));                                    \
     const f32x4* wsrc_ = w_g + (unsigned)(KC) * (unsigned)NW4;                                   \
     _Pragma("unroll") for (int i = 0; i < NWI; ++i) {                                            \
       unsigned idx_ = tid + 256 * i;                                                             \
       if (NW4 % 256 != 0) idx_ = idx_ < (unsigned)NW4 ? idx_ : (unsigned)(NW4 - 1);              \
-      pw[i] = wsrc_[idx_];                                                                       \
+      PW[i] = wsrc_[idx_];                                                                       \
     }                                                                                            \
   }
 
-#define STAGE_COMMIT(KC)                                                                         \
+#define STAGE_COMMIT_S(KC, PIN, PH, PW)                                                                         \
   {                                                                                              \
     const float2 m_ = s_nrm[(KC) * CK + sci];                                                    \
     _Pragma("unroll") for (int r = 0; r < NR; ++r) {                                             \
       const int fin_ = fin0 + r;                                                                 \
       f32x4 v_ = {0.f, 0.f, 0.f, 0.f};                                                           \
       if (fin_ >= 0 && fin_ < Fin) {                      /* uniform */                          \
-        v_.x = fmaf(pin[r].x, m_.x, m_.y);                                                       \
-        v_.y = fmaf(pin[r].y, m_.x, m_.y);                                                       \
-        v_.z = fmaf(pin[r].z, m_.x, m_.y);                                                       \
-        v_.w = fmaf(pin[r].w, m_.x, m_.y);                                                       \
+        v_.x = fmaf(PIN[r].x, m_.x, m_.y);                                                       \
+        v_.y = fmaf(PIN[r].y, m_.x, m_.y);                                                       \
+        v_.z = fmaf(PIN[r].z, m_.x, m_.y);                                                       \
+        v_.w = fmaf(PIN[r].w, m_.x, m_.y);                                                       \
         if (!full_t) {                                                                           \
           v_.x = (tg + 0 < T) ? v_.x : 0.f;                                                      \
           v_.y = (tg + 1 < T) ? v_.y : 0.f;                                                      \
@@ -240,19 +373,32 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0 && !HALFK
     }                                                                                            \
     if (hr < NR) {                                                                               \
       const float2 m2_ = s_nrm[(KC) * CK + hci];                                                 \
-      s_in[(hci * NR + hr) * TW + (hside ? TT + 4 : 3)] = hok ? fmaf(ph, m2_.x, m2_.y) : 0.f;    \
+      s_in[(hci * NR + hr) * TW + (hside ? TT + 4 : 3)] = hok ? fmaf(PH, m2_.x, m2_.y) : 0.f;    \
     }                                                                                            \
     _Pragma("unroll") for (int i = 0; i < NWI; ++i) {                                            \
       const int idx_ = tid + 256 * i;                                                            \
-      if (NW4 % 256 == 0 || idx_ < NW4) reinterpret_cast<f32x4*>(s_w)[idx_] = pw[i];             \
+      if (NW4 % 256 == 0 || idx_ < NW4) reinterpret_cast<f32x4*>(s_w)[idx_] = PW[i];             \
     }                                                                                            \
   }
+#define STAGE_ISSUE(KC) STAGE_ISSUE_S(KC, pin, ph, pw)
+#define STAGE_COMMIT(KC) STAGE_COMMIT_S(KC, pin, ph, pw)
 
-  const int f = TR2 ? f0 + 2 * wave : f0 + wave;        // (TR2: the even row of the pair; f + 1 is the odd one)
+  // (TR2: the even row of the pair; f + 1 is the odd one.  W1D TR2: pair wave >> 1, column tile wave & 1)
+  const int f = TR2 ? (W1D ? f0 + 2 * (wave >> 1) : f0 + 2 * wave) : f0 + wave;
   const bool row_ok = f < a.Fout;                       // wave-uniform
   int nseg = (T - t0 + 31) >> 5;
   nseg = nseg > 4 ? 4 : nseg;
 
+  // W1D accumulators: [position nu][column tile of 64 frames] (MODE 1) / [nu] for the even and the odd row (MODE 2)
+  f32x16 wacc[4][2];
+  if (W1D) {
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wacc[nu][q][r] = 0.f;
+  }
   f32x16 acc[NCO][4];
   f32x16 acc_o[NCO][4];                                 // TR2: the odd row of the pair (never touched otherwise)
 #pragma unroll
@@ -265,14 +411,39 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0 && !HALFK
   const int half = lane >> 5, l31 = lane & 31;
 
   STAGE_ISSUE(0)
+  // (behind the first chunk's loads: the statistics reads and their float64 arithmetic run while those are in flight -- in front
+  // of them every workgroup started with two serial memory latencies)
+  // instance-norm parameters of the input channels (normalise-on-load)
+  for (int c = tid; c < nchunk * CK; c += 256) {
+    float mean = 0.f, rstd = (c < Cin) ? 1.f : 0.f;       // channels beyond Cin stage as zeros
+    if (c >= a.ident_c && c < Cin) {
+      const dstat_t* st = a.in_stats + ((long long)n * a.in_sstride + a.in_c0 + c) * (2 * DS_NL);
+      const double cnt = (double)Fin * (double)T;
+      const double m = dstat_read(st) / cnt;
+      double var = dstat_read(st + DS_NL) / cnt - m * m;
+      var = var > 0.0 ? var : 0.0;
+      mean = (float)m;
+      rstd = (float)(1.0 / sqrt(var + (double)IN_EPS));
+    }
+    s_nrm[c] = make_float2(rstd, -mean * rstd);            // (scale, shift): x_norm = fma(x, scale, shift)
+  }
+
   __syncthreads();          // s_nrm visible
   STAGE_COMMIT(0)
   __syncthreads();
 
+  // (Measured and dropped, round 6: a second register set with the loads of chunk k + 2 in flight changed nothing on the W1D
+  // kernels -- they are not waiting for the chunk loads; PMC: waves spend 32 % of their time in s_waitcnt / barriers, 50 %
+  // waiting for the matrix pipe the two resident workgroups share, the pipe is 54 % busy.)
   for (int kc = 0; kc < nchunk; ++kc) {
     const bool more = (kc + 1 < nchunk);
     if (more) STAGE_ISSUE(kc + 1)
-    if (row_ok) {
+    if (W1D) {
+      if (row_ok) {
+        if (TR2) chunk_w1d_tr2(wacc, s_in, s_w, wave >> 1, wave & 1, half, l31);
+        else chunk_w1d_s2<NR>(wacc, s_in, s_w, f - f0, half, l31);
+      }
+    } else if (row_ok) {
       if (TR2) {
         chunk_mfma<NCO, NR, SF, TR2, 5>(acc, s_in, s_w, f - f0, half, l31);
         chunk_mfma<NCO, NR, SF, TR2, 2>(acc_o, s_in, s_w, f - f0 + 1, half, l31);
@@ -293,6 +464,35 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0 && !HALFK
   }
 
   float* s_red = smem;   // [FTO rows][COP][2]  (safe: the loop ends with a barrier after the last reads)
+  if (W1D) {
+    // statistics slots: MODE 1 one per row (wave); MODE 2 [row of the tile][column tile]: 8 partial sums, added in slot order
+    if (TR2) {
+      const int q = wave & 1, rt = 2 * (wave >> 1);
+      w1d_epilogue<0, 1>(a, wacc, n, cg, f, t0 + 64 * q, row_ok, lane, s_red + ((rt * 2 + q) * 32) * 2);
+      w1d_epilogue<1, 1>(a, wacc, n, cg, f + 1, t0 + 64 * q, f + 1 < a.Fout, lane, s_red + (((rt + 1) * 2 + q) * 32) * 2);
+    } else {
+      w1d_epilogue<0, 2>(a, wacc, n, cg, f, t0, row_ok, lane, s_red + wave * (32 * 2));
+    }
+    if (a.act) {
+      __syncthreads();
+      if (tid < 64) {
+        const int co_l = tid >> 1, which = tid & 1;
+        const int co = cg * 32 + co_l;
+        if (co < a.Cout) {
+          float tot = 0.f;
+          if (TR2) {
+            for (int sl = 0; sl < 8; ++sl)
+              if (f0 + (sl >> 1) < a.Fout) tot += s_red[(sl * 32 + co_l) * 2 + which];
+          } else {
+            for (int w = 0; w < FT; ++w)
+              if (f0 + w < a.Fout) tot += s_red[(w * 32 + co_l) * 2 + which];
+          }
+          dstat_add(a.out_stats + (((long long)n * a.out_sstride + a.out_c0 + co) * 2 + which) * DS_NL, (double)tot);
+        }
+      }
+    }
+    return;
+  }
   if (TR2) {
     conv_epilogue<NCO, 4, OCTP, true>(a, acc, n, cg, f, t0, row_ok, lane, s_red + (2 * wave) * (COP * 2));
     conv_epilogue<NCO, 4, OCTP, true>(a, acc_o, n, cg, f + 1, t0, f + 1 < a.Fout, lane, s_red + (2 * wave + 1) * (COP * 2));
@@ -316,15 +516,17 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0 && !HALFK
 
 #undef STAGE_ISSUE
 #undef STAGE_COMMIT
+#undef STAGE_ISSUE_S
+#undef STAGE_COMMIT_S
 
-static size_t conv_lds_bytes(int NR, int cop, int Cin) {
+static size_t conv_lds_bytes(int NR, int cop, int Cin, int ntap = 9) {
   const int nchunk = (Cin + CK - 1) / CK;
-  return (size_t)(CK * NR * TW + 9 * CK * cop) * sizeof(float) + (size_t)nchunk * CK * sizeof(float2);
+  return (size_t)(CK * NR * TW + ntap * CK * cop) * sizeof(float) + (size_t)nchunk * CK * sizeof(float2);
 }
 
-template <int NCO, int MODE, int OCTP = 0, bool HALFK = false>
+template <int NCO, int MODE, int OCTP = 0, bool HALFK = false, bool W1D = false>
 static hipError_t set_lds_attr() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma<NCO, MODE, OCTP, HALFK>),
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma<NCO, MODE, OCTP, HALFK, W1D>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
 }
 
@@ -335,6 +537,8 @@ hipError_t conv_init() {
   if ((e = set_lds_attr<1, 2>()) != hipSuccess) return e;
   if ((e = set_lds_attr<2, 0>()) != hipSuccess) return e;
   if ((e = set_lds_attr<2, 1>()) != hipSuccess) return e;
+  if ((e = set_lds_attr<1, 1, 0, false, true>()) != hipSuccess) return e;
+  if ((e = set_lds_attr<1, 2, 0, false, true>()) != hipSuccess) return e;
   if ((e = set_lds_attr<1, 3>()) != hipSuccess) return e;
   if ((e = set_lds_attr<2, 3>()) != hipSuccess) return e;
   if ((e = set_lds_attr<1, 0, 3>()) != hipSuccess) return e;
@@ -374,6 +578,17 @@ hipError_t launch_conv(const ConvArgs& a_in, int n_samples, hipStream_t s) {
   // XCDs get nothing (B = 1: MISO3 runs 2 samples -> 6 of 8 XCDs idle, the first layer took 114 us instead of ~30); the
   // natural (t, f, n) grid is used then
   const int mode = a.tr2 ? 2 : (a.sf == 2 ? 1 : ((a.padf == 2 && a.Fin == 1 && !a.out_oct) ? 3 : 0));
+  if (a.w1d && (mode == 1 || mode == 2) && !a.out_oct && !a.in_oct) {
+    // f32w: the frequency-strided layers in 1-D Winograd form along T (32-channel groups, 4-row tiles)
+    a.cop = 32;
+    a.ncg = (a.Cout + 31) / 32;
+    a.NR = mode == 1 ? 9 : 3;
+    const dim3 gridw = conv_grid(a, n_samples, TT, FT, (n_samples % 8 == 0) ? conv_xcd_env() : 0);
+    const size_t ldsw = conv_lds_bytes(a.NR, 32, a.Cin, 12);
+    if (mode == 1) hipLaunchKernelGGL((conv3x3_mfma<1, 1, 0, false, true>), gridw, dim3(256), ldsw, s, a);
+    else hipLaunchKernelGGL((conv3x3_mfma<1, 2, 0, false, true>), gridw, dim3(256), ldsw, s, a);
+    return hipGetLastError();
+  }
   a.NR = mode == 3 ? 1 : (mode == 0 ? 6 : f32_rows(a));
   if (mode == 2 && a.cop != 32) return hipErrorInvalidValue;   // (net.hip packs stride-2 transposed layers in 32-channel groups)
   const dim3 grid = conv_grid(a, n_samples, TT, mode == 2 ? 2 * FT : FT, (n_samples % 8 == 0) ? conv_xcd_env() : 0);

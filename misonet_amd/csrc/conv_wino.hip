@@ -556,9 +556,21 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
       wf2 mt = {m00, m01}, mb = {m10, m11};
       asm volatile("" : "+v"(l2e), "+v"(mt), "+v"(mb));
       float s1[16], s2[16];
+      // Accumulator quad q (registers 4 q .. 4 q + 3) holds channels cbase + 8 q + {0 .. 3} + 4 half: with 24 (or, in the second
+      // group of a 48-channel layer, 16) output channels the last one (two) of the four quads is padding in BOTH half-waves --
+      // its channels have zero weights and no memory.  Their share of the epilogue (reads, transform, ELU, dropped stores) is
+      // skipped: a wave-uniform branch per quad; their statistics entries are the zeros they would have computed.
+      const int nquad = (a.Cout - cbase + 7) >> 3;           // valid quads of this group (>= 4: all)
       wfor<16>([&](auto rc) __attribute__((always_inline)) {
         constexpr int r = decltype(rc)::value;
         constexpr int kr = (r & 3) + 8 * (r >> 2);
+        if ((r >> 2) >= nquad) {
+          // (the store is still ISSUED, out of range = dropped by the hardware: the s_waitcnt vmcnt immediates of the next two
+          // chunks count exactly W_NSTORE stores per epilogue)
+          if (!(DBG & 64)) __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{0u, 0u, 0u, 0u}, rs_out, 0x80000000u, 0, 2);
+          s1[r] = 0.f; s2[r] = 0.f;
+          return;
+        }
         const unsigned coff = (unsigned)(cbase + kr) * P4;
         const wf2 bb = *W_LP(const wf2, tab_a + kr * 24);
         // The packed arithmetic is written as VECTOR expressions, not asm: the compiler forms the v_pk_*_f32 itself (op_sel / neg

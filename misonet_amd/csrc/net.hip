@@ -115,6 +115,7 @@ struct ConvL {
   long long w6s_off = -1;           // first layer only: offset (floats) of the SHARED 3-part bf16 image [chunk][864 units]
   long long ww_off = -1;            // stride-1 same-padded layers: offset (floats) of the Winograd-domain weights (conv_wino.hip)
   long long ww6_off = -1;           // the same in three bf16 pieces (conv_wino6.hip)
+  long long w1d_off = -1;           // stride-2 convs / transposed convs: 1-D Winograd image along T (conv.hip W1D; f32w mode)
   long long wsm_off = -1;           // <= 4 output channels, no activation (the last layer): [Cin][9][4] image of conv_few.hip
   float wscale = 1.f;               // f16x3: power of two that brings max |W| of the layer to [32, 64)
 };
@@ -478,6 +479,7 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
   a.ww = (n->precision == 5 && c.ww_off >= 0) ? n->w_dev + c.ww_off : nullptr;
   a.ww6 = (MN_ALT_MODES && n->precision == 6 && c.ww6_off >= 0) ? n->w_dev + c.ww6_off : nullptr;
   a.wsm = (planar_f32(n) && c.wsm_off >= 0) ? n->w_dev + c.wsm_off : nullptr;
+  a.w1d = (n->precision == 5 && c.w1d_off >= 0) ? n->w_dev + c.w1d_off : nullptr;
   a.in_bstride = bstride(n, L, c.in_buf);
   a.out_bstride = bstride(n, L, c.out_buf);
   a.in_sstride = n->bufs[c.in_buf].C;
@@ -866,6 +868,27 @@ static void pack_conv_few(const misonet_net* n, const ConvL& c, std::vector<floa
 // carry a minus because the kernel's packed input transform produces -V there (conv_wino.hip, pk_t23); positions with nu = 3
 // and positions with xi = 3 carry one each (both: none) so that the inverse transform A^T M A = sums with a single mixed-sign
 // step per row (conv_wino.hip epilogue: the accumulators hold -M there).
+// conv.hip W1D: U = G g along T per (co, ci, kf), conv-form taps (a transposed conv's are flipped), [cg32][chunk][nu * 3 + kf][ci][32]
+static void w1d_image(const float* W, int Cin, int Cout, bool transposed, float* img) {
+  static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+  const int nchunk = (Cin + CK - 1) / CK, ncg = (Cout + 31) / 32;
+  for (int cg = 0; cg < ncg; ++cg)
+    for (int kc = 0; kc < nchunk; ++kc)
+      for (int nu = 0; nu < 4; ++nu)
+        for (int kf = 0; kf < 3; ++kf)
+          for (int cil = 0; cil < CK; ++cil)
+            for (int col = 0; col < 32; ++col) {
+              const int ci = kc * CK + cil, co = cg * 32 + col;
+              double u = 0.0;
+              if (ci < Cin && co < Cout)
+                for (int kt = 0; kt < 3; ++kt) {
+                  const double g = transposed ? (double)W[(((long long)ci * Cout + co) * 3 + (2 - kt)) * 3 + (2 - kf)]
+                                              : (double)W[(((long long)co * Cin + ci) * 3 + kt) * 3 + kf];
+                  u += G[nu][kt] * g;
+                }
+              img[((((long long)cg * nchunk + kc) * 12 + (nu * 3 + kf)) * CK + cil) * 32 + col] = (float)u;
+            }
+}
 static void wino_image(const float* W, int Cin, int Cout, float* img) {
   struct { int Cin, Cout; } c = {Cin, Cout};
   static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
@@ -1032,6 +1055,7 @@ int misonet_net_commit(misonet_net* n) {
       // the DenseBlock convs (stride 1, same padding, Cin a multiple of 8): Winograd-domain image for the f32w mode
       if (!c.transposed && c.sf == 1 && c.padf == 1 && c.Cin % 8 == 0 && c.Cin <= 256)
         c.ww_off = take((long long)((c.Cout + 31) / 32) * (c.Cin / 8) * 16 * 8 * 32);
+      if (c.tr2 || c.sf == 2) c.w1d_off = take((long long)((c.Cout + 31) / 32) * nchunk * 12 * CK * 32);
       if (c.Cout <= 4 && c.sf == 1 && !c.tr2 && !c.act && c.Cin % 4 == 0 && c.Cin <= 256) c.wsm_off = take((long long)c.Cin * 36);
       if (MN_ALT_MODES && !c.transposed && c.sf == 1 && c.padf == 1 && c.Cin % 8 == 0 && c.Cin >= 24 && c.Cin <= 256)
         c.ww6_off = take((long long)((c.Cout + 31) / 32) * ((c.Cin + 15) / 16) * (16 * 3 * 64 * 16 / 4));
@@ -1051,6 +1075,8 @@ int misonet_net_commit(misonet_net* n) {
     }
   std::vector<float> arena((size_t)off, 0.f);
   for (ConvL& c : n->enc) { pack_conv(n, c, arena); pack_conv_bf16(n, c, arena); pack_conv_wf6(n, c, arena); pack_conv_w6s(n, c, arena); pack_conv_wino(n, c, arena); pack_conv_wino6(n, c, arena); }
+  for (ConvL& c : n->enc) if (c.w1d_off >= 0) w1d_image(n->tensors[c.wt].host.data(), c.Cin, c.Cout, c.transposed, arena.data() + c.w1d_off);
+  for (ConvL& c : n->dec) if (c.w1d_off >= 0) w1d_image(n->tensors[c.wt].host.data(), c.Cin, c.Cout, c.transposed, arena.data() + c.w1d_off);
   for (ConvL& c : n->dec) { pack_conv_few(n, c, arena); pack_conv(n, c, arena); pack_conv_bf16(n, c, arena); pack_conv_wf6(n, c, arena); pack_conv_wino(n, c, arena); pack_conv_wino6(n, c, arena); }
   for (const TcnBlock& tb : n->tcn)
     for (int h = 0; h < 2; ++h) {

@@ -17,14 +17,14 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 # every instantiation that runs in the bench's timed region in the `bf16x6` (headline) and `f32` modes, plus the TCN / MVDR /
 # layout kernels of both: no spills, no scratch
 HOT = [
-    "mn::conv3x3_mfma<1, 0, 0, false>", "mn::conv3x3_mfma<2, 0, 0, false>",        # f32: stride-1 convs, 32 / 64 channels
-    "mn::conv3x3_mfma<1, 1, 0, false>", "mn::conv3x3_mfma<2, 1, 0, false>",        # f32: stride-2 convs
-    "mn::conv3x3_mfma<1, 2, 0, false>",                                            # f32: stride-2 transposed convs
-    "mn::conv3x3_mfma<1, 0, 0, true>", "mn::conv3x3_mfma<1, 0, 3, true>",          # first layer (12 input channels)
-    "mn::conv3x3_mfma<1, 0, 3, false>",                                            # (first layer on the f32 kernel: MISONET_X6_FIRST=0)
+    "mn::conv3x3_mfma<1, 0, 0, false, false>", "mn::conv3x3_mfma<2, 0, 0, false, false>",        # f32: stride-1 convs, 32 / 64 channels
+    "mn::conv3x3_mfma<1, 1, 0, false, false>", "mn::conv3x3_mfma<2, 1, 0, false, false>",        # f32: stride-2 convs
+    "mn::conv3x3_mfma<1, 2, 0, false, false>",                                            # f32: stride-2 transposed convs
+    "mn::conv3x3_mfma<1, 0, 0, true, false>", "mn::conv3x3_mfma<1, 0, 3, true, false>",          # first layer (12 input channels)
+    "mn::conv3x3_mfma<1, 0, 3, false, false>",                                            # (first layer on the f32 kernel: MISONET_X6_FIRST=0)
     "mn::conv3x3_wino_f32<0>",                                                     # f32w: the DenseBlock convs (Winograd F(2x2, 3x3))
     "mn::conv3x3_few<4>", "mn::conv3x3_few<2>",                                    # the 4- / 2-channel last layer on the vector ALU (f32, f32w)
-    "mn::conv3x3_mfma<1, 3, 0, false>", "mn::conv3x3_mfma<2, 3, 0, false>",        # decoder 0 on the single bottleneck row
+    "mn::conv3x3_mfma<1, 3, 0, false, false>", "mn::conv3x3_mfma<2, 3, 0, false, false>",        # decoder 0 on the single bottleneck row
     "mn::conv3x3_x6_first<3>", "mn::conv3x3_x6_first<4>",                          # first layer in bf16x6 (round 4)
     "mn::conv3x3_bf16x6<0, 8, false, 4, false, false, 0>", "mn::conv3x3_bf16x6<0, 8, false, 3, false, false, 0>",    # 38 % + 28 % of the bf16x6 step
     "mn::conv3x3_bf16x6<0, 8, false, 4, false, true, 0>",                             # F <= 31 layers (two statistic units)
@@ -42,8 +42,8 @@ HOT = [
 # known spillers that are NOT on the bench's path, with the scratch they are allowed (bytes per lane): instantiations of
 # the opt-in modes / of shapes this network does not have.  A number going UP here is a regression too.
 TOLERATED = {
-    "mn::conv3x3_mfma<2, 0, 3, false>": 64, "mn::conv3x3_mfma<2, 0, 4, false>": 32,      # 64-channel planar-in / oct-out: unused
-    "mn::conv3x3_mfma<1, 2, 3, false>": 28,                                              # row-pair transposed tile writing oct3: MISONET_X6_FIRST=0 runs only
+    "mn::conv3x3_mfma<2, 0, 3, false, false>": 64, "mn::conv3x3_mfma<2, 0, 4, false, false>": 32,      # 64-channel planar-in / oct-out: unused
+    "mn::conv3x3_mfma<1, 2, 3, false, false>": 28,                                              # row-pair transposed tile writing oct3: MISONET_X6_FIRST=0 runs only
     "mn::conv3x3_bf16x6<0, 8, true, 4, false, false, 0>": 224,                                     # fp16-piece hand-over layer: experiment-build mode f16x3 only
     "mn::mvdr_scm_eig<8>": 600,                                                          # M = 8 microphones (tests only)
 }
@@ -95,8 +95,8 @@ def test_headline_kernel_occupancy(table):
               "mn::conv3x3_bf16x6<0, 8, false, 4, false, true, 0>"):
         assert table[k]["vgprs"] <= 256 and table[k]["occupancy"] >= 2, table[k]
     # the f32 32-channel kernel is tuned for three workgroups per CU (<= 168 VGPRs)
-    assert table["mn::conv3x3_mfma<1, 0, 0, false>"]["vgprs"] <= 168
-    assert table["mn::conv3x3_mfma<1, 0, 0, false>"]["occupancy"] >= 3
+    assert table["mn::conv3x3_mfma<1, 0, 0, false, false>"]["vgprs"] <= 168
+    assert table["mn::conv3x3_mfma<1, 0, 0, false, false>"]["occupancy"] >= 3
     # the first-layer kernel is latency-bound: three workgroups per CU (<= 168 VGPRs, 52 KB of LDS each)
     assert table["mn::conv3x3_x6_first<3>"]["vgprs"] <= 168 and table["mn::conv3x3_x6_first<3>"]["occupancy"] >= 3
 

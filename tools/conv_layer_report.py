@@ -37,7 +37,7 @@ def main():
     name_col = "name" if "name" in cols else "kernel_name"
     rows = cur.execute(f"select {name_col}, start, end from kernels order by start").fetchall()
     conv = [(n, e - s) for n, s, e in rows if "conv3x3_" in n]
-    assert len(conv) % 128 == 0, len(conv)
+    assert len(conv) >= 128, len(conv)      # (+ the two launches of the f32w self-check at the first commit)
     last = conv[-128:]
     l1, l3 = layers(12, 4), layers(16, 2)
     print(f"{'layer':14s} {'Cin':>4s} {'Cout':>4s} {'F':>4s} {'ms(MISO1 x%d)' % (6*B):>14s} {'TF/s':>7s} {'ms(MISO3 x%d)' % (2*B):>14s} {'TF/s':>7s}")
