@@ -561,16 +561,23 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
       // its channels have zero weights and no memory.  Their share of the epilogue (reads, transform, ELU, dropped stores) is
       // skipped: a wave-uniform branch per quad; their statistics entries are the zeros they would have computed.
       const int nquad = (a.Cout - cbase + 7) >> 3;           // valid quads of this group (>= 4: all)
-      wfor<16>([&](auto rc) __attribute__((always_inline)) {
-        constexpr int r = decltype(rc)::value;
-        constexpr int kr = (r & 3) + 8 * (r >> 2);
-        if ((r >> 2) >= nquad) {
-          // (the store is still ISSUED, out of range = dropped by the hardware: the s_waitcnt vmcnt immediates of the next two
-          // chunks count exactly W_NSTORE stores per epilogue)
+      // (ONE branch per quad, the valid quad the fall-through: a taken branch costs a lone wave ~30 cycles -- the first version
+      // tested per register and cost the 32-channel layers what it saved the 24-channel ones)
+      wfor<4>([&](auto qc_) __attribute__((always_inline)) {
+      constexpr int qd = decltype(qc_)::value;
+      if (__builtin_expect(qd >= nquad, 0)) {
+        // (the stores are still ISSUED, out of range = dropped by the hardware: the s_waitcnt vmcnt immediates of the next two
+        // chunks count exactly W_NSTORE stores per epilogue)
+        wfor<4>([&](auto r4) __attribute__((always_inline)) {
+          constexpr int r = 4 * qd + decltype(r4)::value;
           if (!(DBG & 64)) __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{0u, 0u, 0u, 0u}, rs_out, 0x80000000u, 0, 2);
           s1[r] = 0.f; s2[r] = 0.f;
-          return;
-        }
+        });
+        return;
+      }
+      wfor<4>([&](auto r4) __attribute__((always_inline)) {
+        constexpr int r = 4 * qd + decltype(r4)::value;
+        constexpr int kr = (r & 3) + 8 * (r >> 2);
         const unsigned coff = (unsigned)(cbase + kr) * P4;
         const wf2 bb = *W_LP(const wf2, tab_a + kr * 24);
         // The packed arithmetic is written as VECTOR expressions, not asm: the compiler forms the v_pk_*_f32 itself (op_sel / neg
@@ -584,7 +591,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
           // (e0, e1) = (m0 + m1 + m2, m1 - m2 - M3) = (m1 + m2, m1 - m2) + (m0, m3): the weight image carries a minus sign at
           // nu = 3, so m3 = -M3 (and at xi = 3, so E[3] = -E3): the only mixed-sign step left is the one op_sel / neg instruction
           // below (in C the compiler builds the (m2, -m2) pair with a v_xor)
-          E[x] = pk_spm(wf2{m1, m2}) + wf2{m0, m3};
+          E[x] = wf2{m1 + m2, m1 - m2} + wf2{m0, m3};            // (two plain adds: the packed op_sel form needs an asm block, and every asm block is padded with an s_nop on each side)
         });
         wf2 yt = (E[0] + E[1]) + (E[2] + bb);                         // (y00, y01): row fa, frames t, t + 1
         wf2 yb = (E[1] - E[2]) + (bb + E[3]);                         // (y10, y11): row fa + 1
@@ -608,6 +615,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
         const wf2 zs = zt + zb, zq = __builtin_elementwise_fma(zb, zb, zt * zt);
         s1[r] = zs.x + zs.y;
         s2[r] = zq.x + zq.y;
+      });
       });
       W_STAMP(11)
       if (!(DBG & 128)) {
