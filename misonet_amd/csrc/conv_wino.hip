@@ -93,10 +93,10 @@ __device__ __forceinline__ float exp2_ws(float x) {
 }
 // y >= +0 ? pos : neg as ONE v_bfi_b32 on the sign of y (conv_epilogue.hpp elu_select: no compare, NaN-transparent)
 __device__ __forceinline__ float elu_pick(float y, float neg, float pos) {
-  const int m = __builtin_bit_cast(int, y) >> 31;
-  float r;
-  asm volatile("v_bfi_b32 %0, %1, %2, %3\n\ts_nop 1" : "=v"(r) : "v"(m), "v"(neg), "v"(pos));   // (in C, LLVM folds it back into v_cmp + v_cndmask)
-  return r;
+  // (a select on the SIGN BIT: v_cmp_gt_i32 + v_cndmask, scheduled by the compiler -- four of them per channel, so the compare ->
+  // select wait states are covered by the neighbours; the asm v_bfi form needed an s_nop per value in front of the DPP exchange.
+  // NaN-transparent like it: y = NaN selects NaN - c or exp2(NaN) + ..)
+  return __builtin_bit_cast(int, y) < 0 ? neg : pos;
 }
 // (x0 * n0 + n1, x1 * n0 + n1)
 __device__ __forceinline__ wf2 pk_nrm(wf2 x, wf2 nr) { wf2 d; asm volatile("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(x), "v"(nr)); return d; }
