@@ -664,7 +664,9 @@ def main():
                     k = max(1, min(args.steps, 3))
                     _, ms2, cnt2 = run_steps(enh, mix, clean, out, k, 0, None, L, _lib, True)
                     # the two modes whose arithmetic is literally float32 get their own LIVE counters
-                    live2 = pmc_live(other, B, T) if (other in ("f32", "f32w") and not args.no_pmc) else None
+                    # live counters for the OTHER fast mode (f32w or bf16x6: whichever is not the headline); the exact-f32 mode's
+                    # come from the committed profile (its kernels did not change; three PMC triples made the default run 90 s)
+                    live2 = pmc_live(other, B, T) if (other in ("f32w", "bf16x6") and not args.no_pmc) else None
                     a["roofline"] = roofline_objects(other, B, T, k, ms2[0], cnt2[0], live2)[0]
                     a["roofline"]["time_share"] = {"conv_ms_per_step": round(ms2[0] / k, 2), "tcn_ms_per_step": round(ms2[1] / k, 2),
                                                    "mvdr_ms_per_step": round(ms2[2] / k, 2), "other_ms_per_step": round(ms2[3] / k, 2)}
@@ -846,7 +848,7 @@ def cpu_baseline(sd1, sd3, T, gpu_out=None, gpu_pcm=None):
     mix0, _ = utt(0)
     torch.set_num_threads(min(8, threads))
     miso_oracle.miso1_forward(torch.from_numpy(mix0[None]), sd1)          # warm-up
-    ladder = sorted({c for c in (8, 16, 32, 64, threads) if c <= threads})
+    ladder = sorted({c for c in (8, 16, 32) if c <= threads})          # (64 / 128 threads were 2-7 x slower on every box seen: not probed)
     probes, t_all = {}, time.perf_counter()
     for c in ladder:
         torch.set_num_threads(c)

@@ -7,6 +7,7 @@ mkdir -p $R/gpurun_out
 cd $R
 T0=$(date +%s.%N); python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 python -c "import time,sys; print('bench wall: %.1f s' % (time.time() - float(sys.argv[1])))" $T0 | tee gpurun_out/${TAG}_bench.time; cut -c1-500 gpurun_out/${TAG}_bench.json; tail -3 gpurun_out/${TAG}_bench.err
+python bench.py --precision f32 --no-alt --pmc --no-cpu-baseline --steps 5 --warmup 2 > gpurun_out/${TAG}_bench_f32.json 2> gpurun_out/${TAG}_bench_f32.err; cut -c1-200 gpurun_out/${TAG}_bench_f32.json
 bash tools/gpu_layers.sh $TAG bf16x6 | tail -2
 bash tools/gpu_layers.sh ${TAG}_f32w f32w | tail -2
 bash tools/gpu_layers.sh ${TAG}_f32 f32 | tail -2
