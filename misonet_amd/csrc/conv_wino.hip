@@ -68,6 +68,13 @@ __device__ __forceinline__ void wino_mfma(float uu, float vv) {
   if (Z) asm volatile("v_mfma_f32_32x32x2_f32 a[%0:%1], %2, %3, 0" ::"n"(16 * P), "n"(16 * P + 15), "v"(uu), "v"(vv) : W_ACLOB);
   else asm volatile("v_mfma_f32_32x32x2_f32 a[%0:%1], %2, %3, a[%0:%1]" ::"n"(16 * P), "n"(16 * P + 15), "v"(uu), "v"(vv) : W_ACLOB);
 }
+// G16 (round 6): the 16-channel group of a 48-channel layer on v_mfma_f32_16x16x4_f32 -- M = 16 output channels, N = 16 tiles, K = 4
+// input channels; accumulator block B = a[4 B : 4 B + 3] (layout checked by tools/micro/mfma16_layout.hip)
+template <int B, bool Z = false>
+__device__ __forceinline__ void wino_mfma16(float uu, float vv) {
+  if (Z) asm volatile("v_mfma_f32_16x16x4_f32 a[%0:%1], %2, %3, 0" ::"n"(4 * B), "n"(4 * B + 3), "v"(uu), "v"(vv) : W_ACLOB);
+  else asm volatile("v_mfma_f32_16x16x4_f32 a[%0:%1], %2, %3, a[%0:%1]" ::"n"(4 * B), "n"(4 * B + 3), "v"(uu), "v"(vv) : W_ACLOB);
+}
 // packed f32 forms (semantics checked on the GPU by tools/micro/pk_opsel.hip)
 __device__ __forceinline__ wf2 pk_add(wf2 a, wf2 b) { wf2 d; asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 __device__ __forceinline__ wf2 pk_sub(wf2 a, wf2 b) { wf2 d; asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
@@ -98,6 +105,12 @@ __device__ __forceinline__ float elu_pick(float y, float neg, float pos) {
   // NaN-transparent like it: y = NaN selects NaN - c or exp2(NaN) + ..)
   return __builtin_bit_cast(int, y) < 0 ? neg : pos;
 }
+// LDS store as inline asm (for a C++ LDS store the compiler waits for every LDS-DMA in flight); a function, because an asm operand
+// inside a generic lambda may not name a captured variable
+template <int OFF>
+__device__ __forceinline__ void lds_write_f32(unsigned addr, float v) {
+  asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
 // (x0 * n0 + n1, x1 * n0 + n1)
 __device__ __forceinline__ wf2 pk_nrm(wf2 x, wf2 nr) { wf2 d; asm volatile("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(x), "v"(nr)); return d; }
 // LDS map: 3 stages {normalised input [8][10][WTW] | U image 16 KB} | raw ring: 2 slots {80 items x 64 frames as the DMA leaves
@@ -115,7 +128,14 @@ static_assert(WINO_LDS <= 160 * 1024, "one workgroup per CU: at most 160 KB of L
 // DBG (timing experiments only, -DMISONET_EXPERIMENTS + MISONET_WINO_DBG): 1 = no staging side work in the chunk loop (wrong
 // results), 2 = no epilogue arithmetic / stores, 4 = no input transform, 8 / 16 / 32 = no weight DMA / input DMA / staging
 // arithmetic + LDS traffic (the three parts of 1), 64 / 128 / 256 = no epilogue stores / statistics / ELU.
-template <int DBG>
+// G16: the instantiation for a 16-channel output group (the second group of the 48-channel layer dec6.db.c5, model.py:64-73: half of
+// a 32-row MFMA would be padding -- 5.9 ms per step).  Same stream, staging, DMA and bookkeeping; what differs is the operand path:
+//   v_mfma_f32_16x16x4_f32: lane (kk = lane >> 4, nn = lane & 15) <-> B operand V_p[ci = 4 s + kk][tile nn + 16 g], A operand
+//   U_p[co = nn][ci = 4 s + kk]; a K-step = 4 input channels = 16 positions x 2 tile groups = 32 MFMAs of 32 cycles, two K-steps
+//   per chunk; a lane transforms the patches of TWO tiles per K-step; 128 accumulators (block 2 p + g), register r of a block =
+//   channel 4 kk + r.  The 64 MFMA slots of a chunk carry the same side work as the 64 of the 32-row body, re-timed so that the
+//   staging is complete before the chunk barrier in front of the next stage's first operand fetch (slot 36 instead of 51).
+template <int DBG, bool G16 = false>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
   extern __shared__ __align__(16) float smem[];
   char* const smem_c = reinterpret_cast<char*>(smem);
@@ -126,8 +146,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
+  const int kk = lane >> 4, nn = lane & 15;      // G16 operand roles
   const int T = a.T, Tp = a.Tp, F = a.Fin, Cin = a.Cin;
   const int nchunk = Cin / WCK;
+  constexpr unsigned WIMG_B = G16 ? 2u * 4u * 4u * 16u * 16u : (unsigned)(WW_FLOATS * 4);   // U image bytes per chunk: [s][pos / 4][kk][16 co][pos % 4] / [pos / 4][ci][32 co][pos % 4]
 
   // ---- this workgroup's tiles: q0, q0 + qstep, ... < Q of the linear (sample slot, row tile, frame tile, channel group) list of
   // its XCD.  STRIDED, not a contiguous range: at any moment the 32 workgroups of an XCD then work on 32 NEIGHBOURING tiles --
@@ -175,11 +197,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
   // its last step, the first operands of stage n (d0n, un); the chunk being staged is written to stage n (cn, hn).  After a
   // chunk every register moves one stage on with ONE v_add of an SGPR (+ stride, or - 2 strides at the wrap), so the chunk
   // body names no stage and exists once per (frame masks, epilogue distance) instead of three times.
-  constexpr unsigned STAGE_B = (unsigned)WSTAGE_FLOATS * 4u, STEP_B = (unsigned)(2 * WNR * WTW) * 4u;
-  const unsigned dbase = lds0 + (unsigned)((half * WNR + 2 * wave) * WTW + 2 * l31) * 4u;
+  constexpr unsigned STAGE_B = (unsigned)WSTAGE_FLOATS * 4u, STEP_B = (unsigned)((G16 ? 4 : 2) * WNR * WTW) * 4u;
+  const unsigned dbase = G16 ? lds0 + (unsigned)((kk * WNR + 2 * wave) * WTW + 2 * nn) * 4u
+                             : lds0 + (unsigned)((half * WNR + 2 * wave) * WTW + 2 * l31) * 4u;
   unsigned d1 = launder(dbase + STEP_B), d2 = launder(dbase + 2 * STEP_B), d3 = launder(dbase + 3 * STEP_B);
   unsigned d0n = launder(dbase + STAGE_B);
-  unsigned uc = launder(lds0 + (unsigned)WIN_FLOATS * 4u + (unsigned)(half * 32 + l31) * 16u);
+  unsigned uc = launder(lds0 + (unsigned)WIN_FLOATS * 4u + (unsigned)(G16 ? kk * 16 + nn : half * 32 + l31) * 16u);
   unsigned un = launder(uc + STAGE_B);
   unsigned cn = launder(lds0 + STAGE_B + (unsigned)(scr * WTW + 1 + 4 * sq) * 4u);
   unsigned hn = launder(lds0 + (hrole ? STAGE_B + (unsigned)(hit * WTW + (hside ? WTT + 1 : 0)) * 4u : WDUMMY_B + (unsigned)(tid & 63) * 4u));
@@ -192,10 +215,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
   const unsigned rhdma0 = WRAW_B + (unsigned)(WCK * WNR * WTT) * 4u + (unsigned)wave * 256u;
   const unsigned wdma0 = (unsigned)(WIN_FLOATS * 4) + (unsigned)wave * 1024u;          // + stage * WSTAGE_FLOATS * 4 + j * 4096
   const __amdgpu_buffer_rsrc_t rs_w = make_rsrc_e(reinterpret_cast<unsigned long long>(a.ww),
-                                                   (unsigned)(a.ncg * nchunk) * (unsigned)(WW_FLOATS * 4));
+                                                   (unsigned)(a.ncg * nchunk) * WIMG_B);
+  // (G16: the image is 8 KB = two pieces; pieces 2, 3 repeat 0, 1 into the same words -- the s_waitcnt immediates count four)
   unsigned wvo[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) wvo[j] = (unsigned)(tid + 256 * j) * 16u;
+  for (int j = 0; j < 4; ++j) wvo[j] = (unsigned)(tid + 256 * (G16 ? (j & 1) : j)) * 16u;
 
   // ---- load-side state L: the tile and chunk of the NEXT raw-input DMA (three chunks ahead of the matrix pipe).  What the
   // later steps need of a chunk's tile is latched when the chunk is issued and handed down L -> D -> C.  D: the chunk whose
@@ -280,7 +304,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
   {                                                                                                   \
     _Pragma("unroll") for (int i = 0; i < 6; ++i) { Cnr[i] = Dnr[i]; Dnr[i] = Lnr[i] + (unsigned)(kl * WCK * 8); } \
     Cfull = Dfull; Dfull = Lfull; Cmask = Dmask; Dmask = Lmask;                                       \
-    Dwso = (unsigned)(Lcg * nchunk + kl) * (unsigned)(WW_FLOATS * 4);                                 \
+    Dwso = (unsigned)(Lcg * nchunk + kl) * WIMG_B;                                                    \
   }
 #define W_ADVANCE                                                                                     \
   {                                                                                                   \
@@ -304,8 +328,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
 #define W_ISSUE_H                                                                                     \
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_l, MN_WLDS(smem_c + rhdma0 + lslot * (WRAW_FLOATS * 4)), 4, Lhoff, W_CB, 0, 0);
 #define W_ISSUE_W(J, ST, WSO)                                                                         \
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, MN_WLDS(smem_c + (ST) * (WSTAGE_FLOATS * 4) + wdma0 + (J) * 4096), 16, wvo[J], WSO, 0, 0);
-#define W_WSO_L ((unsigned)(Lcg * nchunk + kl) * (unsigned)(WW_FLOATS * 4))
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, MN_WLDS(smem_c + (ST) * (WSTAGE_FLOATS * 4) + wdma0 + (G16 ? ((J) & 1) : (J)) * 4096), 16, wvo[J], WSO, 0, 0);
+#define W_WSO_L ((unsigned)(Lcg * nchunk + kl) * WIMG_B)
 #define W_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");
 #define W_NR(DST, I) DST = *W_LP(const wf2, Cnr[I]);
 #define W_RR(DST, I) DST = *W_LP(const wf4, rofs + (I) * 4096);
@@ -338,6 +362,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
   // of this wave has completed (lgkmcnt(0)); the DMA the OTHER waves must see is covered by the explicit vmcnt in front of it
 #define W_BARRIER { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
 
+  wf2 dd16[2][4][2];                           // G16: the raw patches of the next step's two tile groups
+  wf2 vp16[2][4][2];                           // G16: their transforms
   wf2 dd[4][2];                                // raw patch of the next step: row i, columns (0, 1) / (2, 3)
   wf4 u[4];                                    // U operands: quad q = positions 4 q .. 4 q + 3; refilled quad by quad
   wf2 vp[4][2];                                // V operands of the running K-step: position 4 x + nu = vp[x][nu >> 1][nu & 1] (nu = 2 negated)
@@ -430,7 +456,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
 #define W_BK_S1 /* latch, scalar part; the chunk offset the vector part adds to the norm addresses */  \
   const unsigned klo_ = (unsigned)(kl * WCK * 8);                                                     \
   Cfull = Dfull; Dfull = Lfull;                                                                       \
-  Dwso = (unsigned)(Lcg * nchunk + kl) * (unsigned)(WW_FLOATS * 4);
+  Dwso = (unsigned)(Lcg * nchunk + kl) * WIMG_B;
 #define W_BK_S2 /* advance the load side (the tile change itself -- W_LOAD_SETUP -- stays behind the body) */ \
   lslot ^= 1; ++kl;
 #define W_BK_S3 /* stage rotation deltas, loop state */                                               \
@@ -464,6 +490,82 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
          W_XL(W_ISSUE_I(0)), W_XL(W_ISSUE_I(1)), W_XL(W_ISSUE_I(2)), W_XL(W_ISSUE_I(3)), W_XL(W_ISSUE_I(4)),  \
          W_XL(W_ISSUE_H) W_BK_S1 W_BK_S2 W_BK_S3, W_BK_V)
 
+  // ---- G16 chunk body (see the kernel's header comment).  Slot I of a K-step: position I >> 1, tile group I & 1. ----
+#define W_FD16(G, I0, DREG)                                                                           \
+  {                                                                                                   \
+    const unsigned si_ = (DREG) + (G) * 128u;                                                         \
+    dd16[G][I0][0] = *W_LP(const wf2, si_ + (I0) * (WTW * 4));                                        \
+    dd16[G][I0][1] = *W_LP(const wf2, si_ + (I0) * (WTW * 4) + 8);                                    \
+    dd16[G][I0 + 1][0] = *W_LP(const wf2, si_ + ((I0) + 1) * (WTW * 4));                              \
+    dd16[G][I0 + 1][1] = *W_LP(const wf2, si_ + ((I0) + 1) * (WTW * 4) + 8);                          \
+  }
+#define W_FU16(Q, UREG, S) u[Q] = *W_LP(const wf4, UREG + ((S) * 4 + (Q)) * 1024);
+#define W_TRANSFORM16(G)                                                                              \
+  {                                                                                                   \
+    const wf2 c0a = pk_sub(dd16[G][0][0], dd16[G][2][0]), c0b = pk_sub(dd16[G][0][1], dd16[G][2][1]); \
+    const wf2 c1a = pk_add(dd16[G][1][0], dd16[G][2][0]), c1b = pk_add(dd16[G][1][1], dd16[G][2][1]); \
+    const wf2 c2a = pk_sub(dd16[G][2][0], dd16[G][1][0]), c2b = pk_sub(dd16[G][2][1], dd16[G][1][1]); \
+    const wf2 c3a = pk_sub(dd16[G][1][0], dd16[G][3][0]), c3b = pk_sub(dd16[G][1][1], dd16[G][3][1]); \
+    vp16[G][0][0] = pk_t01(c0a, c0b); vp16[G][0][1] = pk_t23(c0a, c0b);                               \
+    vp16[G][1][0] = pk_t01(c1a, c1b); vp16[G][1][1] = pk_t23(c1a, c1b);                               \
+    vp16[G][2][0] = pk_t01(c2a, c2b); vp16[G][2][1] = pk_t23(c2a, c2b);                               \
+    vp16[G][3][0] = pk_t01(c3a, c3b); vp16[G][3][1] = pk_t23(c3a, c3b);                               \
+  }
+#define W_MF16(I, CS) wino_mfma16<(I), (POST == 2 && (CS) == 0)>(u[(I) >> 3][((I) >> 1) & 3], vp16[(I) & 1][(I) >> 3][(((I) >> 1) & 3) >> 1][((I) >> 1) & 1]);
+#define W_S16(I, CS, ...) W_MF16(I, CS) __VA_ARGS__ W_SB
+#define W_CHUNK16_                                                                                    \
+  /* K-step 0 (channels 0-3 of the chunk); operands of K-step 1 come from the same stage (d1, uc) */  \
+  W_S16(0, 0, W_FU16(3, uc, 0))                                                                       \
+  W_S16(1, 0, W_X(if (POST) { W_VMCNT(26) } else { W_VMCNT(10) } W_RR(rwa, 0)))                       \
+  W_S16(2, 0, W_X(W_RR(rwb, 1)))                                                                      \
+  W_S16(3, 0, W_X(W_NR(nra, 0)))                                                                      \
+  W_S16(4, 0, W_X(W_NR(nrb, 1)))                                                                      \
+  W_S16(5, 0) W_S16(6, 0)                                                                             \
+  W_S16(7, 0, W_X(W_CC(cva, rwa, nra) W_CC(cvb, rwb, nrb)))                                           \
+  W_S16(8, 0, W_FU16(0, uc, 1) W_X(W_CW(cva, 0)))                                                     \
+  W_S16(9, 0, W_X(W_CW(cvb, 1)))                                                                      \
+  W_S16(10, 0, W_FD16(0, 0, d1) W_X(W_RR(rwa, 2)))                                                    \
+  W_S16(11, 0, W_FD16(0, 2, d1) W_X(W_RR(rwb, 3)))                                                    \
+  W_S16(12, 0, W_FD16(1, 0, d1) W_X(W_NR(nra, 2)))                                                    \
+  W_S16(13, 0, W_FD16(1, 2, d1) W_X(W_NR(nrb, 3)))                                                    \
+  W_S16(14, 0) W_S16(15, 0)                                                                           \
+  W_S16(16, 0, W_FU16(1, uc, 1))                                                                      \
+  W_S16(17, 0) W_S16(18, 0)                                                                           \
+  W_S16(19, 0, W_X(W_CC(cva, rwa, nra) W_CC(cvb, rwb, nrb)))                                          \
+  W_S16(20, 0, W_X(W_CW(cva, 2)))                                                                     \
+  W_S16(21, 0, W_X(W_CW(cvb, 3)))                                                                     \
+  W_S16(22, 0, W_X(W_RR(rwa, 4)))                                                                     \
+  W_S16(23, 0, W_X(W_RRH))                                                                            \
+  W_S16(24, 0, W_FU16(2, uc, 1) W_X(W_NR(nra, 4)))                                                    \
+  W_S16(25, 0, W_X(W_NR(nrb, 5)))                                                                     \
+  W_S16(26, 0) W_S16(27, 0) W_S16(28, 0) W_S16(29, 0) W_S16(30, 0) W_S16(31, 0)                       \
+  W_TRANSFORM16(0) W_TRANSFORM16(1) W_X(W_CC(cva, rwa, nra) W_CCH(nrb)) W_SB                          \
+  /* K-step 1; the staging of chunk g + 1 is complete behind slot 1, the barrier stands behind slot 3, then the next stage's operands */ \
+  W_S16(0, 1, W_FU16(3, uc, 1) W_X(W_CW(cva, 4)))                                                     \
+  W_S16(1, 1, W_X(W_CWH))                                                                             \
+  W_S16(2, 1) W_S16(3, 1)                                                                             \
+  W_XW(if (POST == 2) { W_VMCNT(22) } else { W_VMCNT(6) }) W_BARRIER                                  \
+  W_S16(4, 1, W_XW(W_ISSUE_W(0, stnn, Dwso)))                                                         \
+  W_S16(5, 1, W_XW(W_ISSUE_W(1, stnn, Dwso)))                                                         \
+  W_S16(6, 1, W_XW(W_ISSUE_W(2, stnn, Dwso)))                                                         \
+  W_S16(7, 1, W_XW(W_ISSUE_W(3, stnn, Dwso)))                                                         \
+  W_S16(8, 1, W_FU16(0, un, 0) W_XL(W_ISSUE_I(0)))                                                    \
+  W_S16(9, 1, W_XL(W_ISSUE_I(1)))                                                                     \
+  W_S16(10, 1, W_FD16(0, 0, d0n) W_XL(W_ISSUE_I(2)))                                                  \
+  W_S16(11, 1, W_FD16(0, 2, d0n) W_XL(W_ISSUE_I(3)))                                                  \
+  W_S16(12, 1, W_FD16(1, 0, d0n) W_XL(W_ISSUE_I(4)))                                                  \
+  W_S16(13, 1, W_FD16(1, 2, d0n) W_XL(W_ISSUE_H))                                                     \
+  W_S16(14, 1) W_S16(15, 1)                                                                           \
+  W_S16(16, 1, W_FU16(1, un, 0))                                                                      \
+  W_S16(17, 1) W_S16(18, 1) W_S16(19, 1) W_S16(20, 1) W_S16(21, 1) W_S16(22, 1) W_S16(23, 1)          \
+  W_S16(24, 1, W_FU16(2, un, 0))                                                                      \
+  W_S16(25, 1) W_S16(26, 1) W_S16(27, 1) W_S16(28, 1) W_S16(29, 1)                                    \
+  W_S16(30, 1, W_BK_S1 W_BK_S2 W_BK_S3)                                                               \
+  W_S16(31, 1)                                                                                        \
+  W_TRANSFORM16(0) W_TRANSFORM16(1) W_BK_V W_SB
+  // the body of an iteration: one chunk on the matrix pipe in the instantiation's operand form
+#define W_BODY_ if constexpr (G16) { W_CHUNK16_ } else { W_CHUNK_ }
+
   // ---- prologue: raw chunks 0, 1, 2 and the U images of chunks 0, 1 on their way, chunk 0 staged, operands of (chunk 0,
   // step 0) fetched and transformed ----
   constexpr bool RAG = true;                         // (the prologue always applies the frame masks)
@@ -496,8 +598,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
   rofs = rofs0 + WRAW_FLOATS * 4;
   rhofs = rhofs0 + WRAW_FLOATS * 4;
   W_BARRIER
-  W_FD(0, dbase) W_FD(2, dbase) W_FU(0, uc, 0) W_FU(1, uc, 0) W_FU(2, uc, 0)
-  W_TRANSFORM
+  if constexpr (G16) {
+    W_FD16(0, 0, dbase) W_FD16(0, 2, dbase) W_FD16(1, 0, dbase) W_FD16(1, 2, dbase) W_FU16(0, uc, 0) W_FU16(1, uc, 0) W_FU16(2, uc, 0)
+    W_TRANSFORM16(0) W_TRANSFORM16(1)
+  } else {
+    W_FD(0, dbase) W_FD(2, dbase) W_FU(0, uc, 0) W_FU(1, uc, 0) W_FU(2, uc, 0)
+    W_TRANSFORM
+  }
   wfor<256>([&](auto i) __attribute__((always_inline)) { agpr_zero<decltype(i)::value>(); });
   asm volatile("s_nop 4");
 
@@ -512,10 +619,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
     // do not exist) x the distance to the last tile epilogue (the immediates of two waits)
     if (Cfull) {
       constexpr bool RAG = false;
-      if (post == 0) { constexpr int POST = 0; W_CHUNK_ } else if (post == 1) { constexpr int POST = 1; W_CHUNK_ } else { constexpr int POST = 2; W_CHUNK_ }
+      if (post == 0) { constexpr int POST = 0; W_BODY_ } else if (post == 1) { constexpr int POST = 1; W_BODY_ } else { constexpr int POST = 2; W_BODY_ }
     } else {
       constexpr bool RAG = true;
-      if (post == 0) { constexpr int POST = 0; W_CHUNK_ } else if (post == 1) { constexpr int POST = 1; W_CHUNK_ } else { constexpr int POST = 2; W_CHUNK_ }
+      if (post == 0) { constexpr int POST = 0; W_BODY_ } else if (post == 1) { constexpr int POST = 1; W_BODY_ } else { constexpr int POST = 2; W_BODY_ }
     }
     if (++kc == nchunk) {
       // ---- tile epilogue: Y = A^T M A per (channel, tile), + bias, ELU, centring, stores, statistics ----
@@ -527,77 +634,41 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
       const int t0 = tt_ * WTT, f0 = ft_ * WFT;
       const int cbase = cg * 32;
       const int fa = f0 + 2 * wave;
-      const int t = t0 + 2 * l31;
       const bool r0ok = fa < F, r1ok = fa + 1 < F;
-      const bool c0ok = t < T, c1ok = t + 1 < T;
       const unsigned P4 = (unsigned)F * (unsigned)Tp * 4u;
       const float* ob_ = a.out + (long long)n * a.out_bstride + (long long)a.out_c0 * F * Tp;
       const __amdgpu_buffer_rsrc_t rs_out = make_rsrc_e(reinterpret_cast<unsigned long long>(ob_), (unsigned)a.Cout * P4);
-      const unsigned vbase = (unsigned)(fa * Tp + t) * 4u + (unsigned)(4 * half) * P4;
-      // Stores are 16 bytes per lane (the store path is ISSUE-bound: 32 8-byte stores per lane cost 17 k cycles per tile, a
-      // fifth of the kernel): neighbouring lanes exchange pairs, the even lane stores frames t .. t + 3 of row fa, the odd lane
-      // frames t - 2 .. t + 1 of row fa + 1.  A group whose last frames are >= T writes words of the row's padding [T, Tp),
-      // which every consumer masks.
-      const bool ev = (l31 & 1) == 0;
-      const unsigned vo_x = ev ? ((r0ok && c0ok) ? vbase : 0x80000000u)
-                               : ((r1ok && t - 2 < T) ? vbase + (unsigned)Tp * 4u - 8u : 0x80000000u);
-      const float m00 = (r0ok && c0ok) ? 1.f : 0.f, m01 = (r0ok && c1ok) ? 1.f : 0.f;
-      const float m10 = (r1ok && c0ok) ? 1.f : 0.f, m11 = (r1ok && c1ok) ? 1.f : 0.f;
-      // explicit LDS addresses (a generic-pointer access is a FLAT op, and a flat op waits for vmcnt(0) = for every store), the
-      // table base laundered: one register + immediates instead of an address add per access (WBIAS_B is beyond the 16-bit offset)
-      const unsigned tab_a = launder(lds0 + WBIAS_B + (unsigned)(cbase + 4 * half) * 24u);
       const unsigned red_a = lds0 + WRED_B;
       // The epilogue is VALU work the matrix pipe waits for (one wave per SIMD, and the f32 MFMA shares the vector ALU anyway):
       // it is written in PACKED f32 -- (e0, e1) = the two output columns of a position row, (y00, y01) / (y10, y11) = the two
       // frames of an output row -- 8 + 6 packed adds instead of 16 + 16 plain ones per channel, the ELU's scale / centring and
       // the statistics packed as well; per-channel constants come as pairs from the LDS table.
-      // (laundered: the compiler otherwise re-materialises these pairs from their SGPR conditions for every channel)
+      // (laundered: the compiler otherwise re-materialises the pair from its constant for every channel)
       wf2 l2e = {1.44269504088896341f, 1.44269504088896341f};
-      wf2 mt = {m00, m01}, mb = {m10, m11};
-      asm volatile("" : "+v"(l2e), "+v"(mt), "+v"(mb));
-      float s1[16], s2[16];
-      // Accumulator quad q (registers 4 q .. 4 q + 3) holds channels cbase + 8 q + {0 .. 3} + 4 half: with 24 (or, in the second
-      // group of a 48-channel layer, 16) output channels the last one (two) of the four quads is padding in BOTH half-waves --
-      // its channels have zero weights and no memory.  Their share of the epilogue (reads, transform, ELU, dropped stores) is
-      // skipped: a wave-uniform branch per quad; their statistics entries are the zeros they would have computed.
-      const int nquad = (a.Cout - cbase + 7) >> 3;           // valid quads of this group (>= 4: all)
-      // (ONE branch per quad, the valid quad the fall-through: a taken branch costs a lone wave ~30 cycles -- the first version
-      // tested per register and cost the 32-channel layers what it saved the 24-channel ones)
-      wfor<4>([&](auto qc_) __attribute__((always_inline)) {
-      constexpr int qd = decltype(qc_)::value;
-      if (__builtin_expect(qd >= nquad, 0)) {
-        // (the stores are still ISSUED, out of range = dropped by the hardware: the s_waitcnt vmcnt immediates of the next two
-        // chunks count exactly W_NSTORE stores per epilogue)
-        wfor<4>([&](auto r4) __attribute__((always_inline)) {
-          constexpr int r = 4 * qd + decltype(r4)::value;
-          if (!(DBG & 64)) __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{0u, 0u, 0u, 0u}, rs_out, 0x80000000u, 0, 2);
-          s1[r] = 0.f; s2[r] = 0.f;
-        });
-        return;
-      }
-      wfor<4>([&](auto r4) __attribute__((always_inline)) {
-        constexpr int r = 4 * qd + decltype(r4)::value;
-        constexpr int kr = (r & 3) + 8 * (r >> 2);
-        const unsigned coff = (unsigned)(cbase + kr) * P4;
-        const wf2 bb = *W_LP(const wf2, tab_a + kr * 24);
-        // The packed arithmetic is written as VECTOR expressions, not asm: the compiler forms the v_pk_*_f32 itself (op_sel / neg
-        // modifiers folded) and knows that no wait state is needed between two of them -- behind every asm block it pads an s_nop,
-        // 13 per channel, and outside the MFMA shadow every instruction of a lone wave costs its ~4-cycle issue slot.
+      asm volatile("" : "+v"(l2e));
+      // ONE (channel, tile) item: the 16 positions m(xi, nu) of the lane -> 2 x 2 outputs, + bias, ELU, centring, the 16-byte store
+      // (neighbouring lanes exchange pairs: the even lane stores 4 frames of row fa, the odd lane 4 frames of row fa + 1), the
+      // masked sums.  getm(xi, nu): the accumulator register of a position; tabp: the channel's LDS table entry.
+      // The packed arithmetic is written as VECTOR expressions, not asm: the compiler forms the v_pk_*_f32 itself (op_sel / neg
+      // modifiers folded) and knows that no wait state is needed between two of them -- behind every asm block it pads an s_nop,
+      // and outside the MFMA shadow every instruction of a lone wave costs its ~4-cycle issue slot.
+      auto epi_item = [&](auto getm, unsigned tabp, unsigned voff, bool evl, const wf2& mt, const wf2& mb, float& o1, float& o2) __attribute__((always_inline)) {
+        const wf2 bb = *W_LP(const wf2, tabp);
         wf2 E[4];
         wfor<4>([&](auto xc) __attribute__((always_inline)) {
           constexpr int x = decltype(xc)::value;
-          const float m0 = agpr_get<(4 * x + 0) * 16 + r>(), m1 = agpr_get<(4 * x + 1) * 16 + r>();
-          const float m2 = agpr_get<(4 * x + 2) * 16 + r>(), m3 = agpr_get<(4 * x + 3) * 16 + r>();
+          const float m0 = getm(xc, std::integral_constant<int, 0>{}), m1 = getm(xc, std::integral_constant<int, 1>{});
+          const float m2 = getm(xc, std::integral_constant<int, 2>{}), m3 = getm(xc, std::integral_constant<int, 3>{});
           // (e0, e1) = (m0 + m1 + m2, m1 - m2 - M3) = (m1 + m2, m1 - m2) + (m0, m3): the weight image carries a minus sign at
-          // nu = 3, so m3 = -M3 (and at xi = 3, so E[3] = -E3): the only mixed-sign step left is the one op_sel / neg instruction
-          // below (in C the compiler builds the (m2, -m2) pair with a v_xor)
-          E[x] = wf2{m1 + m2, m1 - m2} + wf2{m0, m3};            // (two plain adds: the packed op_sel form needs an asm block, and every asm block is padded with an s_nop on each side)
+          // nu = 3, so m3 = -M3 (and at xi = 3, so E[3] = -E3).  (Two plain adds for the mixed-sign step: its packed op_sel form
+          // needs an asm block, and every asm block is padded with an s_nop on each side.)
+          E[x] = wf2{m1 + m2, m1 - m2} + wf2{m0, m3};
         });
         wf2 yt = (E[0] + E[1]) + (E[2] + bb);                         // (y00, y01): row fa, frames t, t + 1
         wf2 yb = (E[1] - E[2]) + (bb + E[3]);                         // (y10, y11): row fa + 1
         if (!(DBG & 256)) {
-          // ELU(y) - c, c = ELU(bias):  y >= 0 ? y - c : exp(y) - (1 + c)   (elu_select's bit select on the sign of y)
-          const wf2 ncr = *W_LP(const wf2, tab_a + kr * 24 + 8), nc1 = *W_LP(const wf2, tab_a + kr * 24 + 16);
+          // ELU(y) - c, c = ELU(bias):  y >= 0 ? y - c : exp(y) - (1 + c)   (a select on the sign of y)
+          const wf2 ncr = *W_LP(const wf2, tabp + 8), nc1 = *W_LP(const wf2, tabp + 16);
           const wf2 xt = yt * l2e, xb = yb * l2e;
           const wf2 et = wf2{__builtin_amdgcn_exp2f(xt.x), __builtin_amdgcn_exp2f(xt.y)} + nc1;
           const wf2 eb = wf2{__builtin_amdgcn_exp2f(xb.x), __builtin_amdgcn_exp2f(xb.y)} + nc1;
@@ -608,14 +679,96 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
         if (!(DBG & 64)) {
           // (quad_perm [1,0,3,2]: the neighbour's value)
           const float n00 = dpp_get<0xB1>(yt.x), n01 = dpp_get<0xB1>(yt.y), n10 = dpp_get<0xB1>(yb.x), n11 = dpp_get<0xB1>(yb.y);
-          const wf4 o = {ev ? yt.x : n10, ev ? yt.y : n11, ev ? n00 : yb.x, ev ? n01 : yb.y};
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rs_out, (DBG & 512) ? 0x80000000u : vo_x + coff, 0, 2);   // non-temporal: read back by the NEXT launch, long after it left the L2
+          const wf4 o = {evl ? yt.x : n10, evl ? yt.y : n11, evl ? n00 : yb.x, evl ? n01 : yb.y};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rs_out, (DBG & 512) ? 0x80000000u : voff, 0, 2);   // non-temporal: read back by the NEXT launch, long after it left the L2
         }
         const wf2 zt = yt * mt, zb = yb * mb;
         const wf2 zs = zt + zb, zq = __builtin_elementwise_fma(zb, zb, zt * zt);
-        s1[r] = zs.x + zs.y;
-        s2[r] = zq.x + zq.y;
-      });
+        o1 = zs.x + zs.y;
+        o2 = zq.x + zq.y;
+      };
+      // (a store that is ISSUED out of range = dropped by the hardware: the s_waitcnt vmcnt immediates of the next two chunks count
+      // exactly W_NSTORE stores per epilogue)
+      auto dummy_store = [&]() __attribute__((always_inline)) {
+        if (!(DBG & 64)) __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{0u, 0u, 0u, 0u}, rs_out, 0x80000000u, 0, 2);
+      };
+      if constexpr (G16) {
+        // ---- 16-channel group: accumulator block 2 p + g (position p, tile group g), register r = channel 4 kk + r, tile nn + 16 g ----
+        const bool ev = (nn & 1) == 0;
+        const unsigned tab16 = launder(lds0 + WBIAS_B + (unsigned)(cbase + 4 * kk) * 24u);
+        float s1g[8], s2g[8];
+        wfor<2>([&](auto gc) __attribute__((always_inline)) {
+          constexpr int g = decltype(gc)::value;
+          const int t = t0 + 2 * (nn + 16 * g);
+          const bool c0ok = t < T, c1ok = t + 1 < T;
+          const unsigned vbase = (unsigned)(fa * Tp + t) * 4u + (unsigned)(cbase + 4 * kk) * P4;
+          const unsigned vo_x = ev ? ((r0ok && c0ok) ? vbase : 0x80000000u)
+                                   : ((r1ok && t - 2 < T) ? vbase + (unsigned)Tp * 4u - 8u : 0x80000000u);
+          wf2 mt = {(r0ok && c0ok) ? 1.f : 0.f, (r0ok && c1ok) ? 1.f : 0.f}, mb = {(r1ok && c0ok) ? 1.f : 0.f, (r1ok && c1ok) ? 1.f : 0.f};
+          asm volatile("" : "+v"(mt), "+v"(mb));
+          wfor<4>([&](auto rc) __attribute__((always_inline)) {
+            constexpr int r = decltype(rc)::value;
+            epi_item([&](auto xc, auto nc) __attribute__((always_inline)) { return agpr_get<((4 * decltype(xc)::value + decltype(nc)::value) * 2 + g) * 4 + r>(); },
+                     tab16 + r * 24, vo_x + (unsigned)r * P4, ev, mt, mb, s1g[4 * g + r], s2g[4 * g + r]);
+          });
+        });
+        wfor<8>([&](auto) __attribute__((always_inline)) { dummy_store(); });
+        W_STAMP(11)
+        if (!(DBG & 128)) {
+          // sums over the 16 tiles of a lane row (DPP: xor 1, xor 2, row_half_mirror, row_mirror) and the two tile groups
+          wfor<4>([&](auto rc) __attribute__((always_inline)) {
+            constexpr int r = decltype(rc)::value;
+            float x1 = s1g[r] + s1g[4 + r], x2 = s2g[r] + s2g[4 + r];
+            x1 += dpp_get<0xB1>(x1); x2 += dpp_get<0xB1>(x2);
+            x1 += dpp_get<0x4E>(x1); x2 += dpp_get<0x4E>(x2);
+            x1 += dpp_get<0x141>(x1); x2 += dpp_get<0x141>(x2);
+            x1 += dpp_get<0x140>(x1); x2 += dpp_get<0x140>(x2);
+            if (nn == 0) {
+              const unsigned ra_ = red_a + (unsigned)((wave * 32 + 4 * kk + r) * 2) * 4u;
+              lds_write_f32<0>(ra_, x1);
+              lds_write_f32<4>(ra_, x2);
+            }
+          });
+        }
+      } else {
+      const int t = t0 + 2 * l31;
+      const bool c0ok = t < T, c1ok = t + 1 < T;
+      const unsigned vbase = (unsigned)(fa * Tp + t) * 4u + (unsigned)(4 * half) * P4;
+      // Stores are 16 bytes per lane (the store path is ISSUE-bound: 32 8-byte stores per lane cost 17 k cycles per tile, a
+      // fifth of the kernel): neighbouring lanes exchange pairs, the even lane stores frames t .. t + 3 of row fa, the odd lane
+      // frames t - 2 .. t + 1 of row fa + 1.  A group whose last frames are >= T writes words of the row's padding [T, Tp),
+      // which every consumer masks.
+      const bool ev = (l31 & 1) == 0;
+      const unsigned vo_x = ev ? ((r0ok && c0ok) ? vbase : 0x80000000u)
+                               : ((r1ok && t - 2 < T) ? vbase + (unsigned)Tp * 4u - 8u : 0x80000000u);
+      // explicit LDS addresses (a generic-pointer access is a FLAT op, and a flat op waits for vmcnt(0) = for every store), the
+      // table base laundered: one register + immediates instead of an address add per access (WBIAS_B is beyond the 16-bit offset)
+      const unsigned tab_a = launder(lds0 + WBIAS_B + (unsigned)(cbase + 4 * half) * 24u);
+      wf2 mt = {(r0ok && c0ok) ? 1.f : 0.f, (r0ok && c1ok) ? 1.f : 0.f}, mb = {(r1ok && c0ok) ? 1.f : 0.f, (r1ok && c1ok) ? 1.f : 0.f};
+      asm volatile("" : "+v"(mt), "+v"(mb));
+      float s1[16], s2[16];
+      // Accumulator quad q (registers 4 q .. 4 q + 3) holds channels cbase + 8 q + {0 .. 3} + 4 half: with 24 output channels the
+      // last of the four quads is padding in BOTH half-waves -- its channels have zero weights and no memory.  Their share of the
+      // epilogue (reads, transform, ELU) is skipped: ONE wave-uniform branch per quad, the valid quad the fall-through (a taken
+      // branch costs a lone wave ~30 cycles: the first version tested per register and cost the 32-channel layers what it saved
+      // the 24-channel ones); their statistics entries are the zeros they would have computed.
+      const int nquad = (a.Cout - cbase + 7) >> 3;           // valid quads of this group (>= 4: all)
+      wfor<4>([&](auto qc_) __attribute__((always_inline)) {
+        constexpr int qd = decltype(qc_)::value;
+        if (__builtin_expect(qd >= nquad, 0)) {
+          wfor<4>([&](auto r4) __attribute__((always_inline)) {
+            constexpr int r = 4 * qd + decltype(r4)::value;
+            dummy_store();
+            s1[r] = 0.f; s2[r] = 0.f;
+          });
+          return;
+        }
+        wfor<4>([&](auto r4) __attribute__((always_inline)) {
+          constexpr int r = 4 * qd + decltype(r4)::value;
+          constexpr int kr = (r & 3) + 8 * (r >> 2);
+          epi_item([&](auto xc, auto nc) __attribute__((always_inline)) { return agpr_get<(4 * decltype(xc)::value + decltype(nc)::value) * 16 + r>(); },
+                   tab_a + kr * 24, vo_x + (unsigned)(cbase + kr) * P4, ev, mt, mb, s1[r], s2[r]);
+        });
       });
       W_STAMP(11)
       if (!(DBG & 128)) {
@@ -627,6 +780,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
           W_DSW(red_a + (unsigned)((wave * 32 + co_l) * 2) * 4u, x1, 0)
           W_DSW(red_a + (unsigned)((wave * 32 + co_l) * 2) * 4u, x2, 4)
         }
+      }
+      }
+      if (!(DBG & 128)) {
         W_BARRIER
         if (lane < 16) {                       // 16 of the 64 (channel, statistic) pairs per wave: no wave carries the whole tail
           const int pr = wave * 16 + lane;
@@ -678,6 +834,8 @@ static int wino_dbg_env() {
 hipError_t conv_wino_init() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_f32<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)WINO_LDS);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_f32<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS);
 #ifdef MISONET_EXPERIMENTS
 #define W_ATTR(D) if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_f32<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS);
   W_ATTR(1) W_ATTR(2) W_ATTR(3) W_ATTR(4) W_ATTR(7) W_ATTR(10) W_ATTR(18) W_ATTR(34) W_ATTR(64) W_ATTR(128) W_ATTR(256) W_ATTR(448) W_ATTR(512)
@@ -686,17 +844,45 @@ hipError_t conv_wino_init() {
   return e;
 }
 
+// one launch of the persistent kernel over the channel groups of `a` (G16: one 16-channel group)
+static hipError_t launch_wino_groups(ConvArgs a, int n_samples, hipStream_t s, bool g16);
+
 hipError_t launch_conv_wino(const ConvArgs& a_in, int n_samples, hipStream_t s) {
-  ConvArgs a = a_in;
-  if (!conv_wino_ok(a)) return hipErrorInvalidValue;
+  if (!conv_wino_ok(a_in)) return hipErrorInvalidValue;
+  // A layer whose channel count leaves a 16-channel group (the 48-channel dec6.db.c5) runs as two launches: its full 32-channel
+  // groups on the 32-row body, the last 16 channels on the 16-row body (a.ww16: their own weight image) -- half of a 32-row
+  // MFMA would be padding there.
+  if ((a_in.Cout & 31) == 16 && a_in.ww16 != nullptr) {
+    const int c32 = a_in.Cout - 16;
+    if (c32 > 0) {
+      ConvArgs a = a_in;
+      a.Cout = c32;
+      const hipError_t e = launch_wino_groups(a, n_samples, s, false);
+      if (e != hipSuccess) return e;
+    }
+    ConvArgs b = a_in;
+    b.Cout = 16;
+    b.out_c0 = a_in.out_c0 + c32;
+    b.bias = a_in.bias + c32;
+    b.ww = a_in.ww16;
+    return launch_wino_groups(b, n_samples, s, true);
+  }
+  return launch_wino_groups(a_in, n_samples, s, false);
+}
+
+static hipError_t launch_wino_groups(ConvArgs a, int n_samples, hipStream_t s, bool g16) {
   a.cop = 32;
-  a.ncg = (a.Cout + 31) / 32;
+  a.ncg = g16 ? 1 : (a.Cout + 31) / 32;
   const int cus = device_cus();
   if (cus <= 0) return hipErrorInvalidDevice;
   (void)conv_grid(a, n_samples, WTT, WFT, (n_samples % 8 == 0 && cus % 8 == 0) ? conv_xcd_env() : 0);   // ntx, nty, nsamp, xcd
   const long long tiles = (long long)n_samples * a.ntx * a.nty * a.ncg;
   const unsigned grid = (unsigned)(tiles < cus ? tiles : cus);
   const dim3 g(a.xcd ? (unsigned)cus : grid);
+  if (g16) {
+    hipLaunchKernelGGL((conv3x3_wino_f32<0, true>), g, dim3(256), WINO_LDS, s, a);
+    return hipGetLastError();
+  }
 #ifdef MISONET_EXPERIMENTS
   {
     static const int tl_cin = exp_env("MISONET_WINO_TIMELINE", 0);

@@ -43,6 +43,8 @@ struct ConvArgs {
   const unsigned short* w16; // bf16x3 path: packed [ncg][nchunk16][hi|lo][9][2][COP][8] bf16, or nullptr
   const void* ww6;          // bf16x6w path (conv_wino6.hip): the same weights as three bf16 pieces, [cg32][K-step of 16][xi][nu][piece][lane][8], or nullptr
   const float* wsm;         // conv_few.hip (<= 4 output channels): [Cin][9 = kt * 3 + kf][4 co] conv-form taps, or nullptr
+  const float* ww16;        // f32w path: the LAST 16 output channels of a layer with Cout % 32 == 16 as their own Winograd image for the 16-row body
+                            // (conv_wino.hip G16): [chunk of 8][K-step of 4 ci][pos / 4][ci % 4][16 co][pos % 4], or nullptr
   const float* w1d;         // f32w path, frequency-strided layers (conv.hip W1D): 1-D Winograd weights along T, [cg32][chunk of 8][nu * 3 + kf][ci][32 co], or nullptr
   const float* ww;          // f32w path (conv_wino.hip): Winograd-domain weights U = G g G^T, [cg32][chunk of 8][pos / 4][ci][32 co][pos % 4], or nullptr
   long long in_bstride;     // floats per sample of the input buffer

@@ -115,6 +115,7 @@ struct ConvL {
   long long w6s_off = -1;           // first layer only: offset (floats) of the SHARED 3-part bf16 image [chunk][864 units]
   long long ww_off = -1;            // stride-1 same-padded layers: offset (floats) of the Winograd-domain weights (conv_wino.hip)
   long long ww6_off = -1;           // the same in three bf16 pieces (conv_wino6.hip)
+  long long ww16_off = -1;          // Cout % 32 == 16: Winograd image of the last 16 channels for the 16-row body (conv_wino.hip G16)
   long long w1d_off = -1;           // stride-2 convs / transposed convs: 1-D Winograd image along T (conv.hip W1D; f32w mode)
   long long wsm_off = -1;           // <= 4 output channels, no activation (the last layer): [Cin][9][4] image of conv_few.hip
   float wscale = 1.f;               // f16x3: power of two that brings max |W| of the layer to [32, 64)
@@ -480,6 +481,7 @@ static int run_conv(const misonet_net* n, const Layout& L, void* ws, const ConvL
   a.ww6 = (MN_ALT_MODES && n->precision == 6 && c.ww6_off >= 0) ? n->w_dev + c.ww6_off : nullptr;
   a.wsm = (planar_f32(n) && c.wsm_off >= 0) ? n->w_dev + c.wsm_off : nullptr;
   a.w1d = (n->precision == 5 && c.w1d_off >= 0) ? n->w_dev + c.w1d_off : nullptr;
+  a.ww16 = (n->precision == 5 && c.ww16_off >= 0) ? n->w_dev + c.ww16_off : nullptr;
   a.in_bstride = bstride(n, L, c.in_buf);
   a.out_bstride = bstride(n, L, c.out_buf);
   a.in_sstride = n->bufs[c.in_buf].C;
@@ -910,15 +912,38 @@ static void wino_image(const float* W, int Cin, int Cout, float* img) {
           }
         }
 }
+// ... and of output channels [co0, co0 + 16) for the 16-row body: [chunk of 8 ci][K-step s of 4 ci][pos / 4][ci % 4][16 co][pos % 4],
+// the same signs
+static void wino_image16(const float* W, int Cin, int co0, float* img) {
+  static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+  const int nchunk = Cin / 8;
+  for (int kc = 0; kc < nchunk; ++kc)
+    for (int cil = 0; cil < 8; ++cil)
+      for (int col = 0; col < 16; ++col) {
+        const int ci = kc * 8 + cil, co = co0 + col;
+        for (int pos = 0; pos < 16; ++pos) {
+          const int xi = pos >> 2, nu = pos & 3;
+          double u = 0.0;
+          for (int kt = 0; kt < 3; ++kt)
+            for (int kf = 0; kf < 3; ++kf)
+              u += G[xi][kf] * G[nu][kt] * (double)W[(((long long)co * Cin + ci) * 3 + kt) * 3 + kf];
+          const bool minus = (nu == 2) != ((nu == 3) != (xi == 3));
+          const int s = cil >> 2, kk = cil & 3;
+          img[((((((long long)kc * 2 + s) * 4 + (pos >> 2)) * 4 + kk) * 16 + col) * 4) + (pos & 3)] = (float)(minus ? -u : u);
+        }
+      }
+}
 static void pack_conv_wino(const misonet_net* n, const ConvL& c, std::vector<float>& arena) {
   if (c.ww_off < 0) return;
   wino_image(n->tensors[c.wt].host.data(), c.Cin, c.Cout, arena.data() + c.ww_off);
+  if (c.ww16_off >= 0) wino_image16(n->tensors[c.wt].host.data(), c.Cin, c.Cout - 16, arena.data() + c.ww16_off);
 }
 
 // Run-time self-check of the f32w kernel, once per device at the first commit: conv3x3_wino_f32 drives 256 fixed
 // AGPRs and hand-placed wait states through inline asm -- the build guard (tools/check_wino_build.py) covers what the compiler
-// may do to it, this covers the machine: one small layer (40 -> 32 channels, 11 x 70, two samples: ragged row and column tiles,
-// two tiles per workgroup stream) through the Winograd kernel AND through conv3x3_mfma, compared element by element.  A mismatch
+// may do to it, this covers the machine: one small layer (40 -> 48 channels, 11 x 70, two samples: ragged row and column tiles, a
+// 32-channel group on the 32-row body and 16 channels on the 16-row body) through the Winograd kernels AND through conv3x3_mfma,
+// compared element by element.  A mismatch
 // disables mode 5 on this device: misonet_net_set_precision(5) then fails loudly instead of computing garbage.
 static std::atomic<int> g_wino_state[MAX_DEV] = {};          // 0 not checked, 1 ok, 2 failed
 static std::mutex g_wino_mu;
@@ -929,7 +954,7 @@ static int wino_selftest() {
   std::lock_guard<std::mutex> lk(g_wino_mu);
   st = g_wino_state[d].load(std::memory_order_acquire);
   if (st) return st;
-  const int Cin = 40, Cout = 32, F = 11, T = 70, Tp = frames_pitch(T), N = 2;
+  const int Cin = 40, Cout = 48, F = 11, T = 70, Tp = frames_pitch(T), N = 2;   // (48 = a 32-channel group on the 32-row body + 16 channels on the 16-row body)
   std::vector<float> W((size_t)Cout * Cin * 9), bias(Cout), x((size_t)N * Cin * F * Tp);
   unsigned rng = 12345u;
   auto rnd = [&rng]() { rng = rng * 1664525u + 1013904223u; return (float)((int)(rng >> 9) - (1 << 22)) * (1.f / (1 << 22)); };
@@ -937,15 +962,17 @@ static int wino_selftest() {
   for (float& v : bias) v = 0.3f * rnd();
   for (float& v : x) v = rnd();
   const int nchunk = Cin / CK;
-  std::vector<float> wd((size_t)nchunk * 9 * CK * 32), ww((size_t)nchunk * 16 * 8 * 32);
-  direct_image(W.data(), Cin, Cout, 32, 1, false, wd.data());
+  std::vector<float> wd((size_t)nchunk * 9 * CK * 64), ww((size_t)2 * nchunk * 16 * 8 * 32), ww16((size_t)nchunk * 2048);
+  direct_image(W.data(), Cin, Cout, 64, 1, false, wd.data());
   wino_image(W.data(), Cin, Cout, ww.data());
+  wino_image16(W.data(), Cin, Cout - 16, ww16.data());
   const size_t out_n = (size_t)N * Cout * F * Tp, st_n = (size_t)N * Cout * 2 * DS_NL;
-  float *dx = nullptr, *dwd = nullptr, *dww = nullptr, *db = nullptr, *dy = nullptr;
+  float *dx = nullptr, *dwd = nullptr, *dww = nullptr, *dww16 = nullptr, *db = nullptr, *dy = nullptr;
   dstat_t* dst = nullptr;
-  auto release = [&]() { (void)hipFree(dx); (void)hipFree(dwd); (void)hipFree(dww); (void)hipFree(db); (void)hipFree(dy); (void)hipFree(dst); };
+  auto release = [&]() { (void)hipFree(dx); (void)hipFree(dwd); (void)hipFree(dww); (void)hipFree(dww16); (void)hipFree(db); (void)hipFree(dy); (void)hipFree(dst); };
   bool ok = hipMalloc(reinterpret_cast<void**>(&dx), x.size() * 4) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&dwd), wd.size() * 4) == hipSuccess &&
-            hipMalloc(reinterpret_cast<void**>(&dww), ww.size() * 4) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&db), 128 * 4) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&dww), ww.size() * 4) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&dww16), ww16.size() * 4) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&db), 128 * 4) == hipSuccess &&
             hipMalloc(reinterpret_cast<void**>(&dy), 2 * out_n * 4) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&dst), 2 * st_n * 8) == hipSuccess;
   std::vector<float> y(2 * out_n);
   std::vector<dstat_t> sv(2 * st_n);
@@ -955,21 +982,22 @@ static int wino_selftest() {
     ok = hipMemcpy(dx, x.data(), x.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(dwd, wd.data(), wd.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(dww, ww.data(), ww.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(dww16, ww16.data(), ww16.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(db, b128.data(), 128 * 4, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemset(dy, 0, 2 * out_n * 4) == hipSuccess && hipMemset(dst, 0, 2 * st_n * 8) == hipSuccess;
   }
   if (ok) {
     ConvArgs a = {};
-    a.in = dx; a.in_stats = nullptr; a.w = dwd; a.bias = db; a.ww = dww;
+    a.in = dx; a.in_stats = nullptr; a.w = dwd; a.bias = db; a.ww = dww; a.ww16 = dww16;
     a.in_bstride = (long long)Cin * F * Tp; a.out_bstride = (long long)Cout * F * Tp;
     a.in_sstride = Cin; a.out_sstride = Cout;
     a.in_c0 = 0; a.Cin = Cin; a.Fin = F; a.ident_c = Cin;              // input consumed as it is: no statistics to read
     a.out_c0 = 0; a.Cout = Cout; a.Fout = F; a.T = T; a.Tp = Tp;
-    a.sf = 1; a.padf = 1; a.tr2 = 0; a.act = 1; a.NR = conv_rows(1, 0); a.ncg = 1; a.cop = 32;
+    a.sf = 1; a.padf = 1; a.tr2 = 0; a.act = 1; a.NR = conv_rows(1, 0); a.ncg = 1; a.cop = 64;
     a.wscale = a.descale = 1.f;
     a.out = dy; a.out_stats = dst;
     ok = conv_wino_ok(a) && launch_conv_wino(a, N, nullptr) == hipSuccess;
-    a.ww = nullptr; a.out = dy + out_n; a.out_stats = dst + st_n;
+    a.ww = nullptr; a.ww16 = nullptr; a.out = dy + out_n; a.out_stats = dst + st_n;
     ok = ok && launch_conv(a, N, nullptr) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
          hipMemcpy(y.data(), dy, 2 * out_n * 4, hipMemcpyDeviceToHost) == hipSuccess &&
          hipMemcpy(sv.data(), dst, 2 * st_n * 8, hipMemcpyDeviceToHost) == hipSuccess;
@@ -1054,7 +1082,10 @@ int misonet_net_commit(misonet_net* n) {
         c.w6s_off = take((long long)((c.Cin + 7) / 8) * 864 * 4);          // 864 units x 16 bytes = x 4 floats
       // the DenseBlock convs (stride 1, same padding, Cin a multiple of 8): Winograd-domain image for the f32w mode
       if (!c.transposed && c.sf == 1 && c.padf == 1 && c.Cin % 8 == 0 && c.Cin <= 256)
+      {
         c.ww_off = take((long long)((c.Cout + 31) / 32) * (c.Cin / 8) * 16 * 8 * 32);
+        if ((c.Cout & 31) == 16) c.ww16_off = take((long long)(c.Cin / 8) * 2048);
+      }
       if (c.tr2 || c.sf == 2) c.w1d_off = take((long long)((c.Cout + 31) / 32) * nchunk * 12 * CK * 32);
       if (c.Cout <= 4 && c.sf == 1 && !c.tr2 && !c.act && c.Cin % 4 == 0 && c.Cin <= 256) c.wsm_off = take((long long)c.Cin * 36);
       if (MN_ALT_MODES && !c.transposed && c.sf == 1 && c.padf == 1 && c.Cin % 8 == 0 && c.Cin >= 24 && c.Cin <= 256)
