@@ -233,13 +233,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
   bool Lfull = false;                          // every frame t0 .. t0 + 63 of the tile exists (no frame masks)
   unsigned Lmask = 0;                          // bits 0-3: frame t0 + 4 sq + j exists
   __amdgpu_buffer_rsrc_t rs_l;
-  unsigned Cnr[6], Dnr[6];
-  bool Cfull = false, Dfull = false;
-  unsigned Cmask = 0, Dmask = 0;
+  // C-side state (the chunk staged in this iteration): the norm-entry addresses ROLL (+ one chunk = 64 bytes per iteration) and
+  // jump to the load side's base when the staged chunk is the first of the next tile -- the load side is on that tile by then and
+  // stays on it for >= nchunk - 2 more iterations (round 6; rounds 5's L -> D -> C hand-down copied 18 registers per chunk)
+  unsigned Cnr[6];
+  bool Cfull = false;
+  unsigned Cmask = 0;
   unsigned Dwso = 0;                           // byte offset of D's chunk in the weight image
   int cslot = 0;                               // raw slot of C's chunk
 #pragma unroll
-  for (int i = 0; i < 6; ++i) { Lnr[i] = lds0 + WZERO_B; Cnr[i] = lds0 + WZERO_B; Dnr[i] = lds0 + WZERO_B; }
+  for (int i = 0; i < 6; ++i) { Lnr[i] = lds0 + WZERO_B; Cnr[i] = lds0 + WZERO_B; }
 
 #define W_DECODE(Q, TT_, FT_, N_, CG_)                                                                \
   {                                                                                                   \
@@ -302,8 +305,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
   // hand the per-chunk state down (after the chunk L points at has been issued, before L advances)
 #define W_LATCH                                                                                       \
   {                                                                                                   \
-    _Pragma("unroll") for (int i = 0; i < 6; ++i) { Cnr[i] = Dnr[i]; Dnr[i] = Lnr[i] + (unsigned)(kl * WCK * 8); } \
-    Cfull = Dfull; Dfull = Lfull; Cmask = Dmask; Dmask = Lmask;                                       \
     Dwso = (unsigned)(Lcg * nchunk + kl) * WIMG_B;                                                    \
   }
 #define W_ADVANCE                                                                                     \
@@ -453,9 +454,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
   // ablation -- the 10 pieces are ~6 % of the kernel), the scalar bookkeeping (W_BK_S1 .. S3) rides in slot 14, the vector part (W_BK_V: the norm-address
   // hand-down and the stage rotation -- VALU costs its time wherever it stands) joins the transform's VALU group.  What is left
   // between two bodies: the tile-end test, the load-side tile change (once per tile) and the body dispatch.
-#define W_BK_S1 /* latch, scalar part; the chunk offset the vector part adds to the norm addresses */  \
-  const unsigned klo_ = (unsigned)(kl * WCK * 8);                                                     \
-  Cfull = Dfull; Dfull = Lfull;                                                                       \
+#define W_BK_S1 /* latch, scalar part; nxt0_: the chunk staged in the NEXT iteration is the first of the next tile */ \
+  const bool nxt0_ = (kc + 2 == nchunk);                                                              \
+  Cfull = nxt0_ ? Lfull : Cfull;                                                                      \
   Dwso = (unsigned)(Lcg * nchunk + kl) * WIMG_B;
 #define W_BK_S2 /* advance the load side (the tile change itself -- W_LOAD_SETUP -- stays behind the body) */ \
   lslot ^= 1; ++kl;
@@ -467,8 +468,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
   stnn = ph3 == 0 ? 2 : ph3 - 1;                       /* stage of the NEXT body's chunk g + 2 */     \
   const unsigned rsl_ = cslot ? (unsigned)(WRAW_FLOATS * 4) : 0u;
 #define W_BK_V                                                                                        \
-  _Pragma("unroll") for (int i = 0; i < 6; ++i) { Cnr[i] = Dnr[i]; Dnr[i] = Lnr[i] + klo_; }          \
-  Cmask = Dmask; Dmask = Lmask;                                                                       \
+  if (__builtin_expect(nxt0_, 0)) {                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 6; ++i) Cnr[i] = Lnr[i];                                    \
+    Cmask = Lmask;                                                                                    \
+  } else {                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < 6; ++i) Cnr[i] += (unsigned)(WCK * 8);                      \
+  }                                                                                                   \
   d1 = d0n + STEP_B; d2 = d0n + 2 * STEP_B; d3 = d0n + 3 * STEP_B;                                    \
   uc = un;                                                                                            \
   d0n += dl_n_; un += dl_n_; cn += dl_n_;                                                             \
@@ -570,6 +575,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
   // step 0) fetched and transformed ----
   constexpr bool RAG = true;                         // (the prologue always applies the frame masks)
   W_LOAD_SETUP(ql)
+#pragma unroll
+  for (int i = 0; i < 6; ++i) Cnr[i] = Lnr[i];       // C = chunk 0 of the first tile (staged by this prologue)
+  Cmask = Lmask; Cfull = Lfull;
   __syncthreads();                                   // s_nrm, s_zero visible
   W_ISSUE_W(0, 0, W_WSO_L) W_ISSUE_W(1, 0, W_WSO_L) W_ISSUE_W(2, 0, W_WSO_L) W_ISSUE_W(3, 0, W_WSO_L)
   W_ISSUE_I(0) W_ISSUE_I(1) W_ISSUE_I(2) W_ISSUE_I(3) W_ISSUE_I(4) W_ISSUE_H
@@ -577,7 +585,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
   W_ADVANCE
   W_ISSUE_W(0, 1, W_WSO_L) W_ISSUE_W(1, 1, W_WSO_L) W_ISSUE_W(2, 1, W_WSO_L) W_ISSUE_W(3, 1, W_WSO_L)
   W_ISSUE_I(0) W_ISSUE_I(1) W_ISSUE_I(2) W_ISSUE_I(3) W_ISSUE_I(4) W_ISSUE_H
-  W_LATCH                                            // C = chunk 0, D = chunk 1
+  W_LATCH                                            // D = chunk 1
   W_ADVANCE
   W_VMCNT(0)
   cn -= STAGE_B;                                     // (chunk 0 is staged to stage 0; the loop stages chunk g + 1 to the stage after g's)
@@ -588,11 +596,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const ConvArgs a) {
   W_RR(rwa, 3) W_NR(nra, 3) W_CC(cva, rwa, nra) W_CW(cva, 3)
   W_RR(rwa, 4) W_NR(nra, 4) W_CC(cva, rwa, nra) W_CW(cva, 4)
   W_RRH W_NR(nrb, 5) W_CCH(nrb) W_CWH
+#pragma unroll
+  for (int i = 0; i < 6; ++i) Cnr[i] += (unsigned)(WCK * 8);   // C = chunk 1 (iteration 0 stages it)
   cn += STAGE_B;
   if (hrole) hn += STAGE_B;
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's reads of raw slot 0 are done: chunk 2 may land there
   W_ISSUE_I(0) W_ISSUE_I(1) W_ISSUE_I(2) W_ISSUE_I(3) W_ISSUE_I(4) W_ISSUE_H
-  W_LATCH                                            // C = chunk 1, D = chunk 2
+  W_LATCH                                            // D = chunk 2
   W_ADVANCE
   cslot = 1;
   rofs = rofs0 + WRAW_FLOATS * 4;
