@@ -22,6 +22,7 @@
 #include "conv_epilogue.hpp"
 
 #include <atomic>
+#include <type_traits>
 
 namespace mn {
 
@@ -190,53 +191,67 @@ __device__ __forceinline__ void chunk_w1d_tr2(f32x16 (&acc)[4][2], const float* 
 }
 // tile epilogue of the W1D forms: inverse transform, + bias, ELU, centring (conv_epilogue.hpp), 8-byte stores of the lane's frame
 // pair, statistics partials of this (row, column-tile range) into s_red [32][2].  Accumulator columns Q0 .. Q0 + NQ - 1 are
-// NQ consecutive column tiles of row f starting at frame tq.
+// NQ consecutive column tiles of row f starting at frame tq.  The layers are activated ones (launch_conv): ELU and statistics
+// are unconditional -- a run-time `act` inside the unrolled loops is a branch per element -- and (bias, ELU(bias)) come from
+// the LDS table s_bc [32] the kernel fills at its start (round 6: a global load per accumulator row, each waited for with
+// vmcnt(0), was a third of these kernels' time).  Channels >= Cout need no mask: zero weights and bias, ELU(0) - ELU(0) = 0.
 template <int Q0, int NQ>
 __device__ __forceinline__ void w1d_epilogue(const ConvArgs& a, f32x16 (&acc)[4][2], int n, int cg, int f, int tq, bool row_ok, int lane,
-                                             float* s_red) {
+                                             float* s_red, const float2* s_bc) {
   const int half = lane >> 5, l31 = lane & 31;
   const int T = a.T, Tp = a.Tp;
   const int cbase = cg * 32;
   const unsigned P4 = (unsigned)a.Fout * (unsigned)Tp * 4u;
   const float* ob = a.out + (long long)n * a.out_bstride + (long long)a.out_c0 * a.Fout * Tp;
   const __amdgpu_buffer_rsrc_t rs = make_rsrc_e(reinterpret_cast<unsigned long long>(ob), (unsigned)a.Cout * P4);
-  const bool act = a.act != 0;
-  float s1[16], s2[16];
+  const bool all_t = row_ok && (tq + 64 * NQ <= T);          // uniform: every frame of the range exists
+  float2 bc[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int kr = (r & 3) + 8 * (r >> 2);
-    const int co = cbase + kr + 4 * half;
-    const bool cok = co < a.Cout;
-    const float b = a.bias[co];                               // (zero padded to the group)
-    const float cr = act ? elu_fast(b) : 0.f;
-    float a1 = 0.f, a2 = 0.f;
+  for (int r = 0; r < 16; ++r) bc[r] = s_bc[(r & 3) + 8 * (r >> 2) + 4 * half];
+  unsigned voff[NQ];
+  bool ok[NQ], ok2[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const float m0 = acc[0][Q0 + q][r], m1 = acc[1][Q0 + q][r], m2 = acc[2][Q0 + q][r], m3 = acc[3][Q0 + q][r];
-      float ye = (m0 + m1) + m2 + b, yo = (m1 - m2) - m3 + b;
-      if (act) { ye = elu_fast(ye) - cr; yo = elu_fast(yo) - cr; }
-      const int te = tq + 64 * q + 2 * l31;
-      const bool ok = row_ok && te < T;                      // (te + 1 >= T: the second word lands in the row's padding [T, Tp))
-      typedef unsigned int uu2 __attribute__((ext_vector_type(2)));
-      const float2 o = make_float2(ye, yo);
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uu2, o), rs,
-                                            ok ? (unsigned)(f * Tp + te) * 4u + (unsigned)(4 * half) * P4 + (unsigned)(cbase + kr) * P4 : 0x80000000u, 0, 0);
-      const float ze = (ok && cok) ? ye : 0.f, zo = (ok && cok && te + 1 < T) ? yo : 0.f;
-      a1 += ze + zo;
-      a2 = fmaf(ze, ze, fmaf(zo, zo, a2));
-    }
-    s1[r] = a1;
-    s2[r] = a2;
+  for (int q = 0; q < NQ; ++q) {
+    const int te = tq + 64 * q + 2 * l31;
+    ok[q] = row_ok && te < T;                                // (te + 1 >= T: the second word lands in the row's padding [T, Tp))
+    ok2[q] = ok[q] && te + 1 < T;
+    voff[q] = ok[q] ? (unsigned)(f * Tp + te) * 4u + (unsigned)(4 * half) * P4 : 0x80000000u;
   }
-  if (act) {
-    const float x1 = reduce16_halfwave(s1, lane);
-    const float x2 = reduce16_halfwave(s2, lane);
-    if ((lane & 16) == 0) {
-      const int qq = lane & 15;
-      const int co_l = (qq & 3) + 8 * (qq >> 2) + 4 * half;
-      s_red[co_l * 2 + 0] = x1;
-      s_red[co_l * 2 + 1] = x2;
+  float s1[16], s2[16];
+  // (the mask-free body for tiles whose frames all exist -- every tile but the last of a row -- is a separate copy: a uniform
+  // branch per tile instead of two selects per accumulator row)
+  auto body = [&](auto masked) {
+    constexpr bool MASKED = decltype(masked)::value;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kr = (r & 3) + 8 * (r >> 2);
+      const unsigned coff = (unsigned)(cbase + kr) * P4;         // uniform plane offset
+      const float b = bc[r].x;
+      const f32x2_t cr = {bc[r].y, bc[r].y};
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const float m0 = acc[0][Q0 + q][r], m1 = acc[1][Q0 + q][r], m2 = acc[2][Q0 + q][r], m3 = acc[3][Q0 + q][r];
+        f32x2_t y = {(m0 + m1) + m2 + b, (m1 - m2) - m3 + b};
+        y = elu_fast2(y) - cr;
+        typedef unsigned int uu2 __attribute__((ext_vector_type(2)));
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uu2, y), rs, voff[q] + coff, 0, 0);
+        const float ze = (!MASKED || ok[q]) ? y.x : 0.f, zo = (!MASKED || ok2[q]) ? y.y : 0.f;
+        a1 += ze + zo;
+        a2 = fmaf(ze, ze, fmaf(zo, zo, a2));
+      }
+      s1[r] = a1;
+      s2[r] = a2;
     }
+  };
+  if (all_t) body(std::false_type{}); else body(std::true_type{});
+  const float x1 = reduce16_halfwave(s1, lane);
+  const float x2 = reduce16_halfwave(s2, lane);
+  if ((lane & 16) == 0) {
+    const int qq = lane & 15;
+    const int co_l = (qq & 3) + 8 * (qq >> 2) + 4 * half;
+    s_red[co_l * 2 + 0] = x1;
+    s_red[co_l * 2 + 1] = x2;
   }
 }
 
@@ -427,6 +442,12 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0 && !HALFK
     }
     s_nrm[c] = make_float2(rstd, -mean * rstd);            // (scale, shift): x_norm = fma(x, scale, shift)
   }
+  // W1D: (bias, ELU(bias)) of the group's 32 channels for the epilogue (the bias is zero padded to the group)
+  float2* s_bc = s_nrm + nchunk * CK;
+  if (W1D && tid < 32) {
+    const float b = a.bias[cg * 32 + tid];
+    s_bc[tid] = make_float2(b, elu_fast(b));
+  }
 
   __syncthreads();          // s_nrm visible
   STAGE_COMMIT(0)
@@ -468,12 +489,12 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0 && !HALFK
     // statistics slots: MODE 1 one per row (wave); MODE 2 [row of the tile][column tile]: 8 partial sums, added in slot order
     if (TR2) {
       const int q = wave & 1, rt = 2 * (wave >> 1);
-      w1d_epilogue<0, 1>(a, wacc, n, cg, f, t0 + 64 * q, row_ok, lane, s_red + ((rt * 2 + q) * 32) * 2);
-      w1d_epilogue<1, 1>(a, wacc, n, cg, f + 1, t0 + 64 * q, f + 1 < a.Fout, lane, s_red + (((rt + 1) * 2 + q) * 32) * 2);
+      w1d_epilogue<0, 1>(a, wacc, n, cg, f, t0 + 64 * q, row_ok, lane, s_red + ((rt * 2 + q) * 32) * 2, s_bc);
+      w1d_epilogue<1, 1>(a, wacc, n, cg, f + 1, t0 + 64 * q, f + 1 < a.Fout, lane, s_red + (((rt + 1) * 2 + q) * 32) * 2, s_bc);
     } else {
-      w1d_epilogue<0, 2>(a, wacc, n, cg, f, t0, row_ok, lane, s_red + wave * (32 * 2));
+      w1d_epilogue<0, 2>(a, wacc, n, cg, f, t0, row_ok, lane, s_red + wave * (32 * 2), s_bc);
     }
-    if (a.act) {
+    {
       __syncthreads();
       if (tid < 64) {
         const int co_l = tid >> 1, which = tid & 1;
@@ -521,7 +542,7 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0 && !HALFK
 
 static size_t conv_lds_bytes(int NR, int cop, int Cin, int ntap = 9) {
   const int nchunk = (Cin + CK - 1) / CK;
-  return (size_t)(CK * NR * TW + ntap * CK * cop) * sizeof(float) + (size_t)nchunk * CK * sizeof(float2);
+  return (size_t)(CK * NR * TW + ntap * CK * cop) * sizeof(float) + (size_t)(nchunk * CK + 32) * sizeof(float2);   // (+ s_bc: W1D)
 }
 
 template <int NCO, int MODE, int OCTP = 0, bool HALFK = false, bool W1D = false>
@@ -578,7 +599,7 @@ hipError_t launch_conv(const ConvArgs& a_in, int n_samples, hipStream_t s) {
   // XCDs get nothing (B = 1: MISO3 runs 2 samples -> 6 of 8 XCDs idle, the first layer took 114 us instead of ~30); the
   // natural (t, f, n) grid is used then
   const int mode = a.tr2 ? 2 : (a.sf == 2 ? 1 : ((a.padf == 2 && a.Fin == 1 && !a.out_oct) ? 3 : 0));
-  if (a.w1d && (mode == 1 || mode == 2) && !a.out_oct && !a.in_oct) {
+  if (a.w1d && a.act && (mode == 1 || mode == 2) && !a.out_oct && !a.in_oct) {
     // f32w: the frequency-strided layers in 1-D Winograd form along T (32-channel groups, 4-row tiles)
     a.cop = 32;
     a.ncg = (a.Cout + 31) / 32;

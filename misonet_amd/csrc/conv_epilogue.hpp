@@ -38,6 +38,19 @@ __device__ __forceinline__ float elu_select(float x, float e) {
 
 __device__ __forceinline__ float elu_fast(float v) { return elu_select(v, __expf(v) - 1.f); }
 
+// two ELUs at once: the scale and the - 1 are packed (v_pk_mul_f32 / v_pk_add_f32); bitwise the pair (elu_fast(x), elu_fast(y))
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t elu_fast2(f32x2_t v) {
+  f32x2_t e = v * 1.44269504088896341f;                    // (__expf(v) = v_exp_f32(v * log2 e): the same product, packed)
+  e.x = __builtin_amdgcn_exp2f(e.x);
+  e.y = __builtin_amdgcn_exp2f(e.y);
+  e = e - 1.f;
+  f32x2_t r;
+  r.x = elu_select(v.x, e.x);
+  r.y = elu_select(v.y, e.y);
+  return r;
+}
+
 // sum over the 32 lanes of each half-wave; the result is valid in lanes 16..31 (lower half) and 48..63 (upper half)
 __device__ __forceinline__ float half_wave_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
