@@ -1138,6 +1138,9 @@ int misonet_net_commit(misonet_net* n) {
   HIPCHK(conv_init());
   HIPCHK(conv_wino_init());
   HIPCHK(conv_few_init());
+#ifdef MISONET_EXPERIMENTS                  // (timing ablations compute garbage by design: MISONET_WINO_DBG skips the self-check)
+  if (!exp_env("MISONET_WINO_DBG", 0))
+#endif
   if (wino_selftest() != 1 && n->precision == 5)
     return fail(MISONET_ESTATE, "the f32w kernel failed its self-check on this device (see stderr): use mode 0 (f32) or 3 (bf16x6)");
 #if MN_ALT_MODES
