@@ -112,17 +112,18 @@ __device__ __forceinline__ W1dRaw w1d_raw(const float* p) { W1dRaw r; r.d[0] = p
 __device__ __forceinline__ void w1d_vr(const W1dRaw& r, float (&v)[4]) {
   v[0] = r.d[0] - r.d[2]; v[1] = r.d[1] + r.d[2]; v[2] = r.d[2] - r.d[1]; v[3] = r.d[1] - r.d[3];
 }
-// stride-2 conv: one output row per wave, 128 frames = 2 column tiles; s_w = [nu * 3 + kf][CK][32]
-template <int NR>
+// conv with frequency stride SF (2: the down-sampling layers; 1: the network's first layer, round 6): one output row per wave, 128
+// frames = 2 column tiles; s_w = [nu * 3 + kf][CK][32].  NCP: channel pairs of the chunk that hold channels (chunk_mfma)
+template <int NR, int SF = 2, int NCP = CK / 2, int CP0 = 0>
 __device__ __forceinline__ void chunk_w1d_s2(f32x16 (&acc)[4][2], const float* s_in, const float* s_w, int frel, int half, int l31) {
   const float* wb = s_w + half * 32 + l31;
-  const float* ib0 = s_in + (half * NR + 2 * frel) * TW + 2 * l31 + 3;
-  constexpr int NSTEP = 3 * (CK / 2);
+  const float* ib0 = s_in + (half * NR + SF * frel) * TW + 2 * l31 + 3;
+  constexpr int NSTEP = 3 * NCP;
   W1dRaw r0[2], r1[2];
   float u[2][4];
 #define W1D_LOAD(ST, BUF)                                                                        \
   {                                                                                              \
-    constexpr int kf_ = (ST) / (CK / 2), cp_ = (ST) % (CK / 2);                                  \
+    constexpr int kf_ = (ST) / NCP, cp_ = CP0 + (ST) % NCP;                                      \
     const float* ib_ = ib0 + kf_ * TW + cp_ * 2 * NR * TW;                                       \
     r0[BUF] = w1d_raw(ib_); r1[BUF] = w1d_raw(ib_ + 64);                                         \
     _Pragma("unroll") for (int nu = 0; nu < 4; ++nu) u[BUF][nu] = wb[((nu * 3 + kf_) * CK + cp_ * 2) * 32]; \
@@ -132,7 +133,7 @@ __device__ __forceinline__ void chunk_w1d_s2(f32x16 (&acc)[4][2], const float* s
   for (int st = 0; st < NSTEP; ++st) {
     const int cur = st & 1;
     if (st + 1 < NSTEP) {
-      const int kf_ = (st + 1) / (CK / 2), cp_ = (st + 1) % (CK / 2);
+      const int kf_ = (st + 1) / NCP, cp_ = CP0 + (st + 1) % NCP;
       const float* ib_ = ib0 + kf_ * TW + cp_ * 2 * NR * TW;
       r0[cur ^ 1] = w1d_raw(ib_); r1[cur ^ 1] = w1d_raw(ib_ + 64);
 #pragma unroll
@@ -195,7 +196,7 @@ __device__ __forceinline__ void chunk_w1d_tr2(f32x16 (&acc)[4][2], const float* 
 // are unconditional -- a run-time `act` inside the unrolled loops is a branch per element -- and (bias, ELU(bias)) come from
 // the LDS table s_bc [32] the kernel fills at its start (round 6: a global load per accumulator row, each waited for with
 // vmcnt(0), was a third of these kernels' time).  Channels >= Cout need no mask: zero weights and bias, ELU(0) - ELU(0) = 0.
-template <int Q0, int NQ>
+template <int Q0, int NQ, bool ACT = true>
 __device__ __forceinline__ void w1d_epilogue(const ConvArgs& a, f32x16 (&acc)[4][2], int n, int cg, int f, int tq, bool row_ok, int lane,
                                              float* s_red, const float2* s_bc) {
   const int half = lane >> 5, l31 = lane & 31;
@@ -233,9 +234,10 @@ __device__ __forceinline__ void w1d_epilogue(const ConvArgs& a, f32x16 (&acc)[4]
       for (int q = 0; q < NQ; ++q) {
         const float m0 = acc[0][Q0 + q][r], m1 = acc[1][Q0 + q][r], m2 = acc[2][Q0 + q][r], m3 = acc[3][Q0 + q][r];
         f32x2_t y = {(m0 + m1) + m2 + b, (m1 - m2) - m3 + b};
-        y = elu_fast2(y) - cr;
+        if (ACT) y = elu_fast2(y) - cr;
         typedef unsigned int uu2 __attribute__((ext_vector_type(2)));
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uu2, y), rs, voff[q] + coff, 0, 0);
+        if (!ACT) continue;                                      // (a layer without activation has no statistics: its consumers read it raw)
         const float ze = (!MASKED || ok[q]) ? y.x : 0.f, zo = (!MASKED || ok2[q]) ? y.y : 0.f;
         a1 += ze + zo;
         a2 = fmaf(ze, ze, fmaf(zo, zo, a2));
@@ -244,7 +246,8 @@ __device__ __forceinline__ void w1d_epilogue(const ConvArgs& a, f32x16 (&acc)[4]
       s2[r] = a2;
     }
   };
-  if (all_t) body(std::false_type{}); else body(std::true_type{});
+  if (all_t || !ACT) body(std::false_type{}); else body(std::true_type{});
+  if (!ACT) return;
   const float x1 = reduce16_halfwave(s1, lane);
   const float x2 = reduce16_halfwave(s2, lane);
   if ((lane & 16) == 0) {
@@ -279,19 +282,22 @@ __device__ __forceinline__ void w1d_epilogue(const ConvArgs& a, f32x16 (&acc)[4]
 template <int NCO, int MODE, int OCTP = 0, bool HALFK = false, bool W1D = false>
 __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0 && !HALFK && !W1D) ? 3 : 2)) void conv3x3_mfma(const ConvArgs a) {
   static_assert(MODE != 2 || NCO == 1, "stride-2 transposed: two output rows per wave, 32-channel groups");
-  static_assert(!W1D || (NCO == 1 && (MODE == 1 || MODE == 2) && OCTP == 0 && !HALFK), "W1D: the frequency-strided layers, 32-channel groups, planar output");
+  static_assert(MODE != 4 || W1D, "MODE 4 exists in the W1D form only");
+  static_assert(!W1D || (NCO == 1 && OCTP == 0 && (MODE == 0 || (!HALFK && (MODE == 1 || MODE == 2 || MODE == 4)))),
+                "W1D: the frequency-strided layers and the first layer, 32-channel groups, planar output");
   constexpr int COP = NCO * 32;
-  constexpr int NR = MODE == 0 ? 6 : (MODE == 1 ? 9 : (MODE == 2 ? (W1D ? 3 : 5) : 1));
-  constexpr int SF = MODE == 1 ? 2 : 1;
+  constexpr int NR = MODE == 0 ? 6 : (MODE == 1 ? 9 : (MODE == 2 ? (W1D ? 3 : 5) : (MODE == 4 ? 3 : 1)));
+  constexpr int SF = (MODE == 1 || MODE == 4) ? 2 : 1;
+  constexpr int NG = MODE == 4 ? 4 : 1;          // 32-channel groups per workgroup (MODE 4: one per wave)
   constexpr bool TR2 = MODE == 2;
   constexpr int FTO = (TR2 && !W1D) ? 2 * FT : FT;   // output rows per workgroup
   constexpr int NTAP = W1D ? 12 : 9;
-  constexpr int NW4 = NTAP * CK * COP / 4;       // float4 per weight slab
+  constexpr int NW4 = NTAP * CK * COP * NG / 4;  // float4 per weight slab
   constexpr int NWI = (NW4 + 255) / 256;
   extern __shared__ __align__(16) float smem[];
   float* s_in = smem;                         // [CK][NR][TW]: col 3 = frame t0-1, cols 4..131 = t0..t0+127, col 132 = t0+128
   float* s_w = s_in + CK * NR * TW;           // [NTAP][CK][COP]
-  float2* s_nrm = reinterpret_cast<float2*>(s_w + NTAP * CK * COP);   // [CinP] (mean, rstd)
+  float2* s_nrm = reinterpret_cast<float2*>(s_w + NTAP * CK * COP * NG);   // [CinP] (mean, rstd)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0 && !HALFK
   const int fin0 = MODE == 3 ? 0 : (TR2 ? (f0 >> 1) - 1 : SF * f0 - a.padf);
 
   const float* in_n = a.in + (long long)n * a.in_bstride + (long long)a.in_c0 * Fin * Tp;
-  const f32x4* w_g = reinterpret_cast<const f32x4*>((W1D ? a.w1d : a.w) + (long long)cg * nchunk * (NTAP * CK * COP));
+  const f32x4* w_g = reinterpret_cast<const f32x4*>((W1D ? a.w1d : a.w) + (long long)cg * NG * nchunk * (NTAP * CK * COP));
 
   // staging roles
   const int sq = tid & 31, sci = tid >> 5;
@@ -362,7 +368,10 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0 && !HALFK
     _Pragma("unroll") for (int i = 0; i < NWI; ++i) {                                            \
       unsigned idx_ = tid + 256 * i;                                                             \
       if (NW4 % 256 != 0) idx_ = idx_ < (unsigned)NW4 ? idx_ : (unsigned)(NW4 - 1);              \
-      PW[i] = wsrc_[idx_];                                                                       \
+      if (NG > 1) { /* the chunk's slab of group i / 3 (a group's slab = 768 float4 = 3 per thread) */ \
+        constexpr int per_ = NTAP * CK * COP / 4;                                                \
+        PW[i] = w_g[(unsigned)((i / (per_ / 256)) * nchunk + (KC)) * (unsigned)per_ + tid + 256 * (i % (per_ / 256))]; \
+      } else PW[i] = wsrc_[idx_];                                                                \
     }                                                                                            \
   }
 
@@ -399,7 +408,7 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0 && !HALFK
 #define STAGE_COMMIT(KC) STAGE_COMMIT_S(KC, pin, ph, pw)
 
   // (TR2: the even row of the pair; f + 1 is the odd one.  W1D TR2: pair wave >> 1, column tile wave & 1)
-  const int f = TR2 ? (W1D ? f0 + 2 * (wave >> 1) : f0 + 2 * wave) : f0 + wave;
+  const int f = TR2 ? (W1D ? f0 + 2 * (wave >> 1) : f0 + 2 * wave) : (MODE == 4 ? f0 : f0 + wave);
   const bool row_ok = f < a.Fout;                       // wave-uniform
   int nseg = (T - t0 + 31) >> 5;
   nseg = nseg > 4 ? 4 : nseg;
@@ -444,8 +453,8 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0 && !HALFK
   }
   // W1D: (bias, ELU(bias)) of the group's 32 channels for the epilogue (the bias is zero padded to the group)
   float2* s_bc = s_nrm + nchunk * CK;
-  if (W1D && tid < 32) {
-    const float b = a.bias[cg * 32 + tid];
+  if (W1D && tid < 32 * NG) {
+    const float b = a.bias[cg * (32 * NG) + tid];
     s_bc[tid] = make_float2(b, elu_fast(b));
   }
 
@@ -462,7 +471,13 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0 && !HALFK
     if (W1D) {
       if (row_ok) {
         if (TR2) chunk_w1d_tr2(wacc, s_in, s_w, wave >> 1, wave & 1, half, l31);
-        else chunk_w1d_s2<NR>(wacc, s_in, s_w, f - f0, half, l31);
+        else if (MODE == 4) chunk_w1d_s2<NR, SF>(wacc, s_in, s_w + wave * (NTAP * CK * COP), 0, half, l31);
+        else if (HALFK) {
+          // (two half bodies in sequence, the second skipped for the half-empty last chunk: an if / else between a full and a half
+          // body costs the instantiation its register allocation -- 432 bytes of scratch)
+          chunk_w1d_s2<NR, SF, CK / 4, 0>(wacc, s_in, s_w, f - f0, half, l31);
+          if (kc != nchunk - 1) chunk_w1d_s2<NR, SF, CK / 4, CK / 4>(wacc, s_in, s_w, f - f0, half, l31);
+        } else chunk_w1d_s2<NR, SF>(wacc, s_in, s_w, f - f0, half, l31);
       }
     } else if (row_ok) {
       if (TR2) {
@@ -491,12 +506,25 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0 && !HALFK
       const int q = wave & 1, rt = 2 * (wave >> 1);
       w1d_epilogue<0, 1>(a, wacc, n, cg, f, t0 + 64 * q, row_ok, lane, s_red + ((rt * 2 + q) * 32) * 2, s_bc);
       w1d_epilogue<1, 1>(a, wacc, n, cg, f + 1, t0 + 64 * q, f + 1 < a.Fout, lane, s_red + (((rt + 1) * 2 + q) * 32) * 2, s_bc);
+    } else if (MODE == 4) {
+      w1d_epilogue<0, 2>(a, wacc, n, cg * NG + wave, f, t0, row_ok, lane, s_red + wave * (32 * 2), s_bc + wave * 32);
     } else {
-      w1d_epilogue<0, 2>(a, wacc, n, cg, f, t0, row_ok, lane, s_red + wave * (32 * 2), s_bc);
+      // (MODE 0 = a network's first layer, which has no activation: model.py:44)
+      if (MODE == 0 && !a.act) w1d_epilogue<0, 2, false>(a, wacc, n, cg, f, t0, row_ok, lane, s_red + wave * (32 * 2), s_bc);
+      else w1d_epilogue<0, 2>(a, wacc, n, cg, f, t0, row_ok, lane, s_red + wave * (32 * 2), s_bc);
     }
-    {
+    if (a.act) {
       __syncthreads();
-      if (tid < 64) {
+      if (MODE == 4) {
+        // one row, a group per wave: slot g holds the row's sums of group cg * 4 + g (0 + x, as the four-row sum of a one-row layer forms it)
+        const int g = tid >> 6, co_l = (tid & 63) >> 1, which = tid & 1;
+        const int co = (cg * NG + g) * 32 + co_l;
+        if (co < a.Cout) {
+          float tot = 0.f;
+          if (f0 < a.Fout) tot += s_red[(g * 32 + co_l) * 2 + which];
+          dstat_add(a.out_stats + (((long long)n * a.out_sstride + a.out_c0 + co) * 2 + which) * DS_NL, (double)tot);
+        }
+      } else if (tid < 64) {
         const int co_l = tid >> 1, which = tid & 1;
         const int co = cg * 32 + co_l;
         if (co < a.Cout) {
@@ -542,7 +570,7 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0 && !HALFK
 
 static size_t conv_lds_bytes(int NR, int cop, int Cin, int ntap = 9) {
   const int nchunk = (Cin + CK - 1) / CK;
-  return (size_t)(CK * NR * TW + ntap * CK * cop) * sizeof(float) + (size_t)(nchunk * CK + 32) * sizeof(float2);   // (+ s_bc: W1D)
+  return (size_t)(CK * NR * TW + ntap * CK * cop) * sizeof(float) + (size_t)(nchunk * CK + 128) * sizeof(float2);   // (+ s_bc: W1D, up to 4 groups)
 }
 
 template <int NCO, int MODE, int OCTP = 0, bool HALFK = false, bool W1D = false>
@@ -560,6 +588,9 @@ hipError_t conv_init() {
   if ((e = set_lds_attr<2, 1>()) != hipSuccess) return e;
   if ((e = set_lds_attr<1, 1, 0, false, true>()) != hipSuccess) return e;
   if ((e = set_lds_attr<1, 2, 0, false, true>()) != hipSuccess) return e;
+  if ((e = set_lds_attr<1, 0, 0, true, true>()) != hipSuccess) return e;
+  if ((e = set_lds_attr<1, 0, 0, false, true>()) != hipSuccess) return e;
+  if ((e = set_lds_attr<1, 4, 0, false, true>()) != hipSuccess) return e;
   if ((e = set_lds_attr<1, 3>()) != hipSuccess) return e;
   if ((e = set_lds_attr<2, 3>()) != hipSuccess) return e;
   if ((e = set_lds_attr<1, 0, 3>()) != hipSuccess) return e;
@@ -599,15 +630,30 @@ hipError_t launch_conv(const ConvArgs& a_in, int n_samples, hipStream_t s) {
   // XCDs get nothing (B = 1: MISO3 runs 2 samples -> 6 of 8 XCDs idle, the first layer took 114 us instead of ~30); the
   // natural (t, f, n) grid is used then
   const int mode = a.tr2 ? 2 : (a.sf == 2 ? 1 : ((a.padf == 2 && a.Fin == 1 && !a.out_oct) ? 3 : 0));
-  if (a.w1d && a.act && (mode == 1 || mode == 2) && !a.out_oct && !a.in_oct) {
-    // f32w: the frequency-strided layers in 1-D Winograd form along T (32-channel groups, 4-row tiles)
+  const bool w1d_first = mode == 0 && a.Cout <= 32 && a.Cin < 3 * CK;   // (a network's first layer: 12 / 16 -> 24 channels)
+  const bool w1d_half = ((a.Cin - 1) % CK) < CK / 2;
+  const bool w1d_row = (mode == 0 || mode == 1) && a.act && a.Fout == 1 && a.Fin == 3 && a.padf == 0 && a.Cout % 128 == 0;   // (encoder 6: F = 3 -> 1)
+  if (a.w1d && (a.act || w1d_first) && (mode == 1 || mode == 2 || w1d_first || w1d_row) && !a.out_oct && !a.in_oct) {
+    // f32w: the frequency-strided layers (and the first layer) in 1-D Winograd form along T (32-channel groups, 4-row tiles)
     a.cop = 32;
     a.ncg = (a.Cout + 31) / 32;
-    a.NR = mode == 1 ? 9 : 3;
+    if (w1d_row) {
+      // one output row (the encoder's last layer, 64 -> 128 channels on F = 3 -> 1, model.py:50): a row per wave would leave three of
+      // four waves idle -- the waves take a 32-channel group each (MODE 4), the staged input serves all four.  The three staged rows
+      // are the three frequency taps whatever the stride
+      a.ncg = a.Cout / 128;
+      a.NR = 3;
+      const dim3 grid4 = conv_grid(a, n_samples, TT, FT, (n_samples % 8 == 0) ? conv_xcd_env() : 0);
+      hipLaunchKernelGGL((conv3x3_mfma<1, 4, 0, false, true>), grid4, dim3(256), conv_lds_bytes(3, 128, a.Cin, 12), s, a);
+      return hipGetLastError();
+    }
+    a.NR = mode == 1 ? 9 : (mode == 2 ? 3 : 6);
     const dim3 gridw = conv_grid(a, n_samples, TT, FT, (n_samples % 8 == 0) ? conv_xcd_env() : 0);
     const size_t ldsw = conv_lds_bytes(a.NR, 32, a.Cin, 12);
     if (mode == 1) hipLaunchKernelGGL((conv3x3_mfma<1, 1, 0, false, true>), gridw, dim3(256), ldsw, s, a);
-    else hipLaunchKernelGGL((conv3x3_mfma<1, 2, 0, false, true>), gridw, dim3(256), ldsw, s, a);
+    else if (mode == 2) hipLaunchKernelGGL((conv3x3_mfma<1, 2, 0, false, true>), gridw, dim3(256), ldsw, s, a);
+    else if (w1d_half) hipLaunchKernelGGL((conv3x3_mfma<1, 0, 0, true, true>), gridw, dim3(256), ldsw, s, a);
+    else hipLaunchKernelGGL((conv3x3_mfma<1, 0, 0, false, true>), gridw, dim3(256), ldsw, s, a);
     return hipGetLastError();
   }
   a.NR = mode == 3 ? 1 : (mode == 0 ? 6 : f32_rows(a));
