@@ -35,6 +35,19 @@ def test_bench_single_process_line():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     # a clean run carries no MISONET_* variable and runs the product library
     assert d["env_overrides"] == {} and d["library"] == "libmisonet_hip.so", (d["env_overrides"], d["library"])
+    # the headline mode was picked on this box by the recorded rule (round 6): f32w when at least as fast as bf16x6, within 0.5 %
+    hs = d["headline_selection"]
+    assert hs["picked"] == d["dtype"] and d["dtype"] in ("bf16x6", "f32w"), hs
+    cal = hs["calibration_ms_per_step"]
+    assert (cal["f32w"] <= 1.005 * cal["bf16x6"]) == (hs["picked"] == "f32w"), hs
+
+
+def test_bench_fixed_precision_has_no_selection():
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-alt", "--no-profile",
+                        "--precision", "bf16x6"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert d["dtype"] == "bf16x6" and d["headline_selection"] is None
 
 
 def test_bench_line_records_environment():
