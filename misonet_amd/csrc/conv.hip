@@ -435,6 +435,10 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0 && !HALFK
   const int half = lane >> 5, l31 = lane & 31;
 
   STAGE_ISSUE(0)
+  // W1D: the group's bias for the epilogue table, in flight with the first chunk (read where the table is written it was one
+  // more memory round trip in front of the first barrier)
+  float bias_v = 0.f;
+  if (W1D && tid < 32 * NG) bias_v = __builtin_nontemporal_load(a.bias + cg * (32 * NG) + tid);
   // (behind the first chunk's loads: the statistics reads and their float64 arithmetic run while those are in flight -- in front
   // of them every workgroup started with two serial memory latencies)
   // instance-norm parameters of the input channels (normalise-on-load)
@@ -453,10 +457,7 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0 && !HALFK
   }
   // W1D: (bias, ELU(bias)) of the group's 32 channels for the epilogue (the bias is zero padded to the group)
   float2* s_bc = s_nrm + nchunk * CK;
-  if (W1D && tid < 32 * NG) {
-    const float b = a.bias[cg * (32 * NG) + tid];
-    s_bc[tid] = make_float2(b, elu_fast(b));
-  }
+  if (W1D && tid < 32 * NG) s_bc[tid] = make_float2(bias_v, elu_fast(bias_v));
 
   __syncthreads();          // s_nrm visible
   STAGE_COMMIT(0)

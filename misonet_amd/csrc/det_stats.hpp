@@ -54,7 +54,9 @@ MN_HD double dstat_combine(const long long (&Lin)[DS_NL]) {
   long long L[DS_NL];
 #pragma unroll
   for (int i = 0; i < DS_NL; ++i) L[i] = Lin[i];
-  if (L[DS_NL - 1] >= (1ll << 61)) return __builtin_bit_cast(double, 0x7ff8000000000000ll);
+  // (no early return for the poisoned case: a branch on the top limb made the compiler load that limb first, wait for it, and
+  // only then load the other four -- two memory round trips per statistic in front of every conv tile, round 6)
+  const bool poisoned = L[DS_NL - 1] >= (1ll << 61);
   // carry-normalise limbs 0 .. DS_NL-2 into [0, 2^40): the value is then  L[4] 2^160 + ... + L[0]  with one sign
 #pragma unroll
   for (int i = 0; i < DS_NL - 1; ++i) {
@@ -65,7 +67,7 @@ MN_HD double dstat_combine(const long long (&Lin)[DS_NL]) {
   double s = (double)L[DS_NL - 1];
 #pragma unroll
   for (int i = DS_NL - 2; i >= 0; --i) s = fma(s, 0x1p40, (double)L[i]);
-  return s * 0x1p-80;
+  return poisoned ? __builtin_bit_cast(double, 0x7ff8000000000000ll) : s * 0x1p-80;
 }
 
 #if defined(__HIPCC__)
