@@ -188,6 +188,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_few(const ConvArgs a) {
   const float* ob = a.out + (long long)n * a.out_bstride + (long long)a.out_c0 * a.Fout * Tp;
   const __amdgpu_buffer_rsrc_t rs_out = make_rsrc_e(reinterpret_cast<unsigned long long>(ob), (unsigned)a.Cout * P4);
   const int t = t0 + 2 * lane;
+  // (the biases BEFORE the stores: read inside the loop they are re-loaded after every store -- the stores may alias them for all the
+  // compiler knows -- each with its own s_waitcnt vmcnt(0): 4 x COUT serial memory round trips at the end of every workgroup)
+  float bv[COUT];
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) bv[co] = a.bias[co];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int f = f0 + 4 * wave + r;
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_few(const ConvArgs a) {
     const unsigned vo = t < T ? (unsigned)(f * Tp + t) * 4u : 0x80000000u;
 #pragma unroll
     for (int co = 0; co < COUT; ++co) {
-      const float b = a.bias[co];
+      const float b = bv[co];
       const ff2 v = {acc[r][co].x + b, acc[r][co].y + b};
       typedef unsigned int uu2 __attribute__((ext_vector_type(2)));
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uu2, v), rs_out, vo + (unsigned)co * P4, 0, 0);
