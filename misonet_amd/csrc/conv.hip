@@ -265,6 +265,9 @@ __device__ __forceinline__ void w1d_epilogue(const ConvArgs& a, f32x16 (&acc)[4]
 //   best).  Workgroup = 8 output rows, NR = 5 staged rows, 32-channel groups only (two rows x 4 column tiles = 128 registers).
 // MODE 3: stride-1 transposed conv on ONE input row (decoder 0 behind the F = 1 bottleneck, model.py:64): output row f reads
 //   the row through tap kf = 2 - f only; NR = 1, one tap step per wave instead of three (two of them on staged zeros).
+// MODE 4 (W1D only, round 6): a conv whose output is ONE row (encoder 6, 64 -> 128 channels on F = 3 -> 1, model.py:50): the four
+//   waves take a 32-channel group each on one staged tile -- NR = 3 staged rows = the three frequency taps, whatever the stride;
+//   weight slab [4 groups][12][CK][32], statistics slot per group.  (A row per wave left three of four waves idle.)
 //
 // Software pipeline per K-chunk (guide T14, "issue early / write late"): the global loads of chunk k+1 (NR float4 of
 // the input patch + 1 halo scalar + the weight slab share per thread) are issued into registers BEFORE the MFMA loop
@@ -277,8 +280,9 @@ __device__ __forceinline__ void w1d_epilogue(const ConvArgs& a, f32x16 (&acc)[4]
 // that chunk runs half the channel pairs.  It is a separate instantiation because a second fully unrolled chunk_mfma body
 // inside the common kernel costs every MODE 0 instantiation its register allocation (round 3: 74-241 spilled VGPRs, f32
 // mode -36 %); tests/test_build_resources.py holds the hot instantiations to ScratchSize == 0.
-// W1D: MODE 1 / 2 in the 1-D Winograd form above (a.w1d image, 12 taps = 4 positions x 3 kf; 32-channel groups; planar output).
-//   MODE 2 then keeps the 4-row tile (NR = 3): wave w owns row pair w >> 1 over column tile w & 1.
+// W1D: MODE 0 (a network's first layer: <= 16 input channels, no activation), 1, 2 and 4 in the 1-D Winograd form above (a.w1d
+//   image, 12 taps = 4 positions x 3 kf; 32-channel groups; planar output).  MODE 2 then keeps the 4-row tile (NR = 3): wave w owns
+//   row pair w >> 1 over column tile w & 1.  MODE 0 + HALFK: the half-empty chunk runs the first of two half bodies.
 template <int NCO, int MODE, int OCTP = 0, bool HALFK = false, bool W1D = false>
 __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0 && !HALFK && !W1D) ? 3 : 2)) void conv3x3_mfma(const ConvArgs a) {
   static_assert(MODE != 2 || NCO == 1, "stride-2 transposed: two output rows per wave, 32-channel groups");
