@@ -114,11 +114,13 @@ __device__ __forceinline__ void w1d_vr(const W1dRaw& r, float (&v)[4]) {
 }
 // conv with frequency stride SF (2: the down-sampling layers; 1: the network's first layer, round 6): one output row per wave, 128
 // frames = 2 column tiles; s_w = [nu * 3 + kf][CK][32].  NCP: channel pairs of the chunk that hold channels (chunk_mfma)
-template <int NR, int SF = 2, int NCP = CK / 2, int CP0 = 0>
+// NKF: frequency taps the wave runs (3; 1 for MODE 3, where output row f reads the single input row through tap 2 - f only: the
+// caller hands in s_w advanced to that tap)
+template <int NR, int SF = 2, int NCP = CK / 2, int CP0 = 0, int NKF = 3>
 __device__ __forceinline__ void chunk_w1d_s2(f32x16 (&acc)[4][2], const float* s_in, const float* s_w, int frel, int half, int l31) {
   const float* wb = s_w + half * 32 + l31;
   const float* ib0 = s_in + (half * NR + SF * frel) * TW + 2 * l31 + 3;
-  constexpr int NSTEP = 3 * NCP;
+  constexpr int NSTEP = NKF * NCP;
   W1dRaw r0[2], r1[2];
   float u[2][4];
 #define W1D_LOAD(ST, BUF)                                                                        \
@@ -280,14 +282,14 @@ __device__ __forceinline__ void w1d_epilogue(const ConvArgs& a, f32x16 (&acc)[4]
 // that chunk runs half the channel pairs.  It is a separate instantiation because a second fully unrolled chunk_mfma body
 // inside the common kernel costs every MODE 0 instantiation its register allocation (round 3: 74-241 spilled VGPRs, f32
 // mode -36 %); tests/test_build_resources.py holds the hot instantiations to ScratchSize == 0.
-// W1D: MODE 0 (a network's first layer: <= 16 input channels, no activation), 1, 2 and 4 in the 1-D Winograd form above (a.w1d
+// W1D: MODE 0 (a network's first layer: <= 16 input channels, no activation), 1, 2, 3 and 4 in the 1-D Winograd form above (a.w1d
 //   image, 12 taps = 4 positions x 3 kf; 32-channel groups; planar output).  MODE 2 then keeps the 4-row tile (NR = 3): wave w owns
 //   row pair w >> 1 over column tile w & 1.  MODE 0 + HALFK: the half-empty chunk runs the first of two half bodies.
 template <int NCO, int MODE, int OCTP = 0, bool HALFK = false, bool W1D = false>
 __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0 && !HALFK && !W1D) ? 3 : 2)) void conv3x3_mfma(const ConvArgs a) {
   static_assert(MODE != 2 || NCO == 1, "stride-2 transposed: two output rows per wave, 32-channel groups");
   static_assert(MODE != 4 || W1D, "MODE 4 exists in the W1D form only");
-  static_assert(!W1D || (NCO == 1 && OCTP == 0 && (MODE == 0 || (!HALFK && (MODE == 1 || MODE == 2 || MODE == 4)))),
+  static_assert(!W1D || (NCO == 1 && OCTP == 0 && (MODE == 0 || (!HALFK && (MODE == 1 || MODE == 2 || MODE == 3 || MODE == 4)))),
                 "W1D: the frequency-strided layers and the first layer, 32-channel groups, planar output");
   constexpr int COP = NCO * 32;
   constexpr int NR = MODE == 0 ? 6 : (MODE == 1 ? 9 : (MODE == 2 ? (W1D ? 3 : 5) : (MODE == 4 ? 3 : 1)));
@@ -477,6 +479,7 @@ __global__ __launch_bounds__(256, ((NCO == 1 && MODE != 2 && OCTP == 0 && !HALFK
       if (row_ok) {
         if (TR2) chunk_w1d_tr2(wacc, s_in, s_w, wave >> 1, wave & 1, half, l31);
         else if (MODE == 4) chunk_w1d_s2<NR, SF>(wacc, s_in, s_w + wave * (NTAP * CK * COP), 0, half, l31);
+        else if (MODE == 3) chunk_w1d_s2<NR, SF, CK / 2, 0, 1>(wacc, s_in, s_w + (2 - wave) * (CK * COP), 0, half, l31);   // (tap kf = 2 - f of staged row 0)
         else if (HALFK) {
           // (two half bodies in sequence, the second skipped for the half-empty last chunk: an if / else between a full and a half
           // body costs the instantiation its register allocation -- 432 bytes of scratch)
@@ -596,6 +599,7 @@ hipError_t conv_init() {
   if ((e = set_lds_attr<1, 0, 0, true, true>()) != hipSuccess) return e;
   if ((e = set_lds_attr<1, 0, 0, false, true>()) != hipSuccess) return e;
   if ((e = set_lds_attr<1, 4, 0, false, true>()) != hipSuccess) return e;
+  if ((e = set_lds_attr<1, 3, 0, false, true>()) != hipSuccess) return e;
   if ((e = set_lds_attr<1, 3>()) != hipSuccess) return e;
   if ((e = set_lds_attr<2, 3>()) != hipSuccess) return e;
   if ((e = set_lds_attr<1, 0, 3>()) != hipSuccess) return e;
@@ -638,7 +642,7 @@ hipError_t launch_conv(const ConvArgs& a_in, int n_samples, hipStream_t s) {
   const bool w1d_first = mode == 0 && a.Cout <= 32 && a.Cin < 3 * CK;   // (a network's first layer: 12 / 16 -> 24 channels)
   const bool w1d_half = ((a.Cin - 1) % CK) < CK / 2;
   const bool w1d_row = (mode == 0 || mode == 1) && a.act && a.Fout == 1 && a.Fin == 3 && a.padf == 0 && a.Cout % 128 == 0;   // (encoder 6: F = 3 -> 1)
-  if (a.w1d && (a.act || w1d_first) && (mode == 1 || mode == 2 || w1d_first || w1d_row) && !a.out_oct && !a.in_oct) {
+  if (a.w1d && (a.act || w1d_first) && (mode == 1 || mode == 2 || mode == 3 || w1d_first || w1d_row) && !a.out_oct && !a.in_oct) {
     // f32w: the frequency-strided layers (and the first layer) in 1-D Winograd form along T (32-channel groups, 4-row tiles)
     a.cop = 32;
     a.ncg = (a.Cout + 31) / 32;
@@ -652,11 +656,12 @@ hipError_t launch_conv(const ConvArgs& a_in, int n_samples, hipStream_t s) {
       hipLaunchKernelGGL((conv3x3_mfma<1, 4, 0, false, true>), grid4, dim3(256), conv_lds_bytes(3, 128, a.Cin, 12), s, a);
       return hipGetLastError();
     }
-    a.NR = mode == 1 ? 9 : (mode == 2 ? 3 : 6);
+    a.NR = mode == 1 ? 9 : (mode == 2 ? 3 : (mode == 3 ? 1 : 6));
     const dim3 gridw = conv_grid(a, n_samples, TT, FT, (n_samples % 8 == 0) ? conv_xcd_env() : 0);
     const size_t ldsw = conv_lds_bytes(a.NR, 32, a.Cin, 12);
     if (mode == 1) hipLaunchKernelGGL((conv3x3_mfma<1, 1, 0, false, true>), gridw, dim3(256), ldsw, s, a);
     else if (mode == 2) hipLaunchKernelGGL((conv3x3_mfma<1, 2, 0, false, true>), gridw, dim3(256), ldsw, s, a);
+    else if (mode == 3) hipLaunchKernelGGL((conv3x3_mfma<1, 3, 0, false, true>), gridw, dim3(256), ldsw, s, a);
     else if (w1d_half) hipLaunchKernelGGL((conv3x3_mfma<1, 0, 0, true, true>), gridw, dim3(256), ldsw, s, a);
     else hipLaunchKernelGGL((conv3x3_mfma<1, 0, 0, false, true>), gridw, dim3(256), ldsw, s, a);
     return hipGetLastError();

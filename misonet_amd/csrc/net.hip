@@ -1087,7 +1087,7 @@ int misonet_net_commit(misonet_net* n) {
         if ((c.Cout & 31) == 16) c.ww16_off = take((long long)(c.Cin / 8) * 2048);
       }
       // stride-2 convs / transposed convs, and a network's first layer (12 / 16 -> 24 channels): 1-D Winograd image along T
-      if (((c.tr2 || c.sf == 2) && c.act) || (!c.transposed && c.sf == 1 && c.padf == 0 && n->bufs[c.in_buf].F == 3 && c.Cout % 128 == 0 && c.act) || (!c.transposed && c.sf == 1 && !(c.padf == 2 && n->bufs[c.in_buf].F == 1) && c.Cin < 3 * CK && c.Cout <= 32))
+      if (((c.tr2 || c.sf == 2) && c.act) || (c.transposed && c.sf == 1 && !c.tr2 && c.padf == 2 && n->bufs[c.in_buf].F == 1 && c.act) || (!c.transposed && c.sf == 1 && c.padf == 0 && n->bufs[c.in_buf].F == 3 && c.Cout % 128 == 0 && c.act) || (!c.transposed && c.sf == 1 && !(c.padf == 2 && n->bufs[c.in_buf].F == 1) && c.Cin < 3 * CK && c.Cout <= 32))
         c.w1d_off = take((long long)((c.Cout + 31) / 32) * nchunk * 12 * CK * 32);
       if (c.Cout <= 4 && c.sf == 1 && !c.tr2 && !c.act && c.Cin % 4 == 0 && c.Cin <= 256) c.wsm_off = take((long long)c.Cin * 36);
       if (MN_ALT_MODES && !c.transposed && c.sf == 1 && c.padf == 1 && c.Cin % 8 == 0 && c.Cin >= 24 && c.Cin <= 256)

@@ -28,6 +28,7 @@ HOT = [
     "mn::conv3x3_mfma<1, 1, 0, false, true>", "mn::conv3x3_mfma<1, 2, 0, false, true>",          # f32w: stride-2 convs / transposed convs, 1-D Winograd along T
     "mn::conv3x3_mfma<1, 0, 0, true, true>", "mn::conv3x3_mfma<1, 0, 0, false, true>",           # f32w: the first layers (12 / 16 input channels) in that form
     "mn::conv3x3_mfma<1, 4, 0, false, true>",                                             # f32w: encoder 6 (one output row: a channel group per wave)
+    "mn::conv3x3_mfma<1, 3, 0, false, true>",                                             # f32w: decoder 0 (one input row, one tap per output row) in the 1-D form
     "mn::conv3x3_x6_first<3>", "mn::conv3x3_x6_first<4>",                          # first layer in bf16x6 (round 4)
     "mn::conv3x3_bf16x6<0, 8, false, 4, false, false, 0>", "mn::conv3x3_bf16x6<0, 8, false, 3, false, false, 0>",    # 38 % + 28 % of the bf16x6 step
     "mn::conv3x3_bf16x6<0, 8, false, 4, false, true, 0>",                             # F <= 31 layers (two statistic units)
