@@ -39,7 +39,9 @@ def test_bench_single_process_line():
     hs = d["headline_selection"]
     assert hs["picked"] == d["dtype"] and d["dtype"] in ("bf16x6", "f32w"), hs
     cal = hs["calibration_ms_per_step"]
-    assert (cal["f32w"] <= 1.005 * cal["bf16x6"]) == (hs["picked"] == "f32w"), hs
+    ratio = cal["f32w"] / cal["bf16x6"]
+    if abs(ratio - 1.005) > 5e-4:                 # (the line carries the times rounded to 10 us: no verdict at the threshold itself)
+        assert (ratio <= 1.005) == (hs["picked"] == "f32w"), hs
 
 
 def test_bench_fixed_precision_has_no_selection():
