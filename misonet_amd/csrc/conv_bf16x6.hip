@@ -803,27 +803,43 @@ __global__ __launch_bounds__(256, 3) void conv3x3_x6_first(const ConvArgs a, con
   for (int kc = 0; kc < nchunk; ++kc) {
     if (kc) __syncthreads();                                   // the previous chunk's images are consumed
     // ---- stage: 780 (row, frame) units x 8 channels -> three bf16 part images; out-of-image units are zeros ----
+    // (round 6: the chunk's weight image goes in flight first, all pieces at once, and is written to the LDS last -- as "load, wait,
+    // store" per piece behind the patch it was four more serial memory round trips per chunk: 1.18 -> 1.09 ms per step.  Double-
+    // buffering the patch loads as well does not fit the 168 registers of three workgroups per CU: measured at two per CU, 1.12 ms.
+    // The 16-24 bytes of scratch this costs hold staging temporaries outside the MFMA loop)
+    constexpr int NIT = (XN + 255) / 256, NWI = (X6_WU + 255) / 256;
+    const u32x4_t* wsrc = wimg + (long long)kc * X6_WU;
+    u32x4_t wreg[NWI];
 #pragma unroll
-    for (int it = 0; it < (XN + 255) / 256; ++it) {
+    for (int iw = 0; iw < NWI; ++iw) {                       // (in flight under the staging of the patch)
+      const int uw = tid + 256 * iw;
+      wreg[iw] = wsrc[uw < X6_WU ? uw : X6_WU - 1];
+    }
+    float v[1][8];
+#define X6F_LOAD(IT, SL)                                                                                         \
+    {                                                                                                            \
+      const int u_ = tid + 256 * (IT);                                                                           \
+      const int r_ = u_ / X6_TW, j_ = u_ - r_ * X6_TW;                                                           \
+      const int fin_ = f0 - a.padf + r_, t_ = t0 - 1 + j_;                                                       \
+      const bool ok_ = u_ < XN && fin_ >= 0 && fin_ < Fin && t_ >= 0 && t_ < T;                                  \
+      const unsigned vo_ = ok_ ? ((unsigned)fin_ * (unsigned)Tp + (unsigned)t_) * 4u : 0x80000000u;              \
+      _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                            \
+        const int c_ = kc * 8 + e;                          /* (the SGPR offset is not bounds-checked: clamp the channel) */ \
+        const int cc_ = c_ < Cin ? c_ : Cin - 1;                                                                 \
+        v[SL][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, vo_, (unsigned)cc_ * plane_b, 0)); \
+      }                                                                                                          \
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      X6F_LOAD(it, 0)
       const int u = tid + 256 * it;
       if (u < XN) {
-        const int r = u / X6_TW, j = u - r * X6_TW;
-        const int fin = f0 - a.padf + r, t = t0 - 1 + j;
-        const bool ok = fin >= 0 && fin < Fin && t >= 0 && t < T;
-        const unsigned vo = ok ? ((unsigned)fin * (unsigned)Tp + (unsigned)t) * 4u : 0x80000000u;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int c = kc * 8 + e;                            // (the SGPR offset is not bounds-checked: clamp the channel)
-          const int cc = c < Cin ? c : Cin - 1;
-          v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, vo, (unsigned)cc * plane_b, 0));
-          if (c >= Cin) v[e] = 0.f;
-        }
         u32x4_t ph, pm, pl;
 #pragma unroll
         for (int e2 = 0; e2 < 4; ++e2) {
+          const float x0 = (kc * 8 + 2 * e2 < Cin) ? v[0][2 * e2] : 0.f, x1 = (kc * 8 + 2 * e2 + 1 < Cin) ? v[0][2 * e2 + 1] : 0.f;
           unsigned a_, b_, c_;
-          split3_pair_t(v[2 * e2], v[2 * e2 + 1], a_, b_, c_);
+          split3_pair_t(x0, x1, a_, b_, c_);
           ph[e2] = a_; pm[e2] = b_; pl[e2] = c_;
         }
         reinterpret_cast<u32x4_t*>(s_x)[u] = ph;
@@ -831,11 +847,11 @@ __global__ __launch_bounds__(256, 3) void conv3x3_x6_first(const ConvArgs a, con
         reinterpret_cast<u32x4_t*>(s_x)[2 * XN + u] = pl;
       }
     }
-    const u32x4_t* wsrc = wimg + (long long)kc * X6_WU;
+#undef X6F_LOAD
 #pragma unroll
-    for (int it = 0; it < (X6_WU + 255) / 256; ++it) {
+    for (int it = 0; it < NWI; ++it) {
       const int u = tid + 256 * it;
-      if (u < X6_WU) reinterpret_cast<u32x4_t*>(s_w)[u] = wsrc[u];
+      if (u < X6_WU) reinterpret_cast<u32x4_t*>(s_w)[u] = wreg[it];
     }
     __syncthreads();
     if (wave_live) chunk_mfma6<NR, 1, false, FTR>(acc, s_x, s_w, wave, half, l31);
